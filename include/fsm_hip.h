@@ -1,0 +1,229 @@
+/*
+ * fsm_hip.h -- C ABI of libfsm_hip.so: batched DFA execution on MI355X (gfx950).
+ *
+ * Drop-in boundary for ONE path of katef/libfsm: "walk a finished DFA over
+ * input bytes and report accept/reject + the end state".  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Two layers live in the one shared object:
+ *
+ *   1. core   -- takes a flat DFA description (struct fsm_hip_dfa_desc) and
+ *                raw byte buffers.  No dependency on libfsm at all.
+ *   2. shim   -- takes libfsm's own `const struct fsm *` and reads it through
+ *                libfsm's PUBLIC API only (fsm_countstates, fsm_getstart,
+ *                fsm_isend, fsm_walk_edges, fsm_all/fsm_isdfa,
+ *                fsm_countcaptures, fsm_eager_output_count, fsm_endid_count/get).
+ *                Those symbols are resolved with dlsym(RTLD_DEFAULT) on first
+ *                use, i.e. from whichever libfsm the host program already
+ *                links, so libfsm_hip.so itself loads without libfsm.
+ *
+ * Error convention follows the reference: functions returning int give
+ * -1 + errno on failure (cf. fsm_exec, src/libfsm/exec.c:106-114), pointer
+ * returning functions give NULL + errno (cf. fsm_vm_compile, src/libfsm/vm.c:88-131).
+ * There is NO CPU fallback: without a usable HIP device every exec call fails
+ * with -1/ENODEV.
+ */
+#ifndef FSM_HIP_H
+#define FSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* libfsm's own opaque/public types, forward-declared exactly as the reference
+ * does (include/fsm/fsm.h:13, :24, :28; include/fsm/capture.h:21-24). */
+struct fsm;
+struct fsm_capture;
+typedef unsigned int fsm_state_t;   /* include/fsm/fsm.h:24 */
+typedef unsigned int fsm_end_id_t;  /* include/fsm/fsm.h:28 */
+
+/* Value written to end_out[i] for a rejected input.  The reference leaves *end
+ * untouched on reject (src/libfsm/exec.c:133-138, :153-155); a batch needs a
+ * sentinel instead.  fsm_edge.state is 24 bit (src/libfsm/internal.h:48) so
+ * no real state id can collide with it. */
+#define FSM_HIP_NO_MATCH 0xFFFFFFFFu
+
+/* ------------------------------------------------------------------ */
+/* flat DFA description (core layer input)                            */
+/* ------------------------------------------------------------------ */
+
+/* One labelled edge group: bytes lo..hi (inclusive) go to state `to`.
+ * This is the byte-range form of the reference's struct edge_group
+ * {uint64 symbols[4]; fsm_state_t to} (src/adt/edgeset.c:34-41) and of the
+ * codegen IR's struct ir_range (src/libfsm/print/ir.h:23-108). */
+struct fsm_hip_range {
+	uint8_t  lo, hi;
+	uint16_t reserved;
+	uint32_t to;
+};
+
+struct fsm_hip_dfa_desc {
+	uint32_t nstates;                    /* fsm_countstates() */
+	uint32_t start;                      /* fsm_getstart()    */
+	const uint32_t *edge_off;            /* nstates+1 CSR offsets into ranges[] */
+	const struct fsm_hip_range *ranges;  /* ranges of one state must not overlap (DFA) */
+	const uint8_t  *is_end;              /* nstates; fsm_isend() */
+	const uint32_t *endid_off;           /* nstates+1 CSR offsets into endids[], or NULL */
+	const uint32_t *endids;              /* sorted unique per state (fsm_endid_get order) */
+};
+
+/* flags for fsm_hip_dfa_create / fsm_hip_compile */
+enum {
+	FSM_HIP_LAYOUT_AUTO   = 0,   /* planner picks by table size            */
+	FSM_HIP_LAYOUT_TINY   = 1,   /* <=16 states: column-in-register walk   */
+	FSM_HIP_LAYOUT_LDS    = 2,   /* class-compressed dense table in LDS    */
+	FSM_HIP_LAYOUT_COMB   = 3,   /* column-default + comb exceptions, LDS  */
+	FSM_HIP_LAYOUT_GLOBAL = 4,   /* class-compressed table in HBM/L2       */
+	FSM_HIP_LAYOUT_MASK   = 0xf,
+	FSM_HIP_NO_EARLY_RETIRE = 0x10  /* never stop a wavefront early on absorbing states */
+};
+
+struct fsm_hip_dfa;   /* opaque: device-resident transition table + host-side end-id table */
+
+struct fsm_hip_dfa_info {
+	uint32_t nstates;        /* as given (without the synthetic dead state) */
+	uint32_t nclasses;       /* byte equivalence classes */
+	uint32_t layout;         /* FSM_HIP_LAYOUT_* actually chosen */
+	uint32_t nabsorbing;     /* states whose every byte loops to itself (+ dead state) */
+	uint64_t table_bytes;    /* bytes of the device transition table */
+	uint32_t lds_bytes;      /* LDS bytes per workgroup */
+	uint32_t waves_per_block;
+	uint32_t device;         /* HIP device ordinal the table lives on */
+	uint32_t reserved;
+};
+
+/* Build the device table from a flat description.  Replaces, for this path,
+ * fsm_vm_compile_with_options() (src/libfsm/vm.c:88-131): DFA -> executable
+ * form, self-contained after return (the caller may free `desc`, like retest
+ * frees the fsm right after fsm_runner_initialize, src/retest/main.c:1056-1058).
+ * NULL + errno=EINVAL if desc is not a DFA (overlapping ranges, bad ids),
+ * ENODEV without a HIP device, ENOMEM. */
+struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc *desc, unsigned flags);
+
+/* cf. fsm_vm_free() include/fsm/vm.h:56 */
+void fsm_hip_dfa_free(struct fsm_hip_dfa *dfa);
+
+int fsm_hip_dfa_info(const struct fsm_hip_dfa *dfa, struct fsm_hip_dfa_info *out);
+
+/* ------------------------------------------------------------------ */
+/* batched execution (the hot path)                                   */
+/* ------------------------------------------------------------------ */
+
+/* Run n independent inputs through the DFA.  Input i is the len[i] bytes at
+ * base + i*stride (len == NULL: every input is exactly `stride` bytes).
+ * For each input this computes exactly what
+ *     fsm_exec(fsm, getc_over(ptr,len), &opaque, &end, NULL)
+ * computes (src/libfsm/exec.c:85-167): end_out[i] = end state if it returned 1,
+ * FSM_HIP_NO_MATCH if it returned 0.  accept_bitmap (optional, may be NULL)
+ * gets bit (i%64) of word (i/64) set iff input i matched; it must hold
+ * ceil(n/64) words.  end_out may be NULL if only the bitmap is wanted.
+ * Host pointers; data is staged through HBM (PCIe-inclusive).
+ * Replaces the per-input loop over fsm_runner_run() in retest/reperf
+ * (src/retest/main.c:1114, src/retest/reperf.c:772-784).
+ * Returns 0, or -1 + errno. */
+int fsm_hip_exec_batch(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+
+/* Same, inputs packed back to back: input i is bytes [off[i], off[i+1]) of base. */
+int fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+
+/* Same as fsm_hip_exec_batch but every pointer is a DEVICE pointer on the
+ * dfa's device and the launch is asynchronous on `hip_stream` (a hipStream_t
+ * passed as void *, NULL = default stream).  Nothing crosses PCIe. */
+int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+
+/* Device pointers, packed inputs with a device-resident offsets array. */
+int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+
+/* Time of the most recent *_device launch on this dfa, measured with HIP
+ * events recorded on the launch stream around the walk kernel only.
+ * Blocks until that launch finished.  Returns milliseconds, or <0 on error. */
+double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *dfa);
+
+/* ------------------------------------------------------------------ */
+/* end-ids (host side, by end state)                                  */
+/* ------------------------------------------------------------------ */
+
+/* cf. fsm_endid_count() src/libfsm/endids.c:653-684 */
+size_t fsm_hip_endid_count(const struct fsm_hip_dfa *dfa, uint32_t end_state);
+
+/* cf. fsm_endid_get() src/libfsm/endids.c:686-755: ids sorted ascending,
+ * unique; returns 0 if id_buf_count is too small, 1 otherwise. */
+int fsm_hip_endid_get(const struct fsm_hip_dfa *dfa, uint32_t end_state,
+	size_t id_buf_count, uint32_t *id_buf);
+
+/* ------------------------------------------------------------------ */
+/* libfsm-facing shim                                                 */
+/* ------------------------------------------------------------------ */
+
+/* struct fsm * -> device table.  Checks ONCE what fsm_exec checks on every
+ * call (fsm_all(fsm, fsm_isdfa) and fsm_getstart, src/libfsm/exec.c:106-114).
+ * NULL + errno=EINVAL if not a DFA / no start; errno=ENOTSUP if the fsm uses
+ * captures (fsm_countcaptures > 0) or eager outputs, which need the
+ * reference's per-byte host callbacks; errno=ENOSYS if libfsm's symbols are
+ * not present in the process. */
+struct fsm_hip_dfa *fsm_hip_compile(const struct fsm *fsm, unsigned flags);
+
+/* Same signature and result as fsm_exec() (include/fsm/fsm.h:560-562):
+ * 1 and *end on match, 0 on no match (*end untouched), -1 + errno on error.
+ * Drains fsm_getc to EOF (the reference stops pulling at the first missing
+ * edge, src/libfsm/exec.c:133-138; the result is the same).  captures must
+ * be NULL.  One input = one GPU launch: for plumbing/compat, not speed. */
+int fsm_hip_exec(const struct fsm_hip_dfa *dfa,
+	int (*fsm_getc)(void *opaque), void *opaque,
+	fsm_state_t *end, struct fsm_capture *captures);
+
+/* cf. fsm_vm_match_buffer() src/libfsm/vm.c:218-229: 1 / 0, -1 on error. */
+int fsm_hip_match_buffer(const struct fsm_hip_dfa *dfa, const char *buf, size_t n);
+
+/* cf. fsm_vm_match_file() src/libfsm/vm.c:188-216 (reads the whole file). */
+int fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f);
+
+/* Flatten a struct fsm * into a malloc'd description (free with
+ * fsm_hip_desc_free).  Exposed so callers can serialise the table. */
+struct fsm_hip_dfa_desc *fsm_hip_flatten(const struct fsm *fsm);
+void fsm_hip_desc_free(struct fsm_hip_dfa_desc *desc);
+
+/* ------------------------------------------------------------------ */
+/* synthetic input generator (benchmarks and parity tests)            */
+/* ------------------------------------------------------------------ */
+
+/* Counter-based generator, identical on host and device:
+ *   byte(i, t) = alphabet[ mix64(seed ^ (i * 0x9E3779B97F4A7C15) ^ (t >> 3)) >> (8 * (t & 7)) & 0xff  (mod nalpha) ]
+ * with i the GLOBAL input index (first_index + local row).  alphabet == NULL
+ * means all 256 byte values.  If plant_len > 0, every plant_every-th input
+ * (i % plant_every == 0) has `plant` copied at offset
+ * mix64(seed ^ i) % (stride - plant_len + 1).
+ * d_base is a device pointer to n rows of `stride` bytes. */
+int fsm_hip_gen_inputs_device(void *d_base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *plant, unsigned plant_len, unsigned plant_every,
+	void *hip_stream);
+
+/* Host twin of the generator (same bytes). */
+void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *plant, unsigned plant_len, unsigned plant_every);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int fsm_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FSM_HIP_H */

@@ -1,0 +1,57 @@
+/*
+ * fsm_hip_plan.h -- tuning knobs and table-plan inspection for libfsm_hip.so.
+ *
+ * Not part of the drop-in surface (that is fsm_hip.h).  The plan functions run
+ * entirely on the host and exist so that the table builder -- the counterpart
+ * of the reference's DFA -> dfa_table expansion, src/libfsm/vm/ir.c:649-750 --
+ * can be checked against the oracle on machines without a GPU.  They never
+ * execute an input: there is no CPU matching path in this library.
+ */
+#ifndef FSM_HIP_PLAN_H
+#define FSM_HIP_PLAN_H
+
+#include "fsm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles, 2 generic; -1 auto */
+	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (1,2,4,8)      */
+	FSM_HIP_KNOB_NONTEMPORAL   = 3,  /* direct mode: nontemporal input loads                          */
+	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
+	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
+	FSM_HIP_KNOB_EARLY_RETIRE  = 6   /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
+};
+
+int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
+
+struct fsm_hip_plan;
+
+enum {
+	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[9]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off */
+	FSM_HIP_PLAN_CLS       = 1,  /* u8[256]  */
+	FSM_HIP_PLAN_NEW2OLD   = 2,  /* u32[S1]  */
+	FSM_HIP_PLAN_FIN       = 3,  /* u32[S1]  */
+	FSM_HIP_PLAN_DENSE     = 4,  /* u32[S1*C] */
+	FSM_HIP_PLAN_TINY_COL  = 5,  /* u64[256] */
+	FSM_HIP_PLAN_LDS_TAB   = 6,  /* u16[S1*Cpad] */
+	FSM_HIP_PLAN_COMB      = 7,  /* u32[] */
+	FSM_HIP_PLAN_COMB_DFLT = 8,  /* u32[C] */
+	FSM_HIP_PLAN_COMB_OFF  = 9,  /* u32[S1] */
+	FSM_HIP_PLAN_COMB_FIN  = 10, /* u32[] */
+	FSM_HIP_PLAN_GLOB_TAB  = 11  /* u32[S1*C] */
+};
+
+/* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */
+struct fsm_hip_plan *fsm_hip_plan_create(const struct fsm_hip_dfa_desc *desc, unsigned flags, uint32_t lds_limit);
+void fsm_hip_plan_free(struct fsm_hip_plan *plan);
+/* Borrowed pointer into the plan (count = number of elements). */
+int fsm_hip_plan_get(const struct fsm_hip_plan *plan, int what, const void **data, size_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,569 @@
+/*
+ * fsm_hip.hip -- C ABI of libfsm_hip.so (core layer): table upload, kernel
+ * selection/launch, host staging, end-id lookup, synthetic generator.
+ * See include/fsm_hip.h for the contract of every entry point and the
+ * reference interface (file:line) each one replaces.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fsm_hip.h"
+#include "../../include/fsm_hip_plan.h"
+#include "plan.h"
+#include "walk_kernels.h"
+
+using namespace fsmhip;
+
+/* ------------------------------------------------------------------ */
+
+struct fsm_hip_dfa {
+	Plan plan;
+	int device = 0;
+	int ncu = 256;
+	uint32_t lds_limit = 160u * 1024u;
+	void *d_tab = nullptr;
+	uint32_t *d_fin = nullptr;
+	uint32_t *d_btab = nullptr;
+	WalkArgs proto;
+	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool timed = false;
+	/* tuning knobs (fsm_hip_dfa_tune) */
+	int knob_input_mode = -1;    /* -1 auto */
+	int knob_nb = 0;             /* 0 auto */
+	int knob_nt = 0;
+	int knob_waves = 0;          /* 0 auto */
+	int knob_blocks_per_cu = 0;  /* 0 auto */
+	int knob_early = -1;         /* -1: from flags */
+	unsigned flags = 0;
+};
+
+static int hip_errno(hipError_t e)
+{
+	switch (e) {
+	case hipSuccess: return 0;
+	case hipErrorOutOfMemory: return ENOMEM;
+	case hipErrorNoDevice:
+	case hipErrorInvalidDevice:
+	case hipErrorInsufficientDriver: return ENODEV;
+	case hipErrorInvalidValue: return EINVAL;
+	default: return EIO;
+	}
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: %s -> %s\n", #expr, hipGetErrorString(e_)); \
+	errno = hip_errno(e_); goto fail; } } while (0)
+
+extern "C" int fsm_hip_version(void) { return 100; }
+
+/* ------------------------------------------------------------------ */
+/* create / free / info                                               */
+/* ------------------------------------------------------------------ */
+
+template <class T>
+static hipError_t upload(T **dst, const std::vector<T> &src)
+{
+	*dst = nullptr;
+	size_t bytes = src.size() * sizeof(T);
+	if (bytes == 0) bytes = sizeof(T);
+	hipError_t e = hipMalloc((void **)dst, (bytes + 15) & ~(size_t)15);
+	if (e != hipSuccess) return e;
+	if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+	return e;
+}
+
+extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc *desc, unsigned flags)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		errno = ENODEV; /* no CPU fallback by design */
+		return nullptr;
+	}
+	fsm_hip_dfa *d = new (std::nothrow) fsm_hip_dfa();
+	if (d == nullptr) { errno = ENOMEM; return nullptr; }
+	d->flags = flags;
+	{
+		int v = 0;
+		HIP_TRY(hipGetDevice(&d->device));
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) d->ncu = v;
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) == hipSuccess && v > 0) d->lds_limit = (uint32_t)v;
+		if (d->lds_limit > 160u * 1024u) d->lds_limit = 160u * 1024u;
+	}
+	{
+		int r = build_plan(desc, flags, d->lds_limit, d->plan);
+		if (r != 0) { errno = r; goto fail; }
+	}
+	{
+		Plan &p = d->plan;
+		WalkArgs &a = d->proto;
+		memset(&a, 0, sizeof a);
+		std::vector<uint32_t> btab(256);
+		switch (p.layout) {
+		case FSM_HIP_LAYOUT_TINY: {
+			uint64_t *t = nullptr;
+			HIP_TRY(upload(&t, p.tiny_col));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			a.tab_bytes = 256 * 8;
+			a.start = p.start;
+			a.abs_min = p.abs_min;
+			a.fin_div = 1;
+			d->table_lds = TinyPol::kLdsBytes;
+			break;
+		}
+		case FSM_HIP_LAYOUT_LDS: {
+			uint16_t *t = nullptr;
+			HIP_TRY(upload(&t, p.lds_tab));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b] * 2u;
+			a.tab_bytes = (uint32_t)(p.lds_tab.size() * 2);
+			a.start = p.start * p.row_bytes;
+			a.abs_min = p.abs_min * p.row_bytes;
+			a.fin_div = p.row_bytes;
+			d->table_lds = lds_bytes_btab() + ((a.tab_bytes + 15u) & ~15u);
+			break;
+		}
+		case FSM_HIP_LAYOUT_COMB: {
+			uint32_t *t = nullptr;
+			HIP_TRY(upload(&t, p.comb));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.comb_fin));
+			for (int b = 0; b < 256; b++) btab[b] = (p.comb_dflt[p.cls[b]] << 16) | p.cls[b];
+			a.tab_bytes = (uint32_t)(p.comb.size() * 4);
+			a.start = p.comb_off[p.start];
+			a.abs_min = p.comb_abs_min_off;
+			a.fin_div = 1;
+			d->table_lds = lds_bytes_btab() + ((a.tab_bytes + 15u) & ~15u);
+			break;
+		}
+		case FSM_HIP_LAYOUT_GLOBAL: {
+			uint32_t *t = nullptr;
+			HIP_TRY(upload(&t, p.glob_tab));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b] * 4u;
+			a.tab_bytes = 0;
+			a.start = p.start * p.C * 4u;
+			a.abs_min = p.abs_min * p.C * 4u;
+			a.fin_div = p.C * 4u;
+			d->table_lds = lds_bytes_btab();
+			break;
+		}
+		default:
+			errno = EINVAL;
+			goto fail;
+		}
+		HIP_TRY(upload(&d->d_btab, btab));
+		a.tab = d->d_tab;
+		a.fin = d->d_fin;
+		a.btab = d->d_btab;
+		a.early = (flags & FSM_HIP_NO_EARLY_RETIRE) ? 0u : 1u;
+	}
+	HIP_TRY(hipEventCreate(&d->ev0));
+	HIP_TRY(hipEventCreate(&d->ev1));
+	return d;
+fail:
+	{
+		int e = errno;
+		fsm_hip_dfa_free(d);
+		errno = e;
+	}
+	return nullptr;
+}
+
+extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
+{
+	if (d == nullptr) return;
+	if (d->d_tab) (void)hipFree(d->d_tab);
+	if (d->d_fin) (void)hipFree(d->d_fin);
+	if (d->d_btab) (void)hipFree(d->d_btab);
+	if (d->ev0) (void)hipEventDestroy(d->ev0);
+	if (d->ev1) (void)hipEventDestroy(d->ev1);
+	delete d;
+}
+
+/* ------------------------------------------------------------------ */
+/* launch                                                             */
+/* ------------------------------------------------------------------ */
+
+struct LaunchCfg {
+	int mode, nb, nt, waves, blocks_per_cu;
+	uint32_t lds;
+};
+
+static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
+{
+	LaunchCfg c;
+	c.mode = IN_GENERIC;
+	c.nb = 1;
+	c.nt = d->knob_nt;
+	if (fast_ok) {
+		c.mode = d->knob_input_mode >= 0 ? d->knob_input_mode : IN_DIRECT;
+		if (c.mode == IN_LDSDMA && stride % 64u != 0) c.mode = IN_DIRECT;
+		if (c.mode == IN_DIRECT) {
+			c.nb = d->knob_nb > 0 ? d->knob_nb : 4;
+			while (c.nb > 1 && (stride / 16u) % (unsigned)c.nb != 0) c.nb >>= 1;
+		}
+	} else if (d->knob_input_mode == IN_GENERIC || true) {
+		c.mode = IN_GENERIC;
+	}
+	const uint32_t per_wave = c.mode == IN_LDSDMA ? 4096u : 0u;
+	/* waves per block: as many as LDS allows, 16 at most */
+	int waves = d->knob_waves > 0 ? d->knob_waves : 16;
+	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves >>= 1;
+	c.waves = waves;
+	c.lds = d->table_lds + (uint32_t)waves * per_wave;
+	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
+	if (bpc * waves > 32) bpc = 32 / waves;
+	if (bpc < 1) bpc = 1;
+	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
+	c.blocks_per_cu = bpc;
+	return c;
+}
+
+template <class Pol>
+static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	void (*k)(const WalkArgs) = nullptr;
+	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
+	else if (c.mode == IN_LDSDMA) k = walk_ldsdma<Pol>;
+	else if (c.nt) {
+		switch (c.nb) {
+		case 1: k = walk_direct<Pol, 1, true>; break;
+		case 2: k = walk_direct<Pol, 2, true>; break;
+		case 4: k = walk_direct<Pol, 4, true>; break;
+		default: k = walk_direct<Pol, 8, true>; break;
+		}
+	} else {
+		switch (c.nb) {
+		case 1: k = walk_direct<Pol, 1, false>; break;
+		case 2: k = walk_direct<Pol, 2, false>; break;
+		case 4: k = walk_direct<Pol, 4, false>; break;
+		default: k = walk_direct<Pol, 8, false>; break;
+		}
+	}
+	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
+	return hipGetLastError();
+}
+
+static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s)
+{
+	if (a.n == 0) return 0;
+	LaunchCfg c = pick_cfg(d, fast_ok, a.stride);
+	if (c.mode == IN_DIRECT && c.nb == 8) { /* nothing */ }
+	const uint64_t ntiles = (a.n + 63) / 64;
+	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
+	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
+	if (nblocks > cap) nblocks = cap;
+	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early;
+	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
+	hipError_t e = hipEventRecord(md->ev0, s);
+	if (e == hipSuccess) {
+		dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
+		switch (d->plan.layout) {
+		case FSM_HIP_LAYOUT_TINY:   e = launch_pol<TinyPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_LDS:    e = launch_pol<LdsPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMB:   e = launch_pol<CombPol>(c, a, grid, block, s); break;
+		default:                    e = launch_pol<GlobPol>(c, a, grid, block, s); break;
+		}
+	}
+	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
+	if (e != hipSuccess) {
+		if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: launch -> %s\n", hipGetErrorString(e));
+		errno = hip_errno(e);
+		return -1;
+	}
+	md->timed = true;
+	return 0;
+}
+
+extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	if (d == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = stride;
+	a.len = d_len;
+	a.off = nullptr;
+	a.n = n;
+	a.end_out = d_end_out;
+	a.bitmap = d_accept_bitmap;
+	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	if (d == nullptr || (n != 0 && d_off == nullptr)) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = 0;
+	a.len = nullptr;
+	a.off = d_off;
+	a.n = n;
+	a.end_out = d_end_out;
+	a.bitmap = d_accept_bitmap;
+	return launch_walk(d, a, false, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
+{
+	if (d == nullptr || !d->timed) return -1.0;
+	float ms = 0.f;
+	if (hipEventSynchronize(d->ev1) != hipSuccess) return -1.0;
+	if (hipEventElapsedTime(&ms, d->ev0, d->ev1) != hipSuccess) return -1.0;
+	return (double)ms;
+}
+
+/* ------------------------------------------------------------------ */
+/* host-buffer front: stage through HBM                                */
+/* ------------------------------------------------------------------ */
+
+static int exec_host(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t in_bytes, size_t stride,
+	const uint32_t *len, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	unsigned char *d_in = nullptr;
+	uint32_t *d_len = nullptr, *d_end = nullptr;
+	uint64_t *d_off = nullptr, *d_bm = nullptr;
+	const size_t nwords = (n + 63) / 64;
+	int rc = -1;
+	/* +32: the generic kernel reads whole aligned 16-byte chunks */
+	HIP_TRY(hipMalloc((void **)&d_in, in_bytes + 32));
+	if (in_bytes) HIP_TRY(hipMemcpy(d_in, base, in_bytes, hipMemcpyHostToDevice));
+	if (len) {
+		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	if (off) {
+		HIP_TRY(hipMalloc((void **)&d_off, (n + 1) * sizeof(uint64_t)));
+		HIP_TRY(hipMemcpy(d_off, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+	}
+	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
+	if (accept_bitmap) HIP_TRY(hipMalloc((void **)&d_bm, nwords * sizeof(uint64_t)));
+	if (off) {
+		if (fsm_hip_exec_batch_offsets_device(d, d_in, d_off, n, d_end, d_bm, nullptr) != 0) goto fail;
+	} else {
+		if (fsm_hip_exec_batch_device(d, d_in, stride, d_len, n, d_end, d_bm, nullptr) != 0) goto fail;
+	}
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if (accept_bitmap) HIP_TRY(hipMemcpy(accept_bitmap, d_bm, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	rc = 0;
+fail:
+	{
+		int e = errno;
+		if (d_in) (void)hipFree(d_in);
+		if (d_len) (void)hipFree(d_len);
+		if (d_off) (void)hipFree(d_off);
+		if (d_end) (void)hipFree(d_end);
+		if (d_bm) (void)hipFree(d_bm);
+		errno = e;
+	}
+	return rc;
+}
+
+extern "C" int fsm_hip_exec_batch(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (n != 0 && base == nullptr && stride != 0) { errno = EINVAL; return -1; }
+	if (len != nullptr)
+		for (size_t i = 0; i < n; i++)
+			if (len[i] > stride) { errno = EINVAL; return -1; }
+	return exec_host(d, base, n * stride, stride, len, nullptr, n, end_out, accept_bitmap);
+}
+
+extern "C" int fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (n != 0 && off == nullptr) { errno = EINVAL; return -1; }
+	for (size_t i = 0; i < n; i++)
+		if (off[i + 1] < off[i]) { errno = EINVAL; return -1; }
+	const size_t total = n ? (size_t)off[n] : 0;
+	if (total != 0 && base == nullptr) { errno = EINVAL; return -1; }
+	return exec_host(d, base, total, 0, nullptr, off, n, end_out, accept_bitmap);
+}
+
+/* ------------------------------------------------------------------ */
+/* info / tuning / end-ids                                            */
+/* ------------------------------------------------------------------ */
+
+extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_info *out)
+{
+	if (d == nullptr || out == nullptr) { errno = EINVAL; return -1; }
+	memset(out, 0, sizeof *out);
+	const Plan &p = d->plan;
+	out->nstates = p.nstates;
+	out->nclasses = p.C;
+	out->layout = p.layout;
+	out->nabsorbing = p.nabsorbing;
+	switch (p.layout) {
+	case FSM_HIP_LAYOUT_TINY: out->table_bytes = 256 * 8; break;
+	case FSM_HIP_LAYOUT_LDS: out->table_bytes = p.lds_tab.size() * 2; break;
+	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4; break;
+	default: out->table_bytes = p.glob_tab.size() * 4; break;
+	}
+	LaunchCfg c = pick_cfg(d, true, 1024);
+	out->lds_bytes = c.lds;
+	out->waves_per_block = (uint32_t)c.waves;
+	out->device = (uint32_t)d->device;
+	return 0;
+}
+
+extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
+{
+	if (d == nullptr) { errno = EINVAL; return -1; }
+	switch (knob) {
+	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
+	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
+	case FSM_HIP_KNOB_NONTEMPORAL: d->knob_nt = value; break;
+	case FSM_HIP_KNOB_WAVES: d->knob_waves = value; break;
+	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
+	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
+	default: errno = EINVAL; return -1;
+	}
+	return 0;
+}
+
+extern "C" size_t fsm_hip_endid_count(const struct fsm_hip_dfa *d, uint32_t end_state)
+{
+	if (d == nullptr || end_state >= d->plan.nstates) return 0;
+	return d->plan.endid_off[end_state + 1] - d->plan.endid_off[end_state];
+}
+
+extern "C" int fsm_hip_endid_get(const struct fsm_hip_dfa *d, uint32_t end_state,
+	size_t id_buf_count, uint32_t *id_buf)
+{
+	if (d == nullptr || end_state >= d->plan.nstates) return 0;
+	const uint32_t a = d->plan.endid_off[end_state], b = d->plan.endid_off[end_state + 1];
+	if (b - a > id_buf_count) return 0; /* fsm_endid_get: 0 = buffer too small */
+	for (uint32_t k = a; k < b; k++) id_buf[k - a] = d->plan.endids[k];
+	return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* plan inspection (no device needed; used by the CPU-side tests)      */
+/* ------------------------------------------------------------------ */
+
+struct fsm_hip_plan { Plan p; };
+
+extern "C" struct fsm_hip_plan *fsm_hip_plan_create(const struct fsm_hip_dfa_desc *desc, unsigned flags, uint32_t lds_limit)
+{
+	fsm_hip_plan *pl = new (std::nothrow) fsm_hip_plan();
+	if (pl == nullptr) { errno = ENOMEM; return nullptr; }
+	int r = build_plan(desc, flags, lds_limit ? lds_limit : 160u * 1024u, pl->p);
+	if (r != 0) { delete pl; errno = r; return nullptr; }
+	return pl;
+}
+
+extern "C" void fsm_hip_plan_free(struct fsm_hip_plan *pl) { delete pl; }
+
+extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const void **data, size_t *count)
+{
+	if (pl == nullptr || data == nullptr || count == nullptr) { errno = EINVAL; return -1; }
+	const Plan &p = pl->p;
+	static thread_local uint32_t scalars[16];
+	switch (what) {
+	case FSM_HIP_PLAN_SCALARS:
+		scalars[0] = p.nstates; scalars[1] = p.S1; scalars[2] = p.start; scalars[3] = p.C;
+		scalars[4] = p.abs_min; scalars[5] = p.nabsorbing; scalars[6] = p.layout; scalars[7] = p.row_bytes;
+		scalars[8] = p.comb_abs_min_off;
+		*data = scalars; *count = 9; return 0;
+	case FSM_HIP_PLAN_CLS: *data = p.cls; *count = 256; return 0;
+	case FSM_HIP_PLAN_NEW2OLD: *data = p.new2old.data(); *count = p.new2old.size(); return 0;
+	case FSM_HIP_PLAN_FIN: *data = p.fin.data(); *count = p.fin.size(); return 0;
+	case FSM_HIP_PLAN_DENSE: *data = p.dense.data(); *count = p.dense.size(); return 0;
+	case FSM_HIP_PLAN_TINY_COL: *data = p.tiny_col.data(); *count = p.tiny_col.size(); return 0;
+	case FSM_HIP_PLAN_LDS_TAB: *data = p.lds_tab.data(); *count = p.lds_tab.size(); return 0;
+	case FSM_HIP_PLAN_COMB: *data = p.comb.data(); *count = p.comb.size(); return 0;
+	case FSM_HIP_PLAN_COMB_DFLT: *data = p.comb_dflt.data(); *count = p.comb_dflt.size(); return 0;
+	case FSM_HIP_PLAN_COMB_OFF: *data = p.comb_off.data(); *count = p.comb_off.size(); return 0;
+	case FSM_HIP_PLAN_COMB_FIN: *data = p.comb_fin.data(); *count = p.comb_fin.size(); return 0;
+	case FSM_HIP_PLAN_GLOB_TAB: *data = p.glob_tab.data(); *count = p.glob_tab.size(); return 0;
+	default: errno = EINVAL; return -1;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* synthetic generator                                                */
+/* ------------------------------------------------------------------ */
+
+static int fill_gen(GenArgs &g, void *base, size_t stride, size_t n, uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *plant, unsigned plant_len, unsigned plant_every)
+{
+	memset(&g, 0, sizeof g);
+	if (nalpha > 256 || plant_len > sizeof g.plant || (plant_len && (plant_every == 0 || plant_len > stride))) return -1;
+	g.base = static_cast<unsigned char *>(base);
+	g.stride = stride; g.n = n; g.first_index = first_index; g.seed = seed;
+	g.nalpha = alphabet ? nalpha : 0;
+	if (g.nalpha) memcpy(g.alphabet, alphabet, g.nalpha);
+	g.plant_len = plant ? plant_len : 0;
+	g.plant_every = plant_every;
+	if (g.plant_len) memcpy(g.plant, plant, g.plant_len);
+	return 0;
+}
+
+extern "C" int fsm_hip_gen_inputs_device(void *d_base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *plant, unsigned plant_len, unsigned plant_every,
+	void *hip_stream)
+{
+	GenArgs g;
+	if (stride == 0 || stride % 8u != 0 || (reinterpret_cast<uintptr_t>(d_base) % 8u) != 0 ||
+	    fill_gen(g, d_base, stride, n, first_index, seed, alphabet, nalpha, plant, plant_len, plant_every) != 0) {
+		errno = EINVAL;
+		return -1;
+	}
+	if (n == 0) return 0;
+	uint64_t total = (uint64_t)n * (stride / 8u);
+	uint64_t blocks = (total + 255) / 256;
+	if (blocks > 256u * 64u) blocks = 256u * 64u;
+	hipLaunchKernelGGL(gen_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), g);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	return 0;
+}
+
+extern "C" void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *plant, unsigned plant_len, unsigned plant_every)
+{
+	GenArgs g;
+	if (fill_gen(g, base, stride, n, first_index, seed, alphabet, nalpha, plant, plant_len, plant_every) != 0) return;
+	for (size_t row = 0; row < n; row++) {
+		const uint64_t gi = first_index + row;
+		unsigned char *p = base + row * stride;
+		for (size_t t = 0; t < stride; t += 8) {
+			uint64_t v = gen_word(g, gi, t / 8);
+			for (size_t k = 0; k < 8 && t + k < stride; k++) p[t + k] = (unsigned char)(v >> (8 * k));
+		}
+		if (g.plant_len != 0 && gi % g.plant_every == 0)
+			memcpy(p + plant_offset(g, gi), g.plant, g.plant_len);
+	}
+}

@@ -1,0 +1,337 @@
+/*
+ * plan.cpp -- host-side table planner (see plan.h).
+ *
+ * Steps:
+ *  1. validate the description (a DFA: ranges of one state do not overlap);
+ *  2. expand to a dense [S1][256] next-state table, "no edge" -> DEAD
+ *     (recipe of src/libfsm/vm/ir.c:649-750 in the reference);
+ *  3. merge identical byte columns into equivalence classes;
+ *  4. renumber states breadth-first from the start state (rows touched early
+ *     in a walk end up adjacent), absorbing states last, DEAD very last, so a
+ *     single compare `state >= abs_min` identifies lanes that can never change
+ *     state again (the reference VM's STOP shortcut, vm/ir.c:763-766);
+ *  5. emit the device image for the chosen layout.
+ */
+#include "plan.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+
+namespace fsmhip {
+
+static const uint32_t NOEDGE = 0xFFFFFFFFu;
+
+uint32_t lds_bytes_tiny() { return 256u * 32u * 8u; }
+uint32_t lds_bytes_btab() { return 256u * 32u * 4u; }
+
+static int build_comb(Plan &p, uint32_t max_entries);
+
+int build_plan(const fsm_hip_dfa_desc *d, unsigned flags, uint32_t lds_limit, Plan &p)
+try {
+	if (d == nullptr || d->nstates == 0 || d->start >= d->nstates ||
+	    d->edge_off == nullptr || d->is_end == nullptr) {
+		return EINVAL;
+	}
+	if (d->nstates >= 0x00FFFFFFu) {
+		return EINVAL; /* fsm_edge.state is 24 bit, src/libfsm/internal.h:48 */
+	}
+	const uint32_t S = d->nstates, S1 = S + 1, DEAD = S;
+	p.nstates = S;
+	p.S1 = S1;
+
+	/* 1+2: dense expansion in the caller's numbering */
+	std::vector<uint32_t> nx((size_t)S1 * 256, DEAD);
+	for (uint32_t s = 0; s < S; s++) {
+		uint32_t a = d->edge_off[s], b = d->edge_off[s + 1];
+		if (b < a || (b > a && d->ranges == nullptr)) return EINVAL;
+		uint32_t *row = &nx[(size_t)s * 256];
+		bool seen[256];
+		memset(seen, 0, sizeof seen);
+		for (uint32_t k = a; k < b; k++) {
+			const fsm_hip_range &r = d->ranges[k];
+			if (r.lo > r.hi || r.to >= S) return EINVAL;
+			for (unsigned c = r.lo; c <= r.hi; c++) {
+				if (seen[c]) return EINVAL; /* two edges on one byte: not a DFA */
+				seen[c] = true;
+				row[c] = r.to;
+			}
+		}
+	}
+
+	/* 3: byte classes by partition refinement over the rows */
+	{
+		uint32_t cur[256];
+		uint32_t ncls = 1;
+		memset(cur, 0, sizeof cur);
+		std::unordered_map<uint64_t, uint32_t> m;
+		for (uint32_t s = 0; s < S && ncls < 256; s++) {
+			const uint32_t *row = &nx[(size_t)s * 256];
+			/* cheap skip: a row constant on every current class cannot split */
+			m.clear();
+			uint32_t nn = 0;
+			uint32_t nxt[256];
+			for (unsigned c = 0; c < 256; c++) {
+				uint64_t key = ((uint64_t)cur[c] << 32) | row[c];
+				auto it = m.find(key);
+				if (it == m.end()) {
+					it = m.emplace(key, nn++).first;
+				}
+				nxt[c] = it->second;
+			}
+			if (nn != ncls) {
+				memcpy(cur, nxt, sizeof cur);
+				ncls = nn;
+			}
+		}
+		/* canonical numbering: by first byte of each class */
+		uint32_t remap[256];
+		for (unsigned i = 0; i < 256; i++) remap[i] = NOEDGE;
+		uint32_t k = 0;
+		for (unsigned c = 0; c < 256; c++) {
+			if (remap[cur[c]] == NOEDGE) remap[cur[c]] = k++;
+			p.cls[c] = (uint8_t)remap[cur[c]];
+		}
+		p.C = k;
+	}
+	const uint32_t C = p.C;
+	uint8_t rep[256]; /* representative byte per class */
+	for (int c = 255; c >= 0; c--) rep[p.cls[c]] = (uint8_t)c;
+
+	/* 4: renumber */
+	std::vector<uint8_t> absorbing(S1, 0);
+	for (uint32_t s = 0; s < S1; s++) {
+		const uint32_t *row = &nx[(size_t)s * 256];
+		bool ab = true;
+		for (uint32_t c = 0; c < C && ab; c++) ab = (row[rep[c]] == s);
+		absorbing[s] = ab;
+	}
+	p.old2new.assign(S1, NOEDGE);
+	p.new2old.clear();
+	p.new2old.reserve(S1);
+	{
+		std::vector<uint32_t> q;
+		q.reserve(S1);
+		std::vector<uint8_t> vis(S1, 0);
+		vis[d->start] = 1;
+		q.push_back(d->start);
+		for (size_t h = 0; h < q.size(); h++) {
+			uint32_t s = q[h];
+			const uint32_t *row = &nx[(size_t)s * 256];
+			for (uint32_t c = 0; c < C; c++) {
+				uint32_t t = row[rep[c]];
+				if (!vis[t]) { vis[t] = 1; q.push_back(t); }
+			}
+		}
+		for (uint32_t s = 0; s < S; s++) if (!vis[s]) q.push_back(s); /* unreachable */
+		if (!vis[DEAD]) q.push_back(DEAD);
+		/* non-absorbing first (BFS order), absorbing after, DEAD last */
+		for (uint32_t s : q) if (!absorbing[s]) p.new2old.push_back(s);
+		p.abs_min = (uint32_t)p.new2old.size();
+		for (uint32_t s : q) if (absorbing[s] && s != DEAD) p.new2old.push_back(s);
+		p.new2old.push_back(DEAD);
+		p.nabsorbing = S1 - p.abs_min;
+	}
+	for (uint32_t n = 0; n < S1; n++) p.old2new[p.new2old[n]] = n;
+	p.start = p.old2new[d->start];
+	p.fin.assign(S1, FSM_HIP_NO_MATCH);
+	for (uint32_t n = 0; n + 1 < S1; n++) {
+		uint32_t o = p.new2old[n];
+		if (d->is_end[o]) p.fin[n] = o;
+	}
+	p.new2old[S1 - 1] = FSM_HIP_NO_MATCH;
+	p.dense.assign((size_t)S1 * C, 0);
+	for (uint32_t n = 0; n < S1; n++) {
+		uint32_t o = (n == S1 - 1) ? DEAD : p.new2old[n];
+		const uint32_t *row = &nx[(size_t)o * 256];
+		for (uint32_t c = 0; c < C; c++) p.dense[(size_t)n * C + c] = p.old2new[row[rep[c]]];
+	}
+	std::vector<uint32_t>().swap(nx);
+
+	/* end-ids stay keyed by the caller's state ids */
+	p.endid_off.assign((size_t)S + 1, 0);
+	p.endids.clear();
+	if (d->endid_off != nullptr) {
+		for (uint32_t s = 0; s < S; s++) {
+			uint32_t a = d->endid_off[s], b = d->endid_off[s + 1];
+			if (b < a || (b > a && d->endids == nullptr)) return EINVAL;
+			p.endids.insert(p.endids.end(), d->endids + a, d->endids + b);
+			p.endid_off[s + 1] = (uint32_t)p.endids.size();
+		}
+	}
+
+	/* 5: layout */
+	const uint32_t want = flags & FSM_HIP_LAYOUT_MASK;
+	const uint32_t Cpad = (C + 1u) & ~1u;
+	const uint64_t dense_lds = (uint64_t)S1 * Cpad * 2u;
+	/* the walk kernels need the byte->class table (32 KiB) and room for at
+	 * least 8 wavefronts of input staging next to the table */
+	const uint64_t lds_room = lds_limit > lds_bytes_btab() + 8u * 4096u
+		? lds_limit - lds_bytes_btab() - 8u * 4096u : 0;
+
+	auto emit_tiny = [&]() -> int {
+		if (S1 > 16) return ENOTSUP;
+		p.tiny_col.assign(256, 0);
+		for (unsigned b = 0; b < 256; b++) {
+			uint64_t v = 0;
+			for (uint32_t s = 0; s < 16; s++) {
+				uint32_t t = s < S1 ? p.dense[(size_t)s * C + p.cls[b]] : s;
+				v |= (uint64_t)t << (4 * s);
+			}
+			p.tiny_col[b] = v;
+		}
+		p.layout = FSM_HIP_LAYOUT_TINY;
+		return 0;
+	};
+	auto emit_lds = [&]() -> int {
+		if (dense_lds > lds_room || (uint64_t)S1 * (Cpad / 2u) > 65536u) return ENOTSUP;
+		p.row_bytes = Cpad * 2u;
+		p.lds_tab.assign((size_t)S1 * Cpad, 0);
+		for (uint32_t n = 0; n < S1; n++)
+			for (uint32_t c = 0; c < Cpad; c++) {
+				uint32_t t = c < C ? p.dense[(size_t)n * C + c] : n;
+				p.lds_tab[(size_t)n * Cpad + c] = (uint16_t)(t * (p.row_bytes / 4u));
+			}
+		p.layout = FSM_HIP_LAYOUT_LDS;
+		return 0;
+	};
+	auto emit_comb = [&]() -> int {
+		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 4u, 65535u);
+		int r = build_comb(p, max_entries);
+		if (r) return r;
+		p.layout = FSM_HIP_LAYOUT_COMB;
+		return 0;
+	};
+	auto emit_glob = [&]() -> int {
+		if ((uint64_t)S1 * C * 4u >= 0xFFFFFFFFull) return ENOTSUP;
+		p.glob_tab.resize((size_t)S1 * C);
+		for (size_t i = 0; i < p.glob_tab.size(); i++) p.glob_tab[i] = p.dense[i] * C * 4u;
+		p.layout = FSM_HIP_LAYOUT_GLOBAL;
+		return 0;
+	};
+
+	switch (want) {
+	case FSM_HIP_LAYOUT_TINY:   return emit_tiny();
+	case FSM_HIP_LAYOUT_LDS:    return emit_lds();
+	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
+	case FSM_HIP_LAYOUT_GLOBAL: return emit_glob();
+	case FSM_HIP_LAYOUT_AUTO:
+		if (emit_tiny() == 0) return 0;
+		if (emit_lds() == 0) return 0;
+		if (emit_comb() == 0) return 0;
+		return emit_glob();
+	default:
+		return EINVAL;
+	}
+} catch (const std::bad_alloc &) {
+	return ENOMEM;
+}
+
+/*
+ * Column-default + comb ("row displacement") compression.
+ *
+ * dflt[c] = the most common destination of class c over all states.  A state
+ * only stores the classes where it differs from dflt (its exceptions); rows
+ * are overlaid into one array so that no two exceptions share a slot, and
+ * every state gets a distinct row offset which doubles as its id on the
+ * device.  delta(s, c) = comb[off(s)+c] if that slot is owned by off(s),
+ * else dflt[c].  Regex unions are mostly "no edge" (98 % dead in SURVEY.md
+ * section 6's 4 609-state union) and Aho-Corasick rows mostly equal the root
+ * row, so both shrink by an order of magnitude and fit LDS.
+ */
+static int build_comb(Plan &p, uint32_t max_entries)
+{
+	const uint32_t S1 = p.S1, C = p.C;
+	if (max_entries < C + 1) return ENOTSUP;
+
+	std::vector<uint32_t> dflt(C);
+	{
+		std::vector<uint32_t> cnt(S1);
+		for (uint32_t c = 0; c < C; c++) {
+			std::fill(cnt.begin(), cnt.end(), 0);
+			uint32_t best = 0;
+			for (uint32_t n = 0; n < S1; n++) {
+				uint32_t t = p.dense[(size_t)n * C + c];
+				if (++cnt[t] > cnt[best]) best = t;
+			}
+			dflt[c] = best;
+		}
+	}
+	std::vector<uint32_t> nexc(S1, 0);
+	uint64_t total = 0;
+	for (uint32_t n = 0; n < S1; n++) {
+		for (uint32_t c = 0; c < C; c++)
+			if (p.dense[(size_t)n * C + c] != dflt[c]) nexc[n]++;
+		total += nexc[n];
+	}
+	if (total + C > max_entries || S1 > max_entries) return ENOTSUP;
+
+	/* place non-absorbing states densest first, then absorbing ones above */
+	std::vector<uint32_t> order(S1);
+	for (uint32_t n = 0; n < S1; n++) order[n] = n;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+		bool aa = a >= p.abs_min, ab = b >= p.abs_min;
+		if (aa != ab) return ab;              /* non-absorbing first */
+		if (aa) return a < b;                 /* absorbing: keep order, DEAD last */
+		return nexc[a] > nexc[b];
+	});
+
+	/* exception class lists (CSR) so the fit test touches only real entries */
+	std::vector<uint32_t> exo(S1 + 1, 0);
+	for (uint32_t n = 0; n < S1; n++) exo[n + 1] = exo[n] + nexc[n];
+	std::vector<uint16_t> exc(exo[S1]);
+	for (uint32_t n = 0; n < S1; n++) {
+		uint32_t k = exo[n];
+		for (uint32_t c = 0; c < C; c++)
+			if (p.dense[(size_t)n * C + c] != dflt[c]) exc[k++] = (uint16_t)c;
+	}
+
+	std::vector<uint8_t> slot_used(max_entries + C, 0), off_used(max_entries + 1, 0);
+	p.comb_off.assign(S1, 0);
+	uint32_t hi = 0;         /* 1 + highest offset handed out so far */
+	uint32_t first_free = 0; /* lowest offset not yet handed out */
+	bool in_abs = false;
+	for (uint32_t idx = 0; idx < S1; idx++) {
+		uint32_t n = order[idx];
+		if (!in_abs && n >= p.abs_min) {
+			in_abs = true;
+			p.comb_abs_min_off = hi; /* absorbing states get offsets >= every other state's */
+		}
+		/* absorbing offsets keep increasing so one compare identifies them */
+		uint32_t o = in_abs ? hi : first_free;
+		for (;; o++) {
+			if (o + C > max_entries) return ENOTSUP;
+			if (off_used[o]) continue;
+			bool ok = true;
+			for (uint32_t k = exo[n]; k < exo[n + 1] && ok; k++)
+				if (slot_used[o + exc[k]]) ok = false;
+			if (ok) break;
+		}
+		off_used[o] = 1;
+		for (uint32_t k = exo[n]; k < exo[n + 1]; k++) slot_used[o + exc[k]] = 1;
+		p.comb_off[n] = o;
+		if (o + 1 > hi) hi = o + 1;
+		while (first_free < max_entries && off_used[first_free]) first_free++;
+	}
+	if (!in_abs) p.comb_abs_min_off = hi; /* cannot happen: DEAD is absorbing */
+	uint32_t size = hi + C;
+	if (size > max_entries || size > 0xFFFFu) return ENOTSUP;
+
+	p.comb.assign(size, 0xFFFF0000u); /* owner 0xFFFF never matches a real offset */
+	p.comb_fin.assign(size, FSM_HIP_NO_MATCH);
+	for (uint32_t n = 0; n < S1; n++) {
+		uint32_t o = p.comb_off[n];
+		p.comb_fin[o] = p.fin[n];
+		for (uint32_t c = 0; c < C; c++) {
+			uint32_t t = p.dense[(size_t)n * C + c];
+			if (t != dflt[c]) p.comb[o + c] = (o << 16) | p.comb_off[t];
+		}
+	}
+	p.comb_dflt.resize(C);
+	for (uint32_t c = 0; c < C; c++) p.comb_dflt[c] = p.comb_off[dflt[c]];
+	return 0;
+}
+
+} // namespace fsmhip

@@ -1,0 +1,69 @@
+/*
+ * plan.h -- host-side table planner: flat DFA description -> device table images.
+ *
+ * This is the from-scratch counterpart of the reference's "IR -> 256-entry
+ * scratch table" expansion (struct dfa_table, src/libfsm/vm/ir.c:105-130,
+ * dfa_table_init/group_to_table/error_to_table :649-691): every state becomes a
+ * dense row over the 256 byte values with "no edge" mapped to one synthetic,
+ * absorbing, non-accepting DEAD state, which makes the walk branch-free while
+ * keeping fsm_exec's result (a missing edge returns 0, src/libfsm/exec.c:133-138).
+ * The preconditions fsm_exec re-checks on every call (exec.c:106-114) are
+ * checked once, here.
+ */
+#ifndef FSMHIP_CSRC_PLAN_H
+#define FSMHIP_CSRC_PLAN_H
+
+#include <cstdint>
+#include <vector>
+#include "../../include/fsm_hip.h"
+
+namespace fsmhip {
+
+struct Plan {
+	uint32_t nstates = 0;     /* caller's state count                          */
+	uint32_t S1 = 0;          /* nstates + 1 (synthetic dead state, last)      */
+	uint32_t start = 0;       /* renumbered start state                        */
+	uint32_t C = 0;           /* number of byte equivalence classes            */
+	uint8_t  cls[256];        /* byte -> class                                 */
+	uint32_t abs_min = 0;     /* renumbered states >= abs_min are absorbing    */
+	uint32_t nabsorbing = 0;
+	std::vector<uint32_t> old2new, new2old;   /* new2old[S1-1] = NO_MATCH (dead) */
+	std::vector<uint32_t> fin;    /* [S1] caller's state id if end state else FSM_HIP_NO_MATCH */
+	std::vector<uint32_t> dense;  /* [S1][C] next (renumbered) state per class */
+	/* end-ids by ORIGINAL state id (CSR) */
+	std::vector<uint32_t> endid_off, endids;
+
+	uint32_t layout = 0;          /* FSM_HIP_LAYOUT_* chosen */
+
+	/* ---- device images (host copies) ---- */
+	/* TINY: col[256] = 16 nibbles, nibble s = next state of s on that byte */
+	std::vector<uint64_t> tiny_col;
+	/* LDS dense: u16 entries, row stride row_bytes (multiple of 4);
+	 * entry = next_state * (row_bytes/4)                                   */
+	std::vector<uint16_t> lds_tab;
+	uint32_t row_bytes = 0;
+	/* COMB: column default + exception comb.
+	 * comb entry = (owner_off << 16) | next_off  where *_off are the comb
+	 * row offsets (in entries) of the owning / destination state;
+	 * dflt[c] = row offset of the default destination of class c.          */
+	std::vector<uint32_t> comb;
+	std::vector<uint32_t> comb_dflt;      /* [C] */
+	std::vector<uint32_t> comb_off;       /* [S1] row offset of each renumbered state */
+	std::vector<uint32_t> comb_fin;       /* [comb.size()] fin by row offset (NO_MATCH elsewhere) */
+	uint32_t comb_abs_min_off = 0;        /* row offsets >= this are absorbing */
+	/* GLOBAL: u32 entries [S1][C], entry = next_state * C * 4 (byte offset) */
+	std::vector<uint32_t> glob_tab;
+};
+
+/* Returns 0 or an errno value (EINVAL, ENOMEM, ENOTSUP for a forced layout
+ * that cannot hold this DFA).  lds_limit = usable LDS bytes per workgroup. */
+int build_plan(const fsm_hip_dfa_desc *desc, unsigned flags, uint32_t lds_limit, Plan &out);
+
+/* LDS bytes needed by each layout's kernel for `waves` wavefronts per block
+ * (tables only; the kernels add their own staging on top). */
+uint32_t lds_bytes_tiny();
+uint32_t lds_bytes_btab();
+
+} // namespace fsmhip
+
+#endif

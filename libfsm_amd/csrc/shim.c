@@ -1,0 +1,373 @@
+/*
+ * shim.c -- libfsm-facing layer of libfsm_hip.so (plain C, like the host code
+ * it sits next to).
+ *
+ * Reads a `const struct fsm *` ONLY through libfsm's public API, resolved with
+ * dlsym(RTLD_DEFAULT, ...) on first use so that this library neither links
+ * libfsm nor needs its headers at build time.  The prototypes below restate
+ * the public declarations they bind (reference file:line in each comment).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fsm_hip.h"
+
+struct api {
+	int resolved;
+	/* include/fsm/fsm.h:388 */
+	unsigned int (*countstates)(const struct fsm *);
+	/* include/fsm/fsm.h:382 */
+	int (*getstart)(const struct fsm *, fsm_state_t *);
+	/* include/fsm/pred.h:21, :24 */
+	int (*isend)(const struct fsm *, fsm_state_t);
+	int (*isdfa)(const struct fsm *, fsm_state_t);
+	/* include/fsm/walk.h:35 */
+	int (*all)(const struct fsm *, int (*)(const struct fsm *, fsm_state_t));
+	/* include/fsm/walk.h:75-78 */
+	int (*walk_edges)(const struct fsm *, void *,
+		int (*)(const struct fsm *, fsm_state_t, fsm_state_t, char, void *),
+		int (*)(const struct fsm *, fsm_state_t, fsm_state_t, void *));
+	/* include/fsm/capture.h:28 */
+	unsigned (*countcaptures)(const struct fsm *);
+	/* include/fsm/fsm.h:223-228 */
+	int (*endid_get)(const struct fsm *, fsm_state_t, size_t, fsm_end_id_t *);
+	size_t (*endid_count)(const struct fsm *, fsm_state_t);
+	/* include/fsm/fsm.h:327 */
+	size_t (*eager_output_count)(const struct fsm *, fsm_state_t);
+};
+
+static struct api A;
+
+static int
+resolve(void)
+{
+	if (A.resolved) {
+		return A.resolved > 0;
+	}
+#define SYM(field, name) do { \
+		*(void **)(&A.field) = dlsym(RTLD_DEFAULT, name); \
+		if (A.field == NULL) { A.resolved = -1; } \
+	} while (0)
+	A.resolved = 1;
+	SYM(countstates, "fsm_countstates");
+	SYM(getstart, "fsm_getstart");
+	SYM(isend, "fsm_isend");
+	SYM(isdfa, "fsm_isdfa");
+	SYM(all, "fsm_all");
+	SYM(walk_edges, "fsm_walk_edges");
+	SYM(countcaptures, "fsm_countcaptures");
+	SYM(endid_get, "fsm_endid_get");
+	SYM(endid_count, "fsm_endid_count");
+	SYM(eager_output_count, "fsm_eager_output_count");
+#undef SYM
+	return A.resolved > 0;
+}
+
+/* ---- flatten ------------------------------------------------------- */
+
+struct flat {
+	struct fsm_hip_dfa_desc d;
+	uint32_t *edge_off;
+	struct fsm_hip_range *ranges;
+	uint8_t *is_end;
+	uint32_t *endid_off;
+	uint32_t *endids;
+};
+
+struct walk_env {
+	uint32_t *next;   /* [nstates][256], 0xFFFFFFFF = no edge */
+	uint32_t nstates;
+	int nondet;
+};
+
+static int
+lit_cb(const struct fsm *fsm, fsm_state_t from, fsm_state_t to, char c, void *opaque)
+{
+	struct walk_env *env = opaque;
+	uint32_t *slot;
+	(void) fsm;
+	slot = &env->next[(size_t) from * 256 + (unsigned char) c];
+	if (*slot != 0xFFFFFFFFu && *slot != to) {
+		env->nondet = 1;
+		return 0;
+	}
+	*slot = to;
+	return 1;
+}
+
+static int
+eps_cb(const struct fsm *fsm, fsm_state_t from, fsm_state_t to, void *opaque)
+{
+	struct walk_env *env = opaque;
+	(void) fsm; (void) from; (void) to;
+	env->nondet = 1;
+	return 0;
+}
+
+void
+fsm_hip_desc_free(struct fsm_hip_dfa_desc *desc)
+{
+	struct flat *f = (struct flat *) desc;
+	if (f == NULL) {
+		return;
+	}
+	free(f->edge_off);
+	free(f->ranges);
+	free(f->is_end);
+	free(f->endid_off);
+	free(f->endids);
+	free(f);
+}
+
+struct fsm_hip_dfa_desc *
+fsm_hip_flatten(const struct fsm *fsm)
+{
+	struct flat *f = NULL;
+	struct walk_env env;
+	fsm_state_t start;
+	uint32_t n, s;
+	size_t nr, cap, nid;
+
+	memset(&env, 0, sizeof env);
+	if (fsm == NULL) {
+		errno = EINVAL;
+		return NULL;
+	}
+	if (!resolve()) {
+		errno = ENOSYS;
+		return NULL;
+	}
+	/* what fsm_exec checks per call (src/libfsm/exec.c:106-114), once */
+	if (!A.all(fsm, A.isdfa) || !A.getstart(fsm, &start)) {
+		errno = EINVAL;
+		return NULL;
+	}
+	/* captures and eager outputs are per-byte host side channels
+	 * (exec.c:41-44, :126-144): not representable in a table walk */
+	if (A.countcaptures(fsm) > 0) {
+		errno = ENOTSUP;
+		return NULL;
+	}
+	n = A.countstates(fsm);
+	if (n == 0) {
+		errno = EINVAL;
+		return NULL;
+	}
+	for (s = 0; s < n; s++) {
+		if (A.eager_output_count(fsm, s) > 0) {
+			errno = ENOTSUP;
+			return NULL;
+		}
+	}
+
+	f = calloc(1, sizeof *f);
+	env.next = malloc((size_t) n * 256 * sizeof *env.next);
+	if (f == NULL || env.next == NULL) {
+		goto oom;
+	}
+	memset(env.next, 0xFF, (size_t) n * 256 * sizeof *env.next);
+	env.nstates = n;
+	if (!A.walk_edges(fsm, &env, lit_cb, eps_cb) || env.nondet) {
+		free(env.next);
+		free(f);
+		errno = EINVAL;
+		return NULL;
+	}
+
+	f->edge_off = malloc(((size_t) n + 1) * sizeof *f->edge_off);
+	f->is_end = malloc(n);
+	f->endid_off = malloc(((size_t) n + 1) * sizeof *f->endid_off);
+	cap = 1024;
+	f->ranges = malloc(cap * sizeof *f->ranges);
+	if (f->edge_off == NULL || f->is_end == NULL || f->endid_off == NULL || f->ranges == NULL) {
+		goto oom;
+	}
+	nr = 0;
+	for (s = 0; s < n; s++) {
+		const uint32_t *row = &env.next[(size_t) s * 256];
+		unsigned c = 0;
+		f->edge_off[s] = (uint32_t) nr;
+		f->is_end[s] = A.isend(fsm, s) ? 1 : 0;
+		while (c < 256) {
+			unsigned lo;
+			if (row[c] == 0xFFFFFFFFu) {
+				c++;
+				continue;
+			}
+			lo = c;
+			while (c + 1 < 256 && row[c + 1] == row[lo]) {
+				c++;
+			}
+			if (nr == cap) {
+				struct fsm_hip_range *t;
+				cap *= 2;
+				t = realloc(f->ranges, cap * sizeof *t);
+				if (t == NULL) {
+					goto oom;
+				}
+				f->ranges = t;
+			}
+			f->ranges[nr].lo = (uint8_t) lo;
+			f->ranges[nr].hi = (uint8_t) c;
+			f->ranges[nr].reserved = 0;
+			f->ranges[nr].to = row[lo];
+			nr++;
+			c++;
+		}
+	}
+	f->edge_off[n] = (uint32_t) nr;
+	free(env.next);
+	env.next = NULL;
+
+	/* end-ids: sorted unique per end state, as fsm_endid_get returns them
+	 * (src/libfsm/endids.c:686-755) */
+	nid = 0;
+	for (s = 0; s < n; s++) {
+		f->endid_off[s] = (uint32_t) nid;
+		if (f->is_end[s]) {
+			nid += A.endid_count(fsm, s);
+		}
+	}
+	f->endid_off[n] = (uint32_t) nid;
+	f->endids = malloc((nid ? nid : 1) * sizeof *f->endids);
+	if (f->endids == NULL) {
+		goto oom;
+	}
+	for (s = 0; s < n; s++) {
+		size_t cnt = f->endid_off[s + 1] - f->endid_off[s];
+		if (cnt > 0 && !A.endid_get(fsm, s, cnt, f->endids + f->endid_off[s])) {
+			fsm_hip_desc_free(&f->d);
+			errno = EINVAL;
+			return NULL;
+		}
+	}
+
+	f->d.nstates = n;
+	f->d.start = start;
+	f->d.edge_off = f->edge_off;
+	f->d.ranges = f->ranges;
+	f->d.is_end = f->is_end;
+	f->d.endid_off = f->endid_off;
+	f->d.endids = f->endids;
+	return &f->d;
+
+oom:
+	free(env.next);
+	if (f != NULL) {
+		fsm_hip_desc_free(&f->d);
+	}
+	errno = ENOMEM;
+	return NULL;
+}
+
+struct fsm_hip_dfa *
+fsm_hip_compile(const struct fsm *fsm, unsigned flags)
+{
+	struct fsm_hip_dfa_desc *desc;
+	struct fsm_hip_dfa *dfa;
+	int e;
+
+	desc = fsm_hip_flatten(fsm);
+	if (desc == NULL) {
+		return NULL;
+	}
+	dfa = fsm_hip_dfa_create(desc, flags);
+	e = errno;
+	fsm_hip_desc_free(desc);
+	errno = e;
+	return dfa;
+}
+
+/* ---- single-input fronts (batch of one on the GPU) ------------------ */
+
+int
+fsm_hip_match_buffer(const struct fsm_hip_dfa *dfa, const char *buf, size_t n)
+{
+	uint32_t end = FSM_HIP_NO_MATCH;
+	uint64_t off[2];
+	off[0] = 0;
+	off[1] = n;
+	if (fsm_hip_exec_batch_offsets(dfa, (const unsigned char *) buf, off, 1, &end, NULL) != 0) {
+		return -1;
+	}
+	return end != FSM_HIP_NO_MATCH;
+}
+
+int
+fsm_hip_exec(const struct fsm_hip_dfa *dfa,
+	int (*fsm_getc)(void *opaque), void *opaque,
+	fsm_state_t *end, struct fsm_capture *captures)
+{
+	unsigned char *buf = NULL, *t;
+	size_t n = 0, cap = 0;
+	uint32_t e = FSM_HIP_NO_MATCH;
+	uint64_t off[2];
+	int c, r;
+
+	if (dfa == NULL || fsm_getc == NULL || end == NULL || captures != NULL) {
+		errno = EINVAL;
+		return -1;
+	}
+	while (c = fsm_getc(opaque), c != EOF) {
+		if (n == cap) {
+			cap = cap ? cap * 2 : 4096;
+			t = realloc(buf, cap);
+			if (t == NULL) {
+				free(buf);
+				errno = ENOMEM;
+				return -1;
+			}
+			buf = t;
+		}
+		buf[n++] = (unsigned char) c;
+	}
+	off[0] = 0;
+	off[1] = n;
+	r = fsm_hip_exec_batch_offsets(dfa, buf, off, 1, &e, NULL);
+	free(buf);
+	if (r != 0) {
+		return -1;
+	}
+	if (e == FSM_HIP_NO_MATCH) {
+		return 0; /* *end untouched, as exec.c:133-138 / :153-155 */
+	}
+	*end = e;
+	return 1;
+}
+
+int
+fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f)
+{
+	unsigned char *buf = NULL, *t;
+	size_t n = 0, cap = 0, got;
+	int r;
+
+	if (dfa == NULL || f == NULL) {
+		errno = EINVAL;
+		return -1;
+	}
+	for (;;) {
+		if (cap - n < 4096) {
+			cap = cap ? cap * 2 : 65536;
+			t = realloc(buf, cap);
+			if (t == NULL) {
+				free(buf);
+				errno = ENOMEM;
+				return -1;
+			}
+			buf = t;
+		}
+		got = fread(buf + n, 1, cap - n, f);
+		n += got;
+		if (got == 0) {
+			break;
+		}
+	}
+	r = fsm_hip_match_buffer(dfa, (const char *) buf, n);
+	free(buf);
+	return r;
+}
