@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path (batched DFA walk) on N GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3] [--n INPUTS_PER_GPU]
+
+A "step" is one pass of the walk kernel over one batch of synthetic inputs that
+is already resident in HBM (generated on the device, so nothing crosses PCIe),
+followed -- for N > 1 -- by the RCCL all-gather of the accept bitmap.  Inputs are
+sharded by contiguous global index range, one shard per rank (weak scaling:
+per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  c2  configs[1]: PCRE [Ll]ibf+(sm)* DFA (5 states) over 1e8 x 1 KiB random
+      inputs per GPU, "Libfsm" planted in every 8th input.        (default)
+  c3  configs[2]: 1 024 anchored PCRE unioned into a ~4 096-state DFA, half the
+      inputs derived from a pattern (prefix + digits + suffix), half random.
+The DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real
+reference by tests/golden/make_golden.py); /root/reference is not needed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+SEED = 0x5EEDF5A1
+ALNUM = b"abcdefghijklmnopqrstuvwxyz0123456789"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--n", type=int, default=100_000_000, help="inputs per GPU")
+    ap.add_argument("--len", type=int, default=1024, help="bytes per input")
+    ap.add_argument("--input-mode", type=int, default=-1)
+    ap.add_argument("--nb", type=int, default=0)
+    ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--layout", type=int, default=0)
+    ap.add_argument("--no-early-retire", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="inputs for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def c3_affixes():
+    pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
+    return [p[1:p.index(b"[")] for p in pats], [b"x", b"yz"]
+
+
+def generate(hip, workload, d_ptr, n, L, first):
+    if workload == "c2":
+        hip.gen_inputs_device(d_ptr, n, L, first, SEED, None, b"Libfsm", 8)
+    else:
+        pf, sf = c3_affixes()
+        hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
+
+
+def generate_host(hip, workload, n, L, first):
+    if workload == "c2":
+        return hip.gen_inputs_host(n, L, first, SEED, None, b"Libfsm", 8)
+    pf, sf = c3_affixes()
+    return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
+
+
+def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample):
+    """Time the reference's CPU path on a bounded sample of the same inputs (rank 0, N=1 only)
+    and check the GPU's answers on that sample against it, bit for bit."""
+    from oracle import pyoracle
+    rows = generate_host(hip, workload, sample, L, 0)
+    out = {"cores": 1, "unit": "GB/s"}
+    gb = rows.size / 1e9
+    if pyoracle.have_ref():
+        # the real reference, rebuilt as a struct fsm from its own regex sources
+        if workload == "c2":
+            f = pyoracle.RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
+            nfe = sample
+        else:
+            pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
+            f = pyoracle.RefFsm.union_res("pcre", pats, 0)
+            nfe = min(sample, 1500)  # fsm_exec re-runs fsm_all(isdfa) per call: ~9 ms/call on 4k states
+        ret, end = f.exec_stride(rows[:nfe])
+        t_exec = f.last_seconds
+        vm = f.vm_match_stride(rows, 2)
+        t_vm = f.last_seconds
+        want = pyoracle.Oracle(flat).table_walk(rows)
+        assert np.array_equal(end, want[:nfe]), "oracle != reference fsm_exec"
+        assert np.array_equal(vm == 1, want != 0xFFFFFFFF), "reference VM != fsm_exec"
+        out.update(kind="reference", value=round(nfe * L / 1e9 / t_exec, 5),
+                   sample=f"reference fsm_exec (src/libfsm/exec.c) with a (ptr,len) getc, 1 thread, first {nfe} inputs x {L} B of the same generator stream",
+                   vm_v2_value=round(gb / t_vm, 5), vm_v2_sample=f"reference fsm_vm_match_buffer v2, 1 thread, {sample} inputs")
+    else:
+        o = pyoracle.Oracle(flat)
+        want = o.table_walk(rows)
+        out.update(kind="port", value=round(gb / o.last_seconds, 5),
+                   sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, first {sample} inputs x {L} B")
+    parity = bool(np.array_equal(gpu_end_sample, want))
+    return out, parity
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import libfsm_amd as hip
+    hip.load_library()
+
+    flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if a.workload == "c2" else "c3.npz"))
+    flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
+    dfa = hip.HipDfa(flat, flags)
+    for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_NONTEMPORAL, a.nt),
+                    (hip.KNOB_WAVES, a.waves), (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu)):
+        if v > 0 or (knob == hip.KNOB_INPUT_MODE and v >= 0):
+            dfa.tune(knob, v)
+    info = dfa.info()
+
+    L = a.len
+    n = a.n
+    free, total = torch.cuda.mem_get_info()
+    need = n * (L + 4) + n // 8 + (1 << 30)
+    if need > free * 0.92:  # shrink rather than risk an OOM strike; reported in config
+        n = int((free * 0.92 - (1 << 30)) // (L + 5)) // 64 * 64
+    first = rank * n
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    end = torch.empty(n, dtype=torch.int32, device="cuda")
+    nwords = (n + 63) // 64
+    bm = torch.zeros(nwords, dtype=torch.int64, device="cuda")
+    gathered = torch.empty(nwords * world, dtype=torch.int64, device="cuda") if world > 1 else None
+    generate(hip, a.workload, buf.data_ptr(), n, L, first)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    kernel_ms = []
+
+    def step(record):
+        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr(), stream=stream)
+        if record:
+            kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, bm)  # the match bitmap over RCCL/xGMI
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    accepts = int((end != -1).sum().item())
+    acc_t = torch.tensor([accepts], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(acc_t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = elapsed / a.steps * 1e3
+    total_bytes = float(n) * L * world
+    value = total_bytes / (elapsed / a.steps) / 1e9
+    k_ms = float(np.mean(kernel_ms))
+    alg_bytes = float(n) * (L + 4)  # L bytes read + 4 B end state written per input
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", f"pmc_{a.workload}.json")
+    if os.path.exists(pj):
+        try:
+            t = json.load(open(pj))
+            if int(t.get("n", 0)) == n and int(t.get("len", 0)) == L:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "input GB/s matched (whole node)", "value": round(value, 2), "unit": "GB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": ("c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), "
+                         if a.workload == "c2" else
+                         "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, " % flat.nstates)
+                        + f"{n} x {L} B synthetic inputs per GPU resident in HBM, 64 inputs/wavefront",
+            "inputs_per_gpu": n, "input_len": L, "dfa_states": flat.nstates, "byte_classes": info["nclasses"],
+            "table_layout": info["layout_name"], "lds_bytes_per_block": info["lds_bytes"],
+            "waves_per_block": info["waves_per_block"], "sharding": f"{world} contiguous index ranges, all-gather of the accept bitmap" if world > 1 else "single GPU",
+            "accepted_inputs": int(acc_t.item()), "requested_inputs_per_gpu": a.n,
+        },
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if world == 1 and not a.no_cpu_baseline and a.cpu_sample != 0:
+        sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if a.workload == "c2" else 100_000)
+        sample = min(sample, n)
+        cb, parity = cpu_baseline(hip, a.workload, flat, L, sample, end[:sample].cpu().numpy().view(np.uint32))
+        res["cpu_baseline"] = cb
+        res["parity_vs_cpu_sample"] = "bit-exact" if parity else "MISMATCH"
+        if not parity:
+            res["value"] = None  # a fast wrong answer is not a result
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

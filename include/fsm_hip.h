@@ -201,11 +201,12 @@ void fsm_hip_desc_free(struct fsm_hip_dfa_desc *desc);
 /* ------------------------------------------------------------------ */
 
 /* Counter-based generator, identical on host and device:
- *   byte(i, t) = alphabet[ mix64(seed ^ (i * 0x9E3779B97F4A7C15) ^ (t >> 3)) >> (8 * (t & 7)) & 0xff  (mod nalpha) ]
- * with i the GLOBAL input index (first_index + local row).  alphabet == NULL
- * means all 256 byte values.  If plant_len > 0, every plant_every-th input
- * (i % plant_every == 0) has `plant` copied at offset
- * mix64(seed ^ i) % (stride - plant_len + 1).
+ *   r(i, t)    = (mix64(seed ^ (i * 0x9E3779B97F4A7C15) ^ (t >> 3)) >> (8 * (t & 7))) & 0xff
+ *   byte(i, t) = alphabet ? alphabet[r % nalpha] : r
+ * with mix64 the splitmix64 finaliser and i the GLOBAL input index
+ * (first_index + local row).  If plant_len > 0 (<= 64), every input with
+ * i % plant_every == 0 has `plant` copied at offset
+ * mix64(seed ^ i ^ 0xA5A5A5A5A5A5A5A5) % (stride - plant_len + 1).
  * d_base is a device pointer to n rows of `stride` bytes. */
 int fsm_hip_gen_inputs_device(void *d_base, size_t stride, size_t n,
 	uint64_t first_index, uint64_t seed,
@@ -218,6 +219,28 @@ void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size_t n,
 	uint64_t first_index, uint64_t seed,
 	const unsigned char *alphabet, unsigned nalpha,
 	const unsigned char *plant, unsigned plant_len, unsigned plant_every);
+
+/* Affix variant for rx-style multi-pattern workloads: rows whose global index
+ * is a multiple of `every` are  prefix + random bytes of `body` + suffix,
+ * exactly stride bytes long (prefix = prefixes[h % npfx], suffix =
+ * suffixes[(h>>32) % nsfx], h = mix64(seed ^ i ^ 0x5A5A5A5A5A5A5A5A)); every other
+ * row is random over `alphabet` as above.  prefixes/suffixes are HOST arrays of
+ * 8-byte entries [len<=7, b0..b6].  Synchronises the stream before returning. */
+int fsm_hip_gen_affix_inputs_device(void *d_base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every, void *hip_stream);
+
+void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every);
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int fsm_hip_version(void);

@@ -1,0 +1,414 @@
+"""ctypes binding of libfsm_hip.so -- the C ABI declared in include/fsm_hip.h.
+
+Python is only the harness language here (tests, bench.py); the product is the
+shared library.  Nothing in this module matches inputs on the CPU: every
+exec_* call goes through the HIP kernels and raises if the library or a GPU is
+missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+NO_MATCH = 0xFFFFFFFF
+
+LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL = 0, 1, 2, 3, 4
+LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global"}
+NO_EARLY_RETIRE = 0x10
+
+KNOB_INPUT_MODE, KNOB_NB, KNOB_NONTEMPORAL, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE = 1, 2, 3, 4, 5, 6
+IN_DIRECT, IN_LDSDMA, IN_GENERIC = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsm_hip.so")
+
+RANGE_DTYPE = np.dtype([("lo", "u1"), ("hi", "u1"), ("reserved", "<u2"), ("to", "<u4")])
+
+
+class _Desc(C.Structure):
+    _fields_ = [
+        ("nstates", C.c_uint32),
+        ("start", C.c_uint32),
+        ("edge_off", C.c_void_p),
+        ("ranges", C.c_void_p),
+        ("is_end", C.c_void_p),
+        ("endid_off", C.c_void_p),
+        ("endids", C.c_void_p),
+    ]
+
+
+class _Info(C.Structure):
+    _fields_ = [
+        ("nstates", C.c_uint32),
+        ("nclasses", C.c_uint32),
+        ("layout", C.c_uint32),
+        ("nabsorbing", C.c_uint32),
+        ("table_bytes", C.c_uint64),
+        ("lds_bytes", C.c_uint32),
+        ("waves_per_block", C.c_uint32),
+        ("device", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libfsm_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"libfsm_hip.so not built at {p}: run `python __graft_entry__.py` (no CPU fallback exists)")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL, use_errno=True)
+    vp, u32p, u64p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
+    lib.fsm_hip_version.restype = C.c_int
+    lib.fsm_hip_dfa_create.restype = vp
+    lib.fsm_hip_dfa_create.argtypes = [C.POINTER(_Desc), C.c_uint]
+    lib.fsm_hip_dfa_free.argtypes = [vp]
+    lib.fsm_hip_dfa_info.argtypes = [vp, C.POINTER(_Info)]
+    lib.fsm_hip_exec_batch.argtypes = [vp, vp, sz, u32p, sz, u32p, u64p]
+    lib.fsm_hip_exec_batch_offsets.argtypes = [vp, vp, u64p, sz, u32p, u64p]
+    lib.fsm_hip_exec_batch_device.argtypes = [vp, vp, sz, u32p, sz, u32p, u64p, vp]
+    lib.fsm_hip_exec_batch_offsets_device.argtypes = [vp, vp, u64p, sz, u32p, u64p, vp]
+    lib.fsm_hip_last_kernel_ms.restype = C.c_double
+    lib.fsm_hip_last_kernel_ms.argtypes = [vp]
+    lib.fsm_hip_endid_count.restype = sz
+    lib.fsm_hip_endid_count.argtypes = [vp, C.c_uint32]
+    lib.fsm_hip_endid_get.argtypes = [vp, C.c_uint32, sz, u32p]
+    lib.fsm_hip_compile.restype = vp
+    lib.fsm_hip_compile.argtypes = [vp, C.c_uint]
+    lib.fsm_hip_exec.argtypes = [vp, vp, vp, C.POINTER(C.c_uint), vp]
+    lib.fsm_hip_match_buffer.argtypes = [vp, C.c_char_p, sz]
+    lib.fsm_hip_flatten.restype = C.POINTER(_Desc)
+    lib.fsm_hip_flatten.argtypes = [vp]
+    lib.fsm_hip_desc_free.argtypes = [C.POINTER(_Desc)]
+    lib.fsm_hip_gen_inputs_device.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint, vp]
+    lib.fsm_hip_gen_inputs_host.restype = None
+    lib.fsm_hip_gen_inputs_host.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint]
+    lib.fsm_hip_dfa_tune.argtypes = [vp, C.c_int, C.c_int]
+    lib.fsm_hip_plan_create.restype = vp
+    lib.fsm_hip_plan_create.argtypes = [C.POINTER(_Desc), C.c_uint, C.c_uint32]
+    lib.fsm_hip_plan_free.argtypes = [vp]
+    lib.fsm_hip_plan_get.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _oserr(what: str):
+    e = C.get_errno()
+    return OSError(e, f"{what}: {os.strerror(e)}")
+
+
+@dataclass
+class FlatDfa:
+    """Flat DFA description = struct fsm_hip_dfa_desc (include/fsm_hip.h)."""
+
+    nstates: int
+    start: int
+    edge_off: np.ndarray  # u32 [nstates+1]
+    ranges: np.ndarray  # RANGE_DTYPE [nranges]
+    is_end: np.ndarray  # u8 [nstates]
+    endid_off: np.ndarray  # u32 [nstates+1]
+    endids: np.ndarray  # u32 []
+
+    def __post_init__(self):
+        self.edge_off = np.ascontiguousarray(self.edge_off, dtype=np.uint32)
+        self.ranges = np.ascontiguousarray(self.ranges, dtype=RANGE_DTYPE)
+        self.is_end = np.ascontiguousarray(self.is_end, dtype=np.uint8)
+        self.endid_off = np.ascontiguousarray(self.endid_off, dtype=np.uint32)
+        self.endids = np.ascontiguousarray(self.endids, dtype=np.uint32)
+
+    def desc(self) -> _Desc:
+        d = _Desc()
+        d.nstates, d.start = self.nstates, self.start
+        d.edge_off = self.edge_off.ctypes.data
+        d.ranges = self.ranges.ctypes.data if len(self.ranges) else None
+        d.is_end = self.is_end.ctypes.data
+        d.endid_off = self.endid_off.ctypes.data
+        d.endids = self.endids.ctypes.data if len(self.endids) else None
+        return d
+
+    @classmethod
+    def from_desc(cls, d: _Desc) -> "FlatDfa":
+        n = d.nstates
+
+        def arr(addr, count, dt):
+            if count == 0 or not addr:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (count * np.dtype(dt).itemsize)).from_address(addr)
+            return np.frombuffer(buf, dtype=dt).copy()
+
+        edge_off = arr(d.edge_off, n + 1, np.uint32)
+        endid_off = arr(d.endid_off, n + 1, np.uint32) if d.endid_off else np.zeros(n + 1, np.uint32)
+        return cls(n, d.start, edge_off, arr(d.ranges, int(edge_off[n]), RANGE_DTYPE), arr(d.is_end, n, np.uint8),
+                   endid_off, arr(d.endids, int(endid_off[n]), np.uint32))
+
+    @classmethod
+    def from_dense(cls, next_tab: np.ndarray, start: int, is_end: Sequence[int], endids=None) -> "FlatDfa":
+        """next_tab: [S][256] int64/uint32, negative or 0xFFFFFFFF = no edge."""
+        nt = np.asarray(next_tab, dtype=np.int64)
+        S = nt.shape[0]
+        rng, off = [], [0]
+        for s in range(S):
+            c = 0
+            row = nt[s]
+            while c < 256:
+                t = row[c]
+                if t < 0 or t == NO_MATCH:
+                    c += 1
+                    continue
+                lo = c
+                while c + 1 < 256 and row[c + 1] == t:
+                    c += 1
+                rng.append((lo, c, 0, int(t)))
+                c += 1
+            off.append(len(rng))
+        eo, ei = [0], []
+        for s in range(S):
+            if endids is not None and s in endids:
+                ei.extend(sorted(set(endids[s])))
+            eo.append(len(ei))
+        return cls(S, start, np.array(off, np.uint32), np.array(rng, dtype=RANGE_DTYPE) if rng else np.zeros(0, RANGE_DTYPE),
+                   np.asarray(is_end, np.uint8), np.array(eo, np.uint32), np.array(ei, np.uint32))
+
+    def dense(self) -> np.ndarray:
+        """[S][256] uint32 next table, NO_MATCH = no edge."""
+        t = np.full((self.nstates, 256), NO_MATCH, dtype=np.uint32)
+        for s in range(self.nstates):
+            for k in range(int(self.edge_off[s]), int(self.edge_off[s + 1])):
+                r = self.ranges[k]
+                t[s, int(r["lo"]):int(r["hi"]) + 1] = r["to"]
+        return t
+
+    def endids_of(self, state: int) -> np.ndarray:
+        return self.endids[int(self.endid_off[state]):int(self.endid_off[state + 1])]
+
+    def save(self, path: str, **extra):
+        np.savez_compressed(path, nstates=np.uint32(self.nstates), start=np.uint32(self.start), edge_off=self.edge_off,
+                            r_lo=self.ranges["lo"], r_hi=self.ranges["hi"], r_to=self.ranges["to"], is_end=self.is_end,
+                            endid_off=self.endid_off, endids=self.endids, **extra)
+
+    @classmethod
+    def load(cls, path_or_npz) -> "FlatDfa":
+        z = np.load(path_or_npz) if isinstance(path_or_npz, (str, os.PathLike)) else path_or_npz
+        r = np.zeros(len(z["r_lo"]), dtype=RANGE_DTYPE)
+        r["lo"], r["hi"], r["to"] = z["r_lo"], z["r_hi"], z["r_to"]
+        return cls(int(z["nstates"]), int(z["start"]), z["edge_off"], r, z["is_end"], z["endid_off"], z["endids"])
+
+
+class Plan:
+    """Host-side table plan (fsm_hip_plan_*): inspection only, never executes inputs."""
+
+    _WHAT = dict(scalars=(0, np.uint32), cls=(1, np.uint8), new2old=(2, np.uint32), fin=(3, np.uint32),
+                 dense=(4, np.uint32), tiny_col=(5, np.uint64), lds_tab=(6, np.uint16), comb=(7, np.uint32),
+                 comb_dflt=(8, np.uint32), comb_off=(9, np.uint32), comb_fin=(10, np.uint32), glob_tab=(11, np.uint32))
+
+    def __init__(self, flat: FlatDfa, flags: int = 0, lds_limit: int = 0):
+        lib = load_library()
+        C.set_errno(0)
+        d = flat.desc()
+        self._h = lib.fsm_hip_plan_create(C.byref(d), flags, lds_limit)
+        if not self._h:
+            raise _oserr("fsm_hip_plan_create")
+        self._lib = lib
+        s = self.get("scalars")
+        (self.nstates, self.S1, self.start, self.C, self.abs_min, self.nabsorbing, self.layout, self.row_bytes,
+         self.comb_abs_min_off) = (int(x) for x in s)
+
+    def get(self, what: str) -> np.ndarray:
+        w, dt = self._WHAT[what]
+        p, n = C.c_void_p(), C.c_size_t()
+        if self._lib.fsm_hip_plan_get(self._h, w, C.byref(p), C.byref(n)) != 0:
+            raise _oserr("fsm_hip_plan_get")
+        if n.value == 0:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsm_hip_plan_free(self._h)
+            self._h = None
+
+
+class HipDfa:
+    """struct fsm_hip_dfa *: a DFA resident on the GPU."""
+
+    def __init__(self, flat: Optional[FlatDfa] = None, flags: int = 0, *, handle=None):
+        self._lib = load_library()
+        if handle is not None:
+            self._h = handle
+        else:
+            C.set_errno(0)
+            d = flat.desc()
+            self._h = self._lib.fsm_hip_dfa_create(C.byref(d), flags)
+            if not self._h:
+                raise _oserr("fsm_hip_dfa_create")
+
+    @classmethod
+    def compile_fsm(cls, fsm_ptr: int, flags: int = 0) -> "HipDfa":
+        """fsm_hip_compile(const struct fsm *): libfsm must already be loaded RTLD_GLOBAL."""
+        lib = load_library()
+        C.set_errno(0)
+        h = lib.fsm_hip_compile(fsm_ptr, flags)
+        if not h:
+            raise _oserr("fsm_hip_compile")
+        return cls(handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fsm_hip_dfa_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self) -> dict:
+        i = _Info()
+        if self._lib.fsm_hip_dfa_info(self._h, C.byref(i)) != 0:
+            raise _oserr("fsm_hip_dfa_info")
+        d = {k: getattr(i, k) for k, _ in _Info._fields_ if k != "reserved"}
+        d["layout_name"] = LAYOUT_NAMES.get(i.layout, "?")
+        return d
+
+    def tune(self, knob: int, value: int):
+        if self._lib.fsm_hip_dfa_tune(self._h, knob, value) != 0:
+            raise _oserr("fsm_hip_dfa_tune")
+
+    # ---- host-buffer fronts -------------------------------------------------
+    def exec_batch(self, data: np.ndarray, lens: Optional[np.ndarray] = None, want_bitmap: bool = True):
+        """data: uint8 [n, stride]; returns (end u32[n], bitmap u64[ceil(n/64)])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, stride = data.shape
+        end = np.empty(n, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch(self._h, _ptr(data), stride, _ptr(lens), n, _ptr(end), _ptr(bm)) != 0:
+            raise _oserr("fsm_hip_exec_batch")
+        return end, bm
+
+    def exec_batch_offsets(self, base: np.ndarray, off: np.ndarray, want_bitmap: bool = True):
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        end = np.empty(n, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets(self._h, _ptr(base) if len(base) else None, _ptr(off), n, _ptr(end), _ptr(bm)) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets")
+        return end, bm
+
+    def exec_strings(self, strings: Sequence[bytes]):
+        off = np.zeros(len(strings) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in strings])
+        base = np.frombuffer(b"".join(strings), dtype=np.uint8)
+        return self.exec_batch_offsets(base, off)
+
+    def match_buffer(self, s: bytes) -> int:
+        C.set_errno(0)
+        r = self._lib.fsm_hip_match_buffer(self._h, s, len(s))
+        if r < 0:
+            raise _oserr("fsm_hip_match_buffer")
+        return r
+
+    # ---- device-pointer front (raw addresses, e.g. torch tensors' data_ptr()) ----
+    def exec_batch_device(self, d_base: int, stride: int, n: int, d_end: int = 0, d_bitmap: int = 0, d_len: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_device(self._h, d_base, stride, d_len or None, n, d_end or None, d_bitmap or None, stream or None) != 0:
+            raise _oserr("fsm_hip_exec_batch_device")
+
+    def exec_batch_offsets_device(self, d_base: int, d_off: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets_device(self._h, d_base, d_off, n, d_end or None, d_bitmap or None, stream or None) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets_device")
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.fsm_hip_last_kernel_ms(self._h))
+
+    # ---- end-ids --------------------------------------------------------------
+    def endids(self, end_state: int) -> np.ndarray:
+        n = self._lib.fsm_hip_endid_count(self._h, end_state)
+        buf = np.zeros(max(n, 1), dtype=np.uint32)
+        if self._lib.fsm_hip_endid_get(self._h, end_state, n, _ptr(buf)) != 1:
+            raise RuntimeError("fsm_hip_endid_get")
+        return buf[:n]
+
+
+def _gen_args(alphabet, plant):
+    a = np.frombuffer(bytes(alphabet), dtype=np.uint8).copy() if alphabet else None
+    p = np.frombuffer(bytes(plant), dtype=np.uint8).copy() if plant else None
+    return a, p
+
+
+def gen_inputs_host(n: int, stride: int, first_index: int = 0, seed: int = 0x5EEDF5A1, alphabet: Optional[bytes] = None,
+                    plant: Optional[bytes] = None, plant_every: int = 0) -> np.ndarray:
+    lib = load_library()
+    out = np.empty((n, stride), dtype=np.uint8)
+    a, p = _gen_args(alphabet, plant)
+    lib.fsm_hip_gen_inputs_host(_ptr(out), stride, n, first_index, seed, _ptr(a), len(a) if a is not None else 0,
+                                _ptr(p), len(p) if p is not None else 0, plant_every)
+    return out
+
+
+def gen_inputs_device(d_base: int, n: int, stride: int, first_index: int = 0, seed: int = 0x5EEDF5A1,
+                      alphabet: Optional[bytes] = None, plant: Optional[bytes] = None, plant_every: int = 0, stream: int = 0):
+    lib = load_library()
+    a, p = _gen_args(alphabet, plant)
+    C.set_errno(0)
+    if lib.fsm_hip_gen_inputs_device(d_base, stride, n, first_index, seed, _ptr(a), len(a) if a is not None else 0,
+                                     _ptr(p), len(p) if p is not None else 0, plant_every, stream or None) != 0:
+        raise _oserr("fsm_hip_gen_inputs_device")
+
+
+def pack_affixes(items: Sequence[bytes]) -> np.ndarray:
+    """[len<=7, b0..b6] entries for the affix generator."""
+    t = np.zeros((len(items), 8), dtype=np.uint8)
+    for i, s in enumerate(items):
+        assert len(s) <= 7
+        t[i, 0] = len(s)
+        t[i, 1:1 + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    return t
+
+
+def gen_affix_inputs_host(n: int, stride: int, first_index: int, seed: int, alphabet: bytes, body: bytes,
+                          prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2) -> np.ndarray:
+    lib = load_library()
+    lib.fsm_hip_gen_affix_inputs_host.restype = None
+    out = np.empty((n, stride), dtype=np.uint8)
+    a, b = _gen_args(alphabet, body)
+    p, s = pack_affixes(prefixes), pack_affixes(suffixes)
+    lib.fsm_hip_gen_affix_inputs_host(_ptr(out), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index), C.c_uint64(seed),
+                                      _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)), _ptr(p), C.c_uint(len(p)),
+                                      _ptr(s), C.c_uint(len(s)), C.c_uint(every))
+    return out
+
+
+def gen_affix_inputs_device(d_base: int, n: int, stride: int, first_index: int, seed: int, alphabet: bytes, body: bytes,
+                            prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2, stream: int = 0):
+    lib = load_library()
+    a, b = _gen_args(alphabet, body)
+    p, s = pack_affixes(prefixes), pack_affixes(suffixes)
+    C.set_errno(0)
+    r = lib.fsm_hip_gen_affix_inputs_device(C.c_void_p(d_base), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index),
+                                            C.c_uint64(seed), _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)),
+                                            _ptr(p), C.c_uint(len(p)), _ptr(s), C.c_uint(len(s)), C.c_uint(every),
+                                            C.c_void_p(stream or None))
+    if r != 0:
+        raise _oserr("fsm_hip_gen_affix_inputs_device")

@@ -567,3 +567,89 @@ extern "C" void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size
 			memcpy(p + plant_offset(g, gi), g.plant, g.plant_len);
 	}
 }
+
+/* ---- affix generator (see walk_kernels.h) ---- */
+
+static int fill_affix(AffixArgs &x, const unsigned char *body, unsigned nbody, unsigned npfx, unsigned nsfx, unsigned every)
+{
+	memset(&x, 0, sizeof x);
+	if (body == nullptr || nbody == 0 || nbody > 256 || npfx == 0 || nsfx == 0 || every == 0) return -1;
+	x.npfx = npfx; x.nsfx = nsfx; x.every = every; x.nbody = nbody;
+	memcpy(x.body, body, nbody);
+	return 0;
+}
+
+static int check_affixes(const unsigned char *t, unsigned n, size_t stride)
+{
+	if (t == nullptr) return -1;
+	for (unsigned i = 0; i < n; i++) if (t[8 * i] > 7 || t[8 * i] > stride / 2) return -1;
+	return 0;
+}
+
+extern "C" int fsm_hip_gen_affix_inputs_device(void *d_base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every, void *hip_stream)
+{
+	GenArgs g;
+	AffixArgs x;
+	unsigned char *d_tab = nullptr;
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	int rc = -1;
+	if (stride == 0 || stride % 8u != 0 || (reinterpret_cast<uintptr_t>(d_base) % 8u) != 0 ||
+	    fill_gen(g, d_base, stride, n, first_index, seed, alphabet, nalpha, nullptr, 0, 0) != 0 ||
+	    fill_affix(x, body, nbody, npfx, nsfx, every) != 0 ||
+	    check_affixes(prefixes, npfx, stride) != 0 || check_affixes(suffixes, nsfx, stride) != 0) {
+		errno = EINVAL;
+		return -1;
+	}
+	if (n == 0) return 0;
+	HIP_TRY(hipMalloc((void **)&d_tab, 8u * ((size_t)npfx + nsfx)));
+	HIP_TRY(hipMemcpy(d_tab, prefixes, 8u * (size_t)npfx, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_tab + 8u * (size_t)npfx, suffixes, 8u * (size_t)nsfx, hipMemcpyHostToDevice));
+	x.pfx = d_tab;
+	x.sfx = d_tab + 8u * (size_t)npfx;
+	{
+		uint64_t total = (uint64_t)n * (stride / 8u);
+		uint64_t blocks = (total + 255) / 256;
+		if (blocks > 256u * 64u) blocks = 256u * 64u;
+		hipLaunchKernelGGL(gen_affix_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, x);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(s)); /* the table is freed below */
+	}
+	rc = 0;
+fail:
+	{
+		int e = errno;
+		if (d_tab) (void)hipFree(d_tab);
+		errno = e;
+	}
+	return rc;
+}
+
+extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every)
+{
+	GenArgs g;
+	AffixArgs x;
+	if (fill_gen(g, base, stride, n, first_index, seed, alphabet, nalpha, nullptr, 0, 0) != 0 ||
+	    fill_affix(x, body, nbody, npfx, nsfx, every) != 0 ||
+	    check_affixes(prefixes, npfx, stride) != 0 || check_affixes(suffixes, nsfx, stride) != 0) return;
+	x.pfx = prefixes;
+	x.sfx = suffixes;
+	for (size_t row = 0; row < n; row++) {
+		unsigned char *p = base + row * stride;
+		for (size_t t = 0; t < stride; t += 8) {
+			uint64_t v = affix_word(g, x, first_index + row, t / 8);
+			for (size_t k = 0; k < 8 && t + k < stride; k++) p[t + k] = (unsigned char)(v >> (8 * k));
+		}
+	}
+}

@@ -426,6 +426,48 @@ gen_inputs_kernel(const GenArgs g)
 	}
 }
 
+/* Affix generator (rx-style workload, BASELINE config 3): rows whose global
+ * index is a multiple of `every` are  prefix + body alphabet + suffix  (exactly
+ * stride bytes, so they can match ^<prefix>[0-9]+(x|yz)$-like patterns); all
+ * other rows are random over the plain alphabet.  affix entries are 8 bytes:
+ * [len, b0..b6]. */
+struct AffixArgs {
+	const unsigned char *pfx, *sfx; /* npfx / nsfx entries of 8 bytes */
+	uint32_t npfx, nsfx, every, nbody;
+	unsigned char body[256];
+};
+
+__host__ __device__ __forceinline__ uint64_t affix_word(const GenArgs &g, const AffixArgs &x, uint64_t gi, uint64_t wi)
+{
+	if (gi % x.every != 0) return gen_word(g, gi, wi);
+	const uint64_t r = mix64(g.seed ^ (gi * 0x9E3779B97F4A7C15ull) ^ wi);
+	const uint64_t h = mix64(g.seed ^ gi ^ 0x5A5A5A5A5A5A5A5Aull);
+	const unsigned char *pe = x.pfx + 8u * (uint32_t)((h & 0xffffffffu) % x.npfx);
+	const unsigned char *se = x.sfx + 8u * (uint32_t)((h >> 32) % x.nsfx);
+	const uint32_t pl = pe[0], sl = se[0];
+	uint64_t o = 0;
+	for (int k = 0; k < 8; k++) {
+		const uint64_t pos = wi * 8u + k;
+		unsigned char b = x.body[((r >> (8 * k)) & 0xff) % x.nbody];
+		if (pos < pl) b = pe[1 + pos];
+		else if (pos >= g.stride - sl) b = se[1 + (pos - (g.stride - sl))];
+		o |= (uint64_t)b << (8 * k);
+	}
+	return o;
+}
+
+__global__ void __launch_bounds__(256)
+gen_affix_kernel(const GenArgs g, const AffixArgs x)
+{
+	const uint64_t wpr = g.stride / 8u;
+	const uint64_t total = g.n * wpr;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t row = t / wpr, wi = t - row * wpr;
+		*reinterpret_cast<uint64_t *>(g.base + row * g.stride + wi * 8u) = affix_word(g, x, g.first_index + row, wi);
+	}
+}
+
 } // namespace fsmhip
+
 
 #endif

@@ -1,0 +1,280 @@
+/*
+ * oracle/ref_helper.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * Thin C wrappers over the REAL reference libfsm/libre (built by
+ * oracle/build_ref.sh from /root/reference into oracle/_ref/), so that Python
+ * tests, the golden-vector generator and bench.py's cpu_baseline leg can
+ *   - compile regexes / unions / Aho-Corasick string sets into DFAs,
+ *   - run the literal reference fsm_exec() (src/libfsm/exec.c:85-167) and the
+ *     DFAVM interpreters (src/libfsm/vm/v1.c:321-432, v2.c:248-333) over
+ *     batches of (ptr,len) inputs.
+ * Built into oracle/_ref/libref_helper.so, linked against libfsm_ref.so.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <fsm/fsm.h>
+#include <fsm/bool.h>
+#include <fsm/options.h>
+#include <fsm/vm.h>
+#include <re/re.h>
+#include <re/strings.h>
+
+/* (ptr,len) getc: fsm_sgetc would stop at the first NUL (src/libfsm/getc.c:25-29);
+ * same shape as theft/wrap.c:19-36 in the reference. */
+struct span {
+	const unsigned char *p, *e;
+};
+
+static int
+span_getc(void *opaque)
+{
+	struct span *s = opaque;
+	if (s->p == s->e) {
+		return EOF;
+	}
+	return *s->p++;
+}
+
+struct fsm *
+rh_re_comp(int dialect, const char *re, int flags, int determinise, int minimise, long endid)
+{
+	const char *s = re;
+	struct re_err err;
+	struct fsm *fsm;
+
+	fsm = re_comp((enum re_dialect) dialect, fsm_sgetc, &s, NULL, (enum re_flags) flags, &err);
+	if (fsm == NULL) {
+		return NULL;
+	}
+	if (determinise && !fsm_determinise(fsm)) {
+		fsm_free(fsm);
+		return NULL;
+	}
+	if (minimise && !fsm_minimise(fsm)) {
+		fsm_free(fsm);
+		return NULL;
+	}
+	if (endid >= 0 && !fsm_setendid(fsm, (fsm_end_id_t) endid)) {
+		fsm_free(fsm);
+		return NULL;
+	}
+	return fsm;
+}
+
+/* rx-style multi-pattern DFA: each pattern det+min+fsm_setendid(i), then
+ * fsm_union_array + fsm_determinise, NOT minimised so end-ids stay distinct
+ * (src/rx/main.c:1338-1385, src/re/main.c:857-987). */
+struct fsm *
+rh_union_res(int dialect, const char *const *res, size_t n, int flags)
+{
+	struct fsm **a;
+	struct fsm *u;
+	size_t i;
+
+	a = calloc(n ? n : 1, sizeof *a);
+	if (a == NULL) {
+		return NULL;
+	}
+	for (i = 0; i < n; i++) {
+		a[i] = rh_re_comp(dialect, res[i], flags, 1, 1, (long) i);
+		if (a[i] == NULL) {
+			size_t j;
+			for (j = 0; j < i; j++) {
+				fsm_free(a[j]);
+			}
+			free(a);
+			return NULL;
+		}
+	}
+	u = fsm_union_array(n, a, NULL);
+	free(a);
+	if (u == NULL) {
+		return NULL;
+	}
+	if (!fsm_determinise(u)) {
+		fsm_free(u);
+		return NULL;
+	}
+	return u;
+}
+
+/* Aho-Corasick DFA over a word list (src/libre/re_strings.c:83-136);
+ * with_endids: word i carries end-id i. */
+struct fsm *
+rh_re_strings(const char *const *words, const uint32_t *lens, size_t n, int flags, int with_endids)
+{
+	struct re_strings *g;
+	struct fsm *fsm;
+	size_t i;
+
+	g = re_strings_new();
+	if (g == NULL) {
+		return NULL;
+	}
+	for (i = 0; i < n; i++) {
+		fsm_end_id_t id = (fsm_end_id_t) i;
+		if (!re_strings_add_raw(g, words[i], lens[i], with_endids ? &id : NULL)) {
+			re_strings_free(g);
+			return NULL;
+		}
+	}
+	fsm = re_strings_build(g, NULL, (enum re_strings_flags) flags);
+	re_strings_free(g);
+	return fsm;
+}
+
+void
+rh_fsm_free(struct fsm *fsm)
+{
+	fsm_free(fsm);
+}
+
+unsigned
+rh_countstates(const struct fsm *fsm)
+{
+	return fsm_countstates(fsm);
+}
+
+int
+rh_shuffle(struct fsm *fsm, unsigned seed)
+{
+	return fsm_shuffle(fsm, seed);
+}
+
+/* literal reference fsm_exec on one (ptr,len) input */
+int
+rh_exec(const struct fsm *fsm, const unsigned char *buf, size_t len, unsigned *end)
+{
+	struct span s;
+	fsm_state_t st = 0;
+	int r;
+
+	s.p = buf;
+	s.e = buf + len;
+	r = fsm_exec(fsm, span_getc, &s, &st, NULL);
+	if (r == 1 && end != NULL) {
+		*end = st;
+	}
+	return r;
+}
+
+/* packed batch: input i = base[off[i] .. off[i+1]); end[i] = 0xFFFFFFFF unless ret[i]==1.
+ * Returns seconds spent inside the fsm_exec loop (CLOCK_MONOTONIC, as reperf.c:614-648). */
+double
+rh_exec_batch(const struct fsm *fsm, const unsigned char *base, const uint64_t *off, size_t n,
+	int8_t *ret, uint32_t *end)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		unsigned e = 0xFFFFFFFFu;
+		int r = rh_exec(fsm, base + off[i], (size_t) (off[i + 1] - off[i]), &e);
+		if (ret != NULL) {
+			ret[i] = (int8_t) r;
+		}
+		if (end != NULL) {
+			end[i] = r == 1 ? e : 0xFFFFFFFFu;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+double
+rh_exec_batch_stride(const struct fsm *fsm, const unsigned char *base, size_t stride, size_t n,
+	int8_t *ret, uint32_t *end)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		unsigned e = 0xFFFFFFFFu;
+		int r = rh_exec(fsm, base + i * stride, stride, &e);
+		if (ret != NULL) {
+			ret[i] = (int8_t) r;
+		}
+		if (end != NULL) {
+			end[i] = r == 1 ? e : 0xFFFFFFFFu;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+size_t
+rh_endid_count(const struct fsm *fsm, unsigned state)
+{
+	return fsm_endid_count(fsm, state);
+}
+
+int
+rh_endid_get(const struct fsm *fsm, unsigned state, size_t n, unsigned *buf)
+{
+	return fsm_endid_get(fsm, state, n, buf);
+}
+
+/* reference DFAVM: version 1 or 2 bytecode (src/libfsm/vm.c:88-131) */
+struct fsm_dfavm *
+rh_vm_compile(const struct fsm *fsm, int version)
+{
+	static const struct fsm_options opt_zero;
+	struct fsm_options opt = opt_zero;
+	struct fsm_vm_compile_opts vo;
+
+	vo.flags = FSM_VM_COMPILE_DEFAULT_FLAGS;
+	vo.output = version == 1 ? FSM_VM_COMPILE_VM_V1 : FSM_VM_COMPILE_VM_V2;
+	vo.log = NULL;
+	return fsm_vm_compile_with_options(fsm, &opt, vo);
+}
+
+void
+rh_vm_free(struct fsm_dfavm *vm)
+{
+	fsm_vm_free(vm);
+}
+
+double
+rh_vm_match_batch_stride(const struct fsm_dfavm *vm, const unsigned char *base, size_t stride, size_t n,
+	int8_t *ret)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		int r = fsm_vm_match_buffer(vm, (const char *) (base + i * stride), stride);
+		if (ret != NULL) {
+			ret[i] = (int8_t) r;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+double
+rh_vm_match_batch(const struct fsm_dfavm *vm, const unsigned char *base, const uint64_t *off, size_t n,
+	int8_t *ret)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		int r = fsm_vm_match_buffer(vm, (const char *) (base + off[i]), (size_t) (off[i + 1] - off[i]));
+		if (ret != NULL) {
+			ret[i] = (int8_t) r;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,57 @@
+"""Shared helpers for the test-suite: golden fixture loading."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from libfsm_amd import FlatDfa, gen_inputs_host
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, path):
+        self.path = path
+        self.name = os.path.relpath(path, GOLDEN)
+        z = np.load(path)
+        self.flat = FlatDfa.load(z)
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.ret = z["ret"]
+        self.end = z["end"]
+        self.expect = z["expect"] if "expect" in z else None
+        self.ids_off = z["ids_off"] if "ids_off" in z else None
+        self.ids = z["ids"] if "ids" in z else None
+        if "in_off" in z:                      # packed variable-length inputs
+            self.base, self.off = z["in_bytes"], z["in_off"]
+            self.rows = None
+        elif "in_rows" in z:                   # fixed-stride rows stored verbatim
+            self.rows = z["in_rows"]
+            self.base = self.off = None
+        else:                                  # rows defined by the generator parameters
+            g = self.meta["gen"]
+            self.rows = gen_inputs_host(g["n"], g["stride"], 0, g["seed"], None, g["plant"].encode(), g["plant_every"])
+            assert int(self.rows.astype(np.uint64).sum()) == int(z["in_sum"]), "generator drifted from the golden inputs"
+            self.base = self.off = None
+
+    def strings(self):
+        if self.off is not None:
+            return [bytes(self.base[int(self.off[i]):int(self.off[i + 1])]) for i in range(len(self.off) - 1)]
+        return [bytes(r) for r in self.rows]
+
+    def packed(self):
+        if self.off is not None:
+            return self.base, self.off
+        n, L = self.rows.shape
+        return self.rows.reshape(-1), (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+
+    def ids_of(self, i):
+        return self.ids[int(self.ids_off[i]):int(self.ids_off[i + 1])]
+
+
+def all_golden_paths():
+    return sorted(glob.glob(os.path.join(GOLDEN, "retest", "*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def golden_id(p):
+    return os.path.relpath(p, GOLDEN).replace(".npz", "")

@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- regenerate the committed golden vectors.
+
+Runs ONLY where /root/reference exists (the build container): it drives the
+REAL reference (oracle/_ref, built by oracle/build_ref.sh from the reference's
+own sources) and freezes its answers as small .npz fixtures:
+
+  retest/NNN.npz   every regex block of the reference's tests/retest/*.tst
+                   (37 regexes, 115 +/- cases): flattened DFA, the test inputs,
+                   fsm_exec's return code and end state, and the fixture's own
+                   +/- expectation (checked here to agree with fsm_exec).
+  endids_*.npz     the constructions of tests/endids/endids2_union_many_endids.c
+                   (6 patterns x 5 ids, union, determinise[, minimise]) with
+                   fsm_exec + fsm_endid_get answers.
+  re_strings_*.npz tests/re_strings/re_strings{1,2,3,4}.c word lists.
+  c1.npz           BASELINE config 1/2 DFA: PCRE [Ll]ibf+(sm)* det+min, end-id 0,
+                   with fsm_exec answers on generator inputs (parameters stored).
+  c3.npz           BASELINE config 3: 1024 anchored PCRE unioned + determinised
+                   (rx-style, not minimised), end-id = pattern index, with
+                   fsm_exec + end-id answers on 512 x 1 KiB inputs.
+
+Each fixture stores the flat DFA (libfsm_amd.FlatDfa.save) produced by the
+product's own fsm_hip_flatten() from the reference `struct fsm *`.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from libfsm_amd import FlatDfa, gen_inputs_host  # noqa: E402
+from oracle.pyoracle import RE_FLAGS, RefFsm, build_ref  # noqa: E402
+
+REF = os.environ.get("FSM_REF", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_escapes(s: bytes):
+    """retest's escape grammar for test strings (src/retest/main.c:299-441):
+    \\a \\b \\e \\f \\n \\r \\t \\v \\" \\\\, \\ooo (<=3 octal digits), \\xHH, \\x{HH}."""
+    out = bytearray()
+    i, n = 0, len(s)
+    simple = {ord("a"): 7, ord("b"): 8, ord("e"): 27, ord("f"): 12, ord("n"): 10, ord("r"): 13, ord("t"): 9,
+              ord("v"): 11, ord('"'): ord('"'), ord("\\"): ord("\\")}
+    while i < n:
+        c = s[i]
+        if c != 0x5C:
+            out.append(c)
+            i += 1
+            continue
+        i += 1
+        if i >= n:
+            raise ValueError("dangling backslash")
+        c = s[i]
+        if c in simple:
+            out.append(simple[c])
+            i += 1
+        elif ord("0") <= c <= ord("7"):
+            v, nd = 0, 0
+            while i < n and nd < 3 and ord("0") <= s[i] <= ord("7"):
+                v = v * 8 + (s[i] - ord("0"))
+                nd += 1
+                i += 1
+            out.append(v & 0xFF)
+        elif c == ord("x"):
+            i += 1
+            curly = i < n and s[i] == ord("{")
+            if curly:
+                i += 1
+            v, nd = 0, 0
+            while i < n and nd < 2 and chr(s[i]) in "0123456789abcdefABCDEF":
+                v = v * 16 + int(chr(s[i]), 16)
+                nd += 1
+                i += 1
+            if curly:
+                if i >= n or s[i] != ord("}"):
+                    raise ValueError("incomplete \\x{")
+                i += 1
+            out.append(v & 0xFF)
+        else:
+            raise ValueError("invalid escape")
+    return bytes(out)
+
+
+def parse_tst(path):
+    """Yield (line, dialect, flags, regex, [(line, expect_match, raw, bytes)...]) per regex block,
+    following process_test_file (src/retest/main.c:738-1177)."""
+    dialect, default = "pcre", "pcre"
+    flags, opt_e = 0, False
+    restore, saved_e = False, False  # "O &": main.c:861-865, restored at every blank line :832-834
+    regex, cases, rline = None, [], 0
+    with open(path, "rb") as f:
+        for ln, raw in enumerate(f.read().split(b"\n"), 1):
+            s = raw
+            if len(s) == 0:
+                if regex is not None:
+                    yield rline, dialect_at, rflags, regex, cases
+                regex, cases, flags = None, [], 0
+                if restore:
+                    opt_e = saved_e
+                continue
+            if s[:1] == b"#":
+                continue
+            if s[:1] == b"R" and (len(s) == 1 or s[1:2] == b" "):
+                dialect = default if len(s) == 1 else s[2:].decode()
+                continue
+            if s[:2] == b"O ":
+                if s[2:3] == b"&":
+                    restore, saved_e = True, opt_e
+                    continue
+                arg = b"e" in s[3:]
+                if s[2:3] == b"=":
+                    opt_e = arg
+                elif s[2:3] == b"+":
+                    opt_e = opt_e or arg
+                elif s[2:3] == b"-":
+                    opt_e = opt_e and not arg
+                continue
+            if s[:2] == b"M ":
+                for ch in s[2:].decode():
+                    if ch == "0":
+                        flags = 0
+                    elif ch in RE_FLAGS:
+                        flags |= RE_FLAGS[ch]
+                continue
+            if s[:1] == b"~":
+                s = s[1:]
+            if regex is None:
+                regex = parse_escapes(s) if opt_e else s
+                rline, dialect_at, rflags = ln, dialect, flags
+            else:
+                assert s[:1] in (b"+", b"-"), (path, ln, s)
+                cases.append((ln, s[:1] == b"+", s[1:], parse_escapes(s[1:])))
+    if regex is not None:
+        yield rline, dialect_at, rflags, regex, cases
+
+
+def pack(strings):
+    off = np.zeros(len(strings) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    return np.frombuffer(b"".join(strings), np.uint8), off
+
+
+def endid_csr(fsm, ends):
+    """fsm_endid_get for every matched end state, as CSR aligned with the inputs."""
+    off, ids = [0], []
+    for e in ends:
+        if e != 0xFFFFFFFF:
+            ids.extend(int(x) for x in fsm.endids(int(e)))
+        off.append(len(ids))
+    return np.array(off, np.uint32), np.array(ids, np.uint32)
+
+
+def save_case(path, fsm, strings, meta, expect=None):
+    flat = fsm.flatten()
+    base, off = pack(strings)
+    ret, end = fsm.exec_offsets(base, off)
+    io, ii = endid_csr(fsm, end)
+    extra = dict(in_bytes=base, in_off=off, ret=ret, end=end, ids_off=io, ids=ii,
+                 meta=np.frombuffer(json.dumps(meta).encode(), np.uint8))
+    if expect is not None:
+        extra["expect"] = np.array(expect, np.int8)
+        assert (ret == extra["expect"]).all(), (meta, ret, expect)
+    flat.save(path, **extra)
+    return flat, ret, end
+
+
+def gen_retest():
+    d = os.path.join(OUT, "retest")
+    os.makedirs(d, exist_ok=True)
+    k = nre = ncase = 0
+    for fn in sorted(os.listdir(os.path.join(REF, "tests/retest"))):
+        if not fn.endswith(".tst"):
+            continue
+        for rline, dialect, flags, regex, cases in parse_tst(os.path.join(REF, "tests/retest", fn)):
+            nre += 1
+            fsm = RefFsm.re_comp(dialect, regex.split(b"\0")[0], flags, True, True)
+            meta = dict(file=f"tests/retest/{fn}", line=rline, dialect=dialect, flags=flags,
+                        regex=regex.decode("latin1"), case_lines=[c[0] for c in cases])
+            save_case(os.path.join(d, f"{k:03d}.npz"), fsm, [c[3] for c in cases], meta, [int(c[1]) for c in cases])
+            ncase += len(cases)
+            k += 1
+    print(f"retest: {nre} regexes, {ncase} cases")
+    assert (nre, ncase) == (37, 115), "SURVEY section 8c counts"
+
+
+def gen_endids():
+    # tests/endids/endids2_union_many_endids.c:25-33, :137-170
+    patterns = [b"abc", b"def", b"abc.def", b"abc_def", b"foo", b"bar"]
+    u = None
+    for i, p in enumerate(patterns):
+        f = RefFsm.re_comp("native", p, 0, True, True)
+        for j in range(5):
+            f.setendid(5 * i + j + 1)
+        if u is None:
+            u = f
+        else:
+            u.union_with(f)
+    u.determinise()
+    inputs = [b"abc", b"def", b"abcXdef", b"abc_def", b"foo", b"bar", b"", b"ab", b"xxabcyy", b"abc_def foo bar",
+              b"foobar", b"barfoo", b"abcdef", b"de", b"fo\0o", b"abc\0def", b"zzz", b"abc.def", b"ABC", b"barabcfoo_def"]
+    meta = dict(source="tests/endids/endids2_union_many_endids.c", patterns=[p.decode() for p in patterns], stage="determinised")
+    save_case(os.path.join(OUT, "endids_union_det.npz"), u, inputs, meta)
+    u.minimise()
+    meta["stage"] = "minimised"
+    save_case(os.path.join(OUT, "endids_union_min.npz"), u, inputs, meta)
+
+
+def gen_re_strings():
+    # tests/re_strings/re_strings{1,2,3,4}.c + testutil.c:15-70 (flags = 0, end-id = index)
+    sets = {
+        1: [b"aa", b"ab", b"ac", b"ba", b"bb", b"bc", b"ca", b"cb", b"cc"],
+        2: [b"first", b"duplicate", b"duplicate", b"duplicate", b"last"],
+        3: [b"duplicate", b"duplicate", b"duplicate"],
+    }
+    for k, words in sets.items():
+        f = RefFsm.re_strings(words, 0, True)
+        inputs = list(words) + [b"", b"x", b"xx" + words[0], words[-1] + b"yy", words[0] + words[-1], b"a", b"dup"]
+        meta = dict(source=f"tests/re_strings/re_strings{k}.c", words=[w.decode() for w in words], flags=0)
+        flat, ret, end = save_case(os.path.join(OUT, f"re_strings_{k}.npz"), f, inputs, meta)
+        for i, w in enumerate(words):  # the reference test's own assertion (testutil.c:45-60)
+            assert ret[i] == 1 and i in f.endids(int(end[i]))
+
+
+C3_SEED = 20260923
+
+
+def c3_patterns(n=1024, seed=C3_SEED):
+    """1 024 patterns ^<2-3 lowercase>[0-9]+(x|yz)$.  Prefixes may repeat:
+    two patterns with one prefix share their end states, which then carry two end-ids."""
+    rng = random.Random(seed)
+    pats = []
+    while len(pats) < n:
+        k = 2 if rng.random() < 0.62 else 3
+        pre = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(k))
+        pats.append(f"^{pre}[0-9]+(x|yz)$".encode())
+    return pats
+
+
+def c3_inputs(pats, n, L=1024, seed=C3_SEED + 1):
+    """50 % derived from a pattern (prefix + digits + suffix, exactly L bytes), 50 % random over [a-z0-9]."""
+    rng = np.random.RandomState(seed)
+    alnum = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", np.uint8)
+    digits = np.frombuffer(b"0123456789", np.uint8)
+    out = np.empty((n, L), np.uint8)
+    for i in range(n):
+        if i % 2 == 0:
+            p = pats[rng.randint(len(pats))]
+            pre = p[1:p.index(b"[")]
+            suf = b"x" if rng.randint(2) else b"yz"
+            row = digits[rng.randint(0, 10, L)]
+            row[:len(pre)] = np.frombuffer(pre, np.uint8)
+            row[L - len(suf):] = np.frombuffer(suf, np.uint8)
+            if rng.randint(8) == 0:  # a few near-misses: break one byte
+                row[rng.randint(L)] = ord("!")
+            out[i] = row
+        else:
+            out[i] = alnum[rng.randint(0, 36, L)]
+    return out
+
+
+def gen_c1():
+    f = RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
+    flat = f.flatten()
+    assert flat.nstates == 5
+    params = dict(n=4096, stride=256, seed=0x5EEDF5A1, plant="Libfsm", plant_every=8)
+    data = gen_inputs_host(params["n"], params["stride"], 0, params["seed"], None, params["plant"].encode(), params["plant_every"])
+    ret, end = f.exec_stride(data)
+    flat.save(os.path.join(OUT, "c1.npz"), ret=ret, end=end, in_sum=np.uint64(int(data.astype(np.uint64).sum())),
+              meta=np.frombuffer(json.dumps(dict(regex="[Ll]ibf+(sm)*", dialect="pcre", gen=params)).encode(), np.uint8))
+    print("c1: accepts", int((ret == 1).sum()), "of", len(ret))
+
+
+def gen_c3():
+    pats = c3_patterns()
+    f = RefFsm.union_res("pcre", pats, 0)
+    flat = f.flatten()
+    print("c3: states", flat.nstates, "end states", int(flat.is_end.sum()))
+    data = c3_inputs(pats, 512)
+    ret, end = f.exec_stride(data)
+    io, ii = endid_csr(f, end)
+    flat.save(os.path.join(OUT, "c3.npz"), in_rows=data, ret=ret, end=end, ids_off=io, ids=ii,
+              patterns=np.frombuffer(b"\n".join(pats), np.uint8),
+              meta=np.frombuffer(json.dumps(dict(source="BASELINE.json configs[2]", seed=C3_SEED, npatterns=len(pats))).encode(), np.uint8))
+    print("c3: accepts", int((ret == 1).sum()), "of", len(ret), "multi-id ends", int(sum(1 for k in range(len(ret)) if io[k + 1] - io[k] > 1)))
+
+
+if __name__ == "__main__":
+    assert build_ref(), "needs /root/reference to build oracle/_ref"
+    gen_retest()
+    gen_endids()
+    gen_re_strings()
+    gen_c1()
+    gen_c3()

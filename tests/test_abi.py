@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares, and
+fails LOUDLY (ENODEV) instead of falling back to the CPU when there is no GPU."""
+import ctypes
+import errno
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = set()
+    for h in ("fsm_hip.h", "fsm_hip_plan.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(fsm_hip_\w+)\s*\(", txt))
+    return syms
+
+
+def test_exports_every_declared_symbol(built):
+    from libfsm_amd import load_library
+    lib = load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in sorted(syms) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.fsm_hip_version() >= 100
+
+
+def test_no_libfsm_link_dependency(built):
+    """The shim binds libfsm by dlsym at run time: the .so itself must not need libfsm."""
+    import subprocess
+    from libfsm_amd import LIB_PATH
+    out = subprocess.check_output(["readelf", "-d", LIB_PATH]).decode()
+    assert "libfsm" not in out.replace("libfsm_hip", "")
+    assert "liboracle" not in out and "_ref" not in out
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from libfsm_amd import HipDfa
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    with pytest.raises(OSError) as ei:
+        HipDfa(g.flat)
+    assert ei.value.errno == errno.ENODEV
+
+
+def test_product_sources_do_not_touch_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may use oracle/."""
+    for d, _, files in os.walk(os.path.join(ROOT, "libfsm_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".h", ".hip", ".sh")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "pyoracle" not in txt and "dfa_oracle" not in txt and "oracle/" not in txt.replace("see oracle/", ""), (d, f)
+
+
+def test_generator_host_properties(built):
+    from libfsm_amd import gen_inputs_host
+    a = gen_inputs_host(64, 256, 0, 1234)
+    b = gen_inputs_host(32, 256, 32, 1234)
+    assert np.array_equal(a[32:], b)                      # counter based: rows depend on global index only
+    assert not np.array_equal(a[0], a[1])
+    h = np.bincount(gen_inputs_host(512, 1024, 0, 99).reshape(-1), minlength=256)
+    assert h.min() > 1500 and h.max() < 2600              # ~2048 expected per value
+    c = gen_inputs_host(64, 128, 0, 5, b"abc")
+    assert set(np.unique(c)) <= set(b"abc")
+    d = gen_inputs_host(64, 128, 0, 5, None, b"Libfsm", 8)
+    for i in range(64):
+        assert (b"Libfsm" in bytes(d[i])) or i % 8 != 0

@@ -1,0 +1,299 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI (ctypes on
+libfsm_hip.so), against
+  * the committed golden vectors = answers of the REAL reference fsm_exec,
+  * the plain-C oracle on seeded inputs (ragged, empty, unaligned, odd n),
+  * the real reference live (oracle/_ref travels to the GPU box) through the
+    libfsm-facing shim fsm_hip_compile(const struct fsm *),
+  * size-independent properties at large n.
+Bit-exact everywhere: this is integer/index work."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, Golden, all_golden_paths, golden_id
+
+pytestmark = pytest.mark.gpu
+
+NO = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def hip(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    torch.cuda.set_device(0)
+    import libfsm_amd
+    libfsm_amd.load_library()   # raises if the HIP extension is missing: no silent fallback
+    return libfsm_amd
+
+
+def layouts_for(hip, flat):
+    out = []
+    for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_COMB, hip.LAYOUT_GLOBAL):
+        try:
+            out.append((L, hip.HipDfa(flat, L)))
+        except OSError:
+            pass
+    assert out and out[-1][0] == hip.LAYOUT_GLOBAL
+    return out
+
+
+def bits(bm, n):
+    return np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+@pytest.mark.parametrize("path", all_golden_paths(), ids=golden_id)
+def test_golden_vectors_all_layouts(hip, path):
+    """Every reference fixture, every table layout, through the packed (generic) kernel."""
+    g = Golden(path)
+    base, off = g.packed()
+    n = len(off) - 1
+    for L, dfa in layouts_for(hip, g.flat):
+        end, bm = dfa.exec_batch_offsets(base, off)
+        assert np.array_equal(end, g.end), (g.meta, L)
+        assert np.array_equal(bits(bm, n), g.ret == 1), (g.meta, L)
+        if g.expect is not None:
+            assert np.array_equal(end != NO, g.expect == 1)
+        if g.ids_off is not None:
+            for i in range(n):
+                got = dfa.endids(int(end[i])) if end[i] != NO else np.zeros(0, np.uint32)
+                assert np.array_equal(got, g.ids_of(i)), (g.meta, L, i)
+        dfa.close()
+
+
+@pytest.mark.parametrize("name", ["c1.npz", "c3.npz"])
+def test_fast_paths_every_mode(hip, name):
+    """Fixed-stride aligned rows: direct (NB=1,2,4,8, +nontemporal), LDS-DMA, generic; 1..16 waves."""
+    g = Golden(os.path.join(GOLDEN, name))
+    rows = g.rows
+    n = len(rows)
+    for L, dfa in layouts_for(hip, g.flat):
+        variants = [(hip.IN_GENERIC, 0, 0, 0), (hip.IN_LDSDMA, 0, 0, 0), (hip.IN_LDSDMA, 0, 0, 4)]
+        variants += [(hip.IN_DIRECT, nb, nt, 0) for nb in (1, 2, 4, 8) for nt in (0, 1)]
+        variants += [(hip.IN_DIRECT, 4, 0, w) for w in (1, 2, 8)]
+        for mode, nb, nt, waves in variants:
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            dfa.tune(hip.KNOB_NB, nb)
+            dfa.tune(hip.KNOB_NONTEMPORAL, nt)
+            dfa.tune(hip.KNOB_WAVES, waves)
+            for early in (0, 1):
+                dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                end, bm = dfa.exec_batch(rows)
+                assert np.array_equal(end, g.end), (name, L, mode, nb, nt, waves, early)
+                assert np.array_equal(bits(bm, n), g.ret == 1)
+        dfa.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 127, 129, 1000, 4097])
+def test_batch_sizes(hip, n):
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    rows = hip.gen_inputs_host(n, 128, 5, 77, None, b"libffsm", 3)
+    want = Oracle(g.flat).table_walk(rows) if n else np.zeros(0, np.uint32)
+    for L, dfa in layouts_for(hip, g.flat):
+        for mode in (hip.IN_DIRECT, hip.IN_LDSDMA, hip.IN_GENERIC):
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            end, bm = dfa.exec_batch(rows)
+            assert np.array_equal(end, want), (n, L, mode)
+            assert np.array_equal(bits(bm, n), want != NO)
+        dfa.close()
+
+
+def test_ragged_lengths_and_empty_inputs(hip):
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(21)
+    for name, alpha in (("c1.npz", b"Llibfsmx\0"), ("c3.npz", b"abcdwxyz0123456789"), ("endids_union_det.npz", b"abcdef_.or")):
+        g = Golden(os.path.join(GOLDEN, name))
+        a = np.frombuffer(alpha, np.uint8)
+        stride = 80
+        rows = a[rng.randint(0, len(a), (3001, stride))]
+        lens = rng.randint(0, stride + 1, 3001).astype(np.uint32)
+        lens[:5] = [0, 1, 15, 16, 17]
+        ret, want = Oracle(g.flat).exec_stride(rows, lens)
+        for L, dfa in layouts_for(hip, g.flat):
+            end, bm = dfa.exec_batch(rows, lens)
+            assert np.array_equal(end, want), (name, L)
+            assert np.array_equal(bits(bm, len(rows)), ret == 1)
+            dfa.close()
+
+
+def test_packed_unaligned_offsets(hip):
+    """Inputs back to back at arbitrary byte offsets (the retest-style front), incl. empty ones."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(33)
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    strings = []
+    for i in range(5000):
+        if i % 3 == 0:
+            p = pats[rng.randint(len(pats))]
+            pre = p[1:p.index(b"[")]
+            s = pre + bytes(rng.randint(48, 58, rng.randint(1, 40)).astype(np.uint8)) + (b"x" if i % 2 else b"yz")
+        else:
+            s = bytes(rng.randint(97, 123, rng.randint(0, 12)).astype(np.uint8))
+        strings.append(s)
+    ret, want = Oracle(g.flat).exec_strings(strings)
+    assert (ret == 1).sum() > 1000
+    for L, dfa in layouts_for(hip, g.flat):
+        end, bm = dfa.exec_strings(strings)
+        assert np.array_equal(end, want), L
+        dfa.close()
+
+
+def test_device_generator_equals_host(hip):
+    import torch
+    n, L = 1000, 256
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    hip.gen_inputs_device(buf.data_ptr(), n, L, 123456789, 42, b"abc0123", b"Libfsm", 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), hip.gen_inputs_host(n, L, 123456789, 42, b"abc0123", b"Libfsm", 4))
+    hip.gen_inputs_device(buf.data_ptr(), n, L, 7, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), hip.gen_inputs_host(n, L, 7, 1))
+    pf, sf = [b"ab", b"cde", b"zz"], [b"x", b"yz"]
+    hip.gen_affix_inputs_device(buf.data_ptr(), n, L, 11, 5, b"abcxyz012", b"0123456789", pf, sf, 2)
+    assert np.array_equal(buf.cpu().numpy(), hip.gen_affix_inputs_host(n, L, 11, 5, b"abcxyz012", b"0123456789", pf, sf, 2))
+
+
+def test_device_pointer_front_and_timing(hip):
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    n, L = 100_003, 1024
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    end = torch.empty(n, dtype=torch.int32, device="cuda")
+    bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    hip.gen_inputs_device(buf.data_ptr(), n, L, 0, 9, None, b"Libfsm", 8)
+    want = Oracle(g.flat).table_walk(hip.gen_inputs_host(n, L, 0, 9, None, b"Libfsm", 8))
+    s = torch.cuda.Stream()
+    for L_, dfa in layouts_for(hip, g.flat):
+        for mode in (hip.IN_DIRECT, hip.IN_LDSDMA):
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            end.fill_(-2)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s):
+                dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr(), stream=s.cuda_stream)
+            ms = dfa.last_kernel_ms()
+            s.synchronize()
+            assert 0.0 < ms < 1000.0
+            assert np.array_equal(end.cpu().numpy().view(np.uint32), want), (L_, mode)
+            assert np.array_equal(bits(bm.cpu().numpy(), n), want != NO)
+        dfa.close()
+
+
+def test_large_batch_properties(hip):
+    """Size-independent properties on 2e6 x 1 KiB (2 GB): idempotence, shard == whole,
+    popcount(bitmap) == #(end != NO_MATCH), planted rows accept, sampled rows == oracle."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    n, L = 2_000_000, 1024
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    hip.gen_inputs_device(buf.data_ptr(), n, L, 0, 0x5EEDF5A1, None, b"Libfsm", 8)
+    dfa = hip.HipDfa(g.flat)
+    e1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    e2 = torch.empty(n, dtype=torch.int32, device="cuda")
+    bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    dfa.exec_batch_device(buf.data_ptr(), L, n, e1.data_ptr(), bm.data_ptr())
+    dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_LDSDMA)
+    h = n // 2 + 64 * 7
+    dfa.exec_batch_device(buf.data_ptr(), L, h, e2.data_ptr(), 0)
+    dfa.exec_batch_device(buf.data_ptr() + h * L, L, n - h, e2.data_ptr() + 4 * h, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(e1, e2)
+    acc = (e1 != -1)
+    assert int(acc.sum()) == int(np.unpackbits(bm.cpu().numpy().view(np.uint8)).sum())
+    assert bool(acc[::8].all())                    # every 8th row has "Libfsm" planted
+    assert int(acc.sum()) < n // 8 + n // 1000     # random rows almost never match
+    idx = np.random.RandomState(1).randint(0, n, 4096)
+    rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want = Oracle(g.flat).table_walk(rows)
+    assert np.array_equal(e1.cpu().numpy().view(np.uint32)[idx], want)
+    dfa.close()
+
+
+# ---------------------------------------------------------------------------
+# live reference through the libfsm-facing shim
+# ---------------------------------------------------------------------------
+
+def _need_ref():
+    from oracle.pyoracle import have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref not present")
+
+
+@pytest.mark.parametrize("dialect,regex,flags", [
+    ("pcre", b"[Ll]ibf+(sm)*", 0), ("pcre", b"^ab+c?(de|fg)*$", 0), ("pcre", b"a.c", 16), ("glob", b"foo*bar?", 0),
+    ("native", b"(abc|abd)+x", 0), ("pcre", b"^[0-9a-f]{2,4}(:[0-9a-f]{2})*$", 1), ("pcre", b"", 0), ("pcre", b"^$", 0),
+])
+def test_shim_compile_vs_reference_fsm_exec(hip, dialect, regex, flags):
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    f = RefFsm.re_comp(dialect, regex, flags, True, True, endid=5)
+    f.shuffle(1234)                                   # renumber states: ids must still agree with THIS fsm
+    dfa = hip.HipDfa.compile_fsm(f.ptr)
+    rng = np.random.RandomState(17)
+    alpha = np.frombuffer(b"abcdefgxLlibsm0123456789:? \0\xff", np.uint8)
+    strings = [bytes(alpha[rng.randint(0, len(alpha), rng.randint(0, 40))]) for _ in range(3000)]
+    strings += [regex, b"", b"libfsm", b"abbbcdefg", b"foobar", b"fooXXbarz", b"ab:cd:ef", b"abcabdx"]
+    ret, want = f.exec_strings(strings)
+    end, _ = dfa.exec_strings(strings)
+    assert np.array_equal(end, want)
+    for e in set(int(x) for x in end if x != NO):
+        assert np.array_equal(dfa.endids(e), f.endids(e))
+    # single-input fronts: fsm_hip_match_buffer, and fsm_hip_exec with libfsm's own fsm_sgetc
+    for s in (b"libfsm", b"zzz", b"", regex):
+        r, e = f.exec_one(s)
+        assert dfa.match_buffer(s) == r
+    lib = hip.load_library()
+    ref = ctypes.CDLL(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libfsm_ref.so"))
+    sgetc = ctypes.cast(ref.fsm_sgetc, ctypes.c_void_p)
+    for s in (b"xxlibfsmyy", b"ab:cd", b"abcx"):
+        cs = ctypes.c_char_p(s)
+        pp = ctypes.pointer(cs)
+        endv = ctypes.c_uint(0xDEAD)
+        r = lib.fsm_hip_exec(dfa.handle, sgetc, ctypes.cast(pp, ctypes.c_void_p), ctypes.byref(endv), None)
+        r0, e0 = f.exec_one(s)
+        assert r == r0
+        assert endv.value == (e0 if r0 == 1 else 0xDEAD)   # *end untouched on reject (exec.c:133-138)
+    dfa.close()
+
+
+def test_shim_rejects_what_fsm_exec_rejects(hip):
+    _need_ref()
+    import errno
+    from oracle.pyoracle import RefFsm
+    nfa = RefFsm.re_comp("pcre", b"a*b|ab*", 0, False, False)       # NFA with epsilons: fsm_exec -> -1/EINVAL
+    assert nfa.exec_one(b"ab")[0] == -1
+    with pytest.raises(OSError) as ei:
+        hip.HipDfa.compile_fsm(nfa.ptr)
+    assert ei.value.errno == errno.EINVAL
+
+
+def test_aho_corasick_union_big_table(hip):
+    """re_strings over 20k words -> tens of thousands of states: exercises the HBM-resident layout."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    rng = np.random.RandomState(4)
+    alpha = np.frombuffer(b"abcdefghijklmnop", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 16, rng.randint(4, 9))]) for _ in range(20000)))
+    f = RefFsm.re_strings(words, 0, True)
+    dfa = hip.HipDfa.compile_fsm(f.ptr)
+    info = dfa.info()
+    assert info["nstates"] > 30000
+    rows = alpha[rng.randint(0, 16, (3000, 64))]
+    for i in range(0, 3000, 3):                        # end a third of the rows on a word
+        w = words[rng.randint(len(words))]
+        rows[i, 64 - len(w):] = np.frombuffer(w, np.uint8)
+    ret, want = f.exec_stride(rows[:600])              # literal fsm_exec re-checks isdfa per call: keep it small
+    end, _ = dfa.exec_batch(rows)
+    assert np.array_equal(end[:600], want)
+    assert (want != NO).sum() >= 200
+    for e in set(int(x) for x in end[:600] if x != NO):
+        assert np.array_equal(dfa.endids(e), f.endids(e))
+    # the rest against the flattened oracle
+    from oracle.pyoracle import Oracle
+    assert np.array_equal(end, Oracle(f.flatten()).table_walk(rows))
+    dfa.close()

@@ -1,0 +1,101 @@
+"""CPU: the plain-C oracle (oracle/dfa_oracle.c) is pinned against
+ (a) every committed golden vector -- answers of the REAL reference fsm_exec on the
+     reference's own fixtures (tests/retest/*.tst, endids, re_strings) and on the
+     BASELINE config DFAs, frozen by tests/golden/make_golden.py;
+ (b) live, the real reference (oracle/_ref) on seeded random inputs, when present."""
+import numpy as np
+import pytest
+
+from common import Golden, all_golden_paths, golden_id
+from oracle.pyoracle import Oracle, RefFsm, have_ref
+
+NO = 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("path", all_golden_paths(), ids=golden_id)
+def test_oracle_matches_golden(path):
+    g = Golden(path)
+    o = Oracle(g.flat)
+    base, off = g.packed()
+    ret, end = o.exec_offsets(base, off)
+    assert np.array_equal(ret, g.ret), g.meta
+    assert np.array_equal(end, g.end), g.meta
+    if g.expect is not None:  # the fixture's own +/- lines
+        assert np.array_equal(ret, g.expect)
+    if g.ids_off is not None:
+        for i, e in enumerate(end):
+            want = g.ids_of(i)
+            got = o.endids(int(e)) if e != NO else np.zeros(0, np.uint32)
+            assert np.array_equal(got, want)
+
+
+def test_golden_counts():
+    paths = [p for p in all_golden_paths() if "/retest/" in p]
+    assert len(paths) == 37  # 37 regexes ...
+    assert sum(len(Golden(p).ret) for p in paths) == 115  # ... 115 cases
+
+
+@pytest.mark.parametrize("name", ["c1.npz", "c3.npz", "endids_union_det.npz", "re_strings_1.npz"])
+def test_table_walker_equals_group_scan(name):
+    import os
+    from common import GOLDEN
+    g = Golden(os.path.join(GOLDEN, name))
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(7)
+    alpha = np.frombuffer(b"abcdefLlibfsm0123456789xyz_. \0", np.uint8)
+    data = alpha[rng.randint(0, len(alpha), (300, 96))]
+    lens = rng.randint(0, 97, 300).astype(np.uint32)
+    ret, end = o.exec_stride(data, lens)
+    end2 = o.table_walk(data, lens)
+    assert np.array_equal(end, end2)
+    assert np.array_equal(ret == 1, end != NO)
+
+
+def test_oracle_semantics_edge_cases():
+    """Appendix B of SURVEY.md: empty input, no start, *end only on match, NUL is data."""
+    from libfsm_amd import FlatDfa
+    nt = np.full((2, 256), -1, np.int64)
+    nt[0, ord("a")] = 1
+    nt[1, 0] = 1          # NUL byte is an ordinary symbol for a (ptr,len) stream
+    flat = FlatDfa.from_dense(nt, 0, [0, 1])
+    o = Oracle(flat)
+    assert o.exec_one(b"") == (0, NO)              # start is not an end state
+    assert o.exec_one(b"a") == (1, 1)
+    assert o.exec_one(b"a\0\0") == (1, 1)
+    assert o.exec_one(b"ab") == (0, NO)            # missing edge
+    assert o.exec_one(b"b") == (0, NO)
+    flat2 = FlatDfa.from_dense(nt, 0, [1, 1])
+    assert Oracle(flat2).exec_one(b"") == (1, 0)   # empty input accepts iff start is an end state
+    assert Oracle(flat, hasstart=False).exec_one(b"a")[0] == -1  # exec.c:111-114
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("dialect,regex,flags", [
+    ("pcre", b"[Ll]ibf+(sm)*", 0), ("pcre", b"^ab+c?(de|fg)*$", 0), ("pcre", b"a.c", 16), ("glob", b"foo*bar?", 0),
+    ("native", b"(abc|abd)+x", 0), ("pcre", b"^[0-9a-f]{2,4}(:[0-9a-f]{2})*$", 1), ("like", b"a%b_c", 0),
+])
+def test_oracle_vs_live_reference(dialect, regex, flags):
+    f = RefFsm.re_comp(dialect, regex, flags, True, True, endid=3)
+    flat = f.flatten()
+    o = Oracle(flat)
+    rng = np.random.RandomState(11)
+    alpha = np.frombuffer(b"abcdefgxLlibsm0123456789:? \0\xff", np.uint8)
+    strings = [bytes(alpha[rng.randint(0, len(alpha), rng.randint(0, 24))]) for _ in range(2000)]
+    strings += [regex, b"", b"libfsm", b"abbbcdefg", b"foobar", b"fooXXbarz", b"ab:cd:ef", b"abcabdx"]
+    r1, e1 = f.exec_strings(strings)
+    r2, e2 = o.exec_strings(strings)
+    assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+    for e in set(int(x) for x in e1 if x != NO):
+        assert np.array_equal(f.endids(e), o.endids(e))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_reference_vm_agrees_with_fsm_exec():
+    """The reference never tests VM == fsm_exec directly; we do, on accept/reject."""
+    f = RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True)
+    rng = np.random.RandomState(3)
+    data = rng.randint(0, 256, (2000, 64)).astype(np.uint8)
+    data[::5, 10:16] = np.frombuffer(b"Libfsm", np.uint8)
+    ret, _ = f.exec_stride(data)
+    for v in (1, 2):
+        assert np.array_equal(f.vm_match_stride(data, v), ret)

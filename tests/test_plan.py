@@ -1,0 +1,118 @@
+"""CPU: the host-side table planner (libfsm_amd/csrc/plan.cpp) encodes exactly the
+DFA's transition function in every device layout.  The layouts are decoded here
+with numpy (mirroring the kernels' step functions) and compared, for EVERY
+(state, byte) pair, with the flat description's dense table."""
+import numpy as np
+import pytest
+
+from common import Golden, all_golden_paths, golden_id
+from libfsm_amd import LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
+
+NO = 0xFFFFFFFF
+
+
+def reference_table(flat):
+    """[S+1][256] in ORIGINAL numbering, missing edge -> S (dead)."""
+    d = flat.dense().astype(np.int64)
+    S = flat.nstates
+    d[d == NO] = S
+    return np.vstack([d, np.full((1, 256), S, np.int64)])
+
+
+def check_plan(flat, layout):
+    try:
+        p = Plan(flat, layout)
+    except OSError:
+        return False  # this layout cannot hold this DFA (ENOTSUP)
+    ref = reference_table(flat)
+    S, S1, Cn = flat.nstates, p.S1, p.C
+    cls = p.get("cls").astype(np.int64)
+    new2old = p.get("new2old").astype(np.int64)
+    new2old[S1 - 1] = S
+    old2new = np.empty(S1, np.int64)
+    old2new[new2old] = np.arange(S1)
+    fin = p.get("fin")
+    # fin: original id for end states, NO_MATCH otherwise
+    want_fin = np.where(np.append(flat.is_end, 0).astype(bool)[new2old], new2old, NO).astype(np.uint32)
+    assert np.array_equal(fin, want_fin)
+    assert old2new[flat.start] == p.start
+    # expected next state in NEW numbering for all (new state, byte)
+    want = old2new[ref[new2old]]            # [S1][256]
+    # absorbing threshold
+    absorbing = (want == np.arange(S1)[:, None]).all(axis=1)
+    assert absorbing[p.abs_min:].all() and not absorbing[:p.abs_min].any()
+    assert p.nabsorbing == S1 - p.abs_min
+    bytes_ = np.arange(256)
+    if p.layout == LAYOUT_TINY:
+        col = p.get("tiny_col")
+        got = np.stack([(col >> np.uint64(4 * s)) & np.uint64(15) for s in range(S1)]).astype(np.int64)
+    elif p.layout == LAYOUT_LDS:
+        tab = p.get("lds_tab").astype(np.int64)
+        rb = p.row_bytes
+        st = np.arange(S1)[:, None] * rb                      # encoded state = byte offset of row
+        e = tab[(st + cls[bytes_][None, :] * 2) // 2]
+        got = (e << 2) // rb
+        assert ((e << 2) % rb == 0).all()
+    elif p.layout == LAYOUT_COMB:
+        comb = p.get("comb").astype(np.int64)
+        off = p.get("comb_off").astype(np.int64)
+        dfl = p.get("comb_dflt").astype(np.int64)
+        cfin = p.get("comb_fin")
+        assert len(set(off.tolist())) == S1                    # distinct row offsets
+        st = off[:, None]
+        x = comb[st + cls[bytes_][None, :]] ^ (st << 16)
+        nxt_off = np.where(x < 0x10000, x, dfl[cls[bytes_]][None, :])
+        back = np.full(len(comb), -1, np.int64)
+        back[off] = np.arange(S1)
+        got = back[nxt_off]
+        assert np.array_equal(cfin[off], fin)
+        assert ((off >= p.comb_abs_min_off) == absorbing).all()
+    else:
+        tab = p.get("glob_tab").astype(np.int64)
+        st = np.arange(S1)[:, None] * Cn * 4
+        e = tab[(st + cls[bytes_][None, :] * 4) // 4]
+        got = e // (Cn * 4)
+    assert np.array_equal(got, want)
+    return True
+
+
+@pytest.mark.parametrize("path", all_golden_paths(), ids=golden_id)
+def test_layouts_encode_delta(path, built):
+    flat = Golden(path).flat
+    ok = [check_plan(flat, L) for L in (LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL)]
+    assert ok[3], "the global layout must hold any DFA"
+    assert check_plan(flat, 0)
+
+
+def test_auto_layout_choices(built):
+    import os
+    from common import GOLDEN
+    assert Plan(Golden(os.path.join(GOLDEN, "c1.npz")).flat).layout == LAYOUT_TINY
+    c3 = Plan(Golden(os.path.join(GOLDEN, "c3.npz")).flat)
+    assert c3.layout in (LAYOUT_LDS, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
+
+
+def test_rejects_non_dfa(built):
+    from libfsm_amd.capi import RANGE_DTYPE
+    r = np.zeros(2, RANGE_DTYPE)
+    r["lo"], r["hi"], r["to"] = [0, 5], [10, 20], [0, 0]     # overlapping ranges on bytes 5..10
+    flat = FlatDfa(1, 0, np.array([0, 2], np.uint32), r, np.array([1], np.uint8), np.zeros(2, np.uint32), np.zeros(0, np.uint32))
+    with pytest.raises(OSError):
+        Plan(flat)
+    r["to"] = [0, 7]
+    r["lo"], r["hi"] = [0, 30], [10, 40]
+    with pytest.raises(OSError):                               # destination out of range
+        Plan(FlatDfa(1, 0, np.array([0, 2], np.uint32), r, np.array([1], np.uint8), np.zeros(2, np.uint32), np.zeros(0, np.uint32)))
+
+
+def test_random_dfas_all_layouts(built):
+    rng = np.random.RandomState(5)
+    for S in (1, 2, 7, 16, 17, 300, 2000):
+        nt = rng.randint(0, S, (S, 256)).astype(np.int64)
+        nt[rng.rand(S, 256) < 0.5] = -1
+        ncls = rng.randint(1, 40)
+        colmap = rng.randint(0, ncls, 256)
+        nt = nt[:, colmap]                                     # force few byte classes
+        flat = FlatDfa.from_dense(nt, int(rng.randint(S)), rng.randint(0, 2, S))
+        for L in (0, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL):
+            check_plan(flat, L)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""tools/sweep.py -- time many kernel variants in ONE process (GPU minutes are scarce).
+
+Every variant's end states are compared with the first variant's (and the first
+is sample-checked against the oracle), so a fast-but-wrong variant is flagged.
+Usage: python tools/sweep.py [--n 8000000] [--workloads c2,c3] [--quick]
+"""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=8_000_000)
+    ap.add_argument("--len", type=int, default=1024)
+    ap.add_argument("--workloads", default="c2,c3")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--set", default="full")
+    a = ap.parse_args()
+    import torch
+    import bench
+    import libfsm_amd as hip
+    from oracle.pyoracle import Oracle
+    hip.load_library()
+    torch.cuda.set_device(0)
+    n, L = a.n, a.len
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    end = torch.empty(n, dtype=torch.int32, device="cuda")
+    ref_end = torch.empty(n, dtype=torch.int32, device="cuda")
+    bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    print(f"# n={n} len={L} bytes={n * L / 1e9:.2f} GB  device={torch.cuda.get_device_name(0)}", flush=True)
+    for wl in a.workloads.split(","):
+        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
+        bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
+        torch.cuda.synchronize()
+        first = True
+        layouts = [hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_COMB, hip.LAYOUT_GLOBAL]
+        for layout in layouts:
+            try:
+                dfa = hip.HipDfa(flat, layout)
+            except OSError:
+                continue
+            info = dfa.info()
+            print(f"## {wl} layout={info['layout_name']} states={info['nstates']} classes={info['nclasses']} "
+                  f"table_bytes={info['table_bytes']} lds={info['lds_bytes']}", flush=True)
+            if a.set == "full":
+                variants = [(hip.IN_DIRECT, nb, nt, w, 0) for nb in (1, 2, 4, 8) for nt in (0, 1) for w in (16,)]
+                variants += [(hip.IN_DIRECT, 4, 0, w, 0) for w in (4, 8)]
+                variants += [(hip.IN_DIRECT, 4, 1, 16, b) for b in (1, 2)]
+                variants += [(hip.IN_LDSDMA, 0, 0, w, b) for w in (4, 8, 16) for b in (0, 1)]
+                variants += [(hip.IN_GENERIC, 0, 0, 16, 0)]
+            else:
+                variants = [(hip.IN_DIRECT, 4, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 8, 0)]
+            for mode, nb, nt, waves, bpc in variants:
+                for early in ((1, 0) if (mode, nb, nt, waves, bpc) in ((hip.IN_DIRECT, 4, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 16, 0)) else (1,)):
+                    dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                    dfa.tune(hip.KNOB_NB, nb)
+                    dfa.tune(hip.KNOB_NONTEMPORAL, nt)
+                    dfa.tune(hip.KNOB_WAVES, waves)
+                    dfa.tune(hip.KNOB_BLOCKS_PER_CU, bpc)
+                    dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                    ms = []
+                    try:
+                        for r in range(a.reps + 1):
+                            dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr())
+                            t = dfa.last_kernel_ms()
+                            if r:
+                                ms.append(t)
+                    except OSError as e:
+                        print(f"{wl} {info['layout_name']:6s} mode={mode} nb={nb} nt={nt} waves={waves} bpc={bpc} early={early} ERROR {e}", flush=True)
+                        continue
+                    torch.cuda.synchronize()
+                    if first:
+                        ref_end.copy_(end)
+                        idx = np.random.RandomState(0).randint(0, n, 2048)
+                        rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
+                        ok = np.array_equal(Oracle(flat).table_walk(rows), end.cpu().numpy().view(np.uint32)[idx])
+                        print(f"# {wl}: first variant vs oracle on 2048 sampled rows: {'OK' if ok else 'MISMATCH'}; accepts={(end != -1).sum().item()}", flush=True)
+                        first = False
+                        same = True
+                    else:
+                        same = bool(torch.equal(end, ref_end))
+                    best = min(ms)
+                    print(f"{wl} {info['layout_name']:6s} mode={mode} nb={nb} nt={nt} waves={waves:2d} bpc={bpc} early={early} "
+                          f"ms={best:8.3f} GB/s={n * L / best / 1e6:8.1f} frac_hbm={n * (L + 4) / best / 1e6 / 8000:.3f} {'ok' if same else 'DIFF'}", flush=True)
+            dfa.close()
+
+
+if __name__ == "__main__":
+    main()
