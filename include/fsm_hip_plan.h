@@ -19,10 +19,11 @@ extern "C" {
 enum {
 	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles, 2 generic; -1 auto */
 	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (1,2,4,8)      */
-	FSM_HIP_KNOB_NONTEMPORAL   = 3,  /* direct mode: nontemporal input loads                          */
+	FSM_HIP_KNOB_ROWS          = 3,  /* direct mode: independent inputs per lane (1 or 2)             */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
-	FSM_HIP_KNOB_EARLY_RETIRE  = 6   /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
+	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
+	FSM_HIP_KNOB_MASK          = 7   /* 0/1: absorbing lanes skip the state-dependent table lookup    */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
@@ -30,7 +31,8 @@ int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
 struct fsm_hip_plan;
 
 enum {
-	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[9]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off */
+	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[11]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off,
+	                              *          comb256_abs_min_off,comb256_dflt */
 	FSM_HIP_PLAN_CLS       = 1,  /* u8[256]  */
 	FSM_HIP_PLAN_NEW2OLD   = 2,  /* u32[S1]  */
 	FSM_HIP_PLAN_FIN       = 3,  /* u32[S1]  */
@@ -41,7 +43,10 @@ enum {
 	FSM_HIP_PLAN_COMB_DFLT = 8,  /* u32[C] */
 	FSM_HIP_PLAN_COMB_OFF  = 9,  /* u32[S1] */
 	FSM_HIP_PLAN_COMB_FIN  = 10, /* u32[] */
-	FSM_HIP_PLAN_GLOB_TAB  = 11  /* u32[S1*C] */
+	FSM_HIP_PLAN_GLOB_TAB  = 11, /* u32[S1*C] */
+	FSM_HIP_PLAN_COMB256     = 12, /* u32[] */
+	FSM_HIP_PLAN_COMB256_OFF = 13, /* u32[S1] */
+	FSM_HIP_PLAN_COMB256_FIN = 14  /* u32[] */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

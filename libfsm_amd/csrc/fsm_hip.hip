@@ -37,7 +37,8 @@ struct fsm_hip_dfa {
 	/* tuning knobs (fsm_hip_dfa_tune) */
 	int knob_input_mode = -1;    /* -1 auto */
 	int knob_nb = 0;             /* 0 auto */
-	int knob_nt = 0;
+	int knob_rows = 0;           /* 0 auto */
+	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
@@ -115,7 +116,20 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.start = p.start;
 			a.abs_min = p.abs_min;
 			a.fin_div = 1;
-			d->table_lds = TinyPol::kLdsBytes;
+			d->table_lds = p.S1 <= 8 ? TinyPol<uint32_t>::lds_bytes(0) : TinyPol<uint64_t>::lds_bytes(0);
+			break;
+		}
+		case FSM_HIP_LAYOUT_COMB256: {
+			uint32_t *t = nullptr;
+			HIP_TRY(upload(&t, p.comb256));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.comb256_fin));
+			a.tab_bytes = (uint32_t)(p.comb256.size() * 4);
+			a.start = p.comb256_off[p.start];
+			a.abs_min = p.comb256_abs_min_off;
+			a.dflt = p.comb256_dflt;
+			a.fin_div = 1;
+			d->table_lds = Comb256Pol<false>::lds_bytes(a.tab_bytes);
 			break;
 		}
 		case FSM_HIP_LAYOUT_LDS: {
@@ -195,29 +209,37 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 struct LaunchCfg {
-	int mode, nb, nt, waves, blocks_per_cu;
+	int mode, nb, rows, mask, waves, blocks_per_cu;
 	uint32_t lds;
 };
 
 static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 {
 	LaunchCfg c;
+	const uint32_t layout = d->plan.layout;
 	c.mode = IN_GENERIC;
 	c.nb = 1;
-	c.nt = d->knob_nt;
+	c.rows = 1;
+	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
+	c.mask = d->knob_mask >= 0 ? d->knob_mask : (layout == FSM_HIP_LAYOUT_TINY ? 0 : 1);
 	if (fast_ok) {
-		c.mode = d->knob_input_mode >= 0 ? d->knob_input_mode : IN_DIRECT;
-		if (c.mode == IN_LDSDMA && stride % 64u != 0) c.mode = IN_DIRECT;
+		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging wins while the table leaves room for
+		 * per-wave tiles; per-lane loads with 8 chunks in flight win next to a big LDS table */
+		int mode = layout == FSM_HIP_LAYOUT_TINY ? IN_LDSDMA : IN_DIRECT;
+		if (d->knob_input_mode >= 0) mode = d->knob_input_mode;
+		if (mode == IN_LDSDMA && stride % 64u != 0) mode = IN_DIRECT;
+		c.mode = mode;
 		if (c.mode == IN_DIRECT) {
-			c.nb = d->knob_nb > 0 ? d->knob_nb : 4;
+			c.nb = d->knob_nb > 0 ? d->knob_nb : 8;
 			while (c.nb > 1 && (stride / 16u) % (unsigned)c.nb != 0) c.nb >>= 1;
+			c.rows = d->knob_rows == 2 ? 2 : 1;
+			if (c.rows == 2 && c.nb > 4) c.nb = 4;
 		}
-	} else if (d->knob_input_mode == IN_GENERIC || true) {
-		c.mode = IN_GENERIC;
 	}
 	const uint32_t per_wave = c.mode == IN_LDSDMA ? 4096u : 0u;
 	/* waves per block: as many as LDS allows, 16 at most */
-	int waves = d->knob_waves > 0 ? d->knob_waves : 16;
+	int waves = d->knob_waves > 0 ? d->knob_waves : (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY ? 8 : 16);
+	if (waves > 16) waves = 16;
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves >>= 1;
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
@@ -235,19 +257,18 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	void (*k)(const WalkArgs) = nullptr;
 	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
 	else if (c.mode == IN_LDSDMA) k = walk_ldsdma<Pol>;
-	else if (c.nt) {
+	else if (c.rows == 2) {
 		switch (c.nb) {
-		case 1: k = walk_direct<Pol, 1, true>; break;
-		case 2: k = walk_direct<Pol, 2, true>; break;
-		case 4: k = walk_direct<Pol, 4, true>; break;
-		default: k = walk_direct<Pol, 8, true>; break;
+		case 1: k = walk_direct<Pol, 1, 2>; break;
+		case 2: k = walk_direct<Pol, 2, 2>; break;
+		default: k = walk_direct<Pol, 4, 2>; break;
 		}
 	} else {
 		switch (c.nb) {
-		case 1: k = walk_direct<Pol, 1, false>; break;
-		case 2: k = walk_direct<Pol, 2, false>; break;
-		case 4: k = walk_direct<Pol, 4, false>; break;
-		default: k = walk_direct<Pol, 8, false>; break;
+		case 1: k = walk_direct<Pol, 1, 1>; break;
+		case 2: k = walk_direct<Pol, 2, 1>; break;
+		case 4: k = walk_direct<Pol, 4, 1>; break;
+		default: k = walk_direct<Pol, 8, 1>; break;
 		}
 	}
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
@@ -256,12 +277,17 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	return hipGetLastError();
 }
 
+template <template <bool> class PolT>
+static hipError_t launch_masked(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	return c.mask ? launch_pol<PolT<true>>(c, a, grid, block, s) : launch_pol<PolT<false>>(c, a, grid, block, s);
+}
+
 static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s)
 {
 	if (a.n == 0) return 0;
 	LaunchCfg c = pick_cfg(d, fast_ok, a.stride);
-	if (c.mode == IN_DIRECT && c.nb == 8) { /* nothing */ }
-	const uint64_t ntiles = (a.n + 63) / 64;
+	const uint64_t ntiles = (a.n + 64u * c.rows - 1) / (64u * c.rows);
 	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
@@ -271,10 +297,14 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (e == hipSuccess) {
 		dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
 		switch (d->plan.layout) {
-		case FSM_HIP_LAYOUT_TINY:   e = launch_pol<TinyPol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_LDS:    e = launch_pol<LdsPol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMB:   e = launch_pol<CombPol>(c, a, grid, block, s); break;
-		default:                    e = launch_pol<GlobPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_TINY:
+			e = d->plan.S1 <= 8 ? launch_pol<TinyPol<uint32_t>>(c, a, grid, block, s)
+			                    : launch_pol<TinyPol<uint64_t>>(c, a, grid, block, s);
+			break;
+		case FSM_HIP_LAYOUT_LDS:     e = launch_masked<LdsPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMB:    e = launch_masked<CombPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMB256: e = launch_masked<Comb256Pol>(c, a, grid, block, s); break;
+		default:                     e = launch_masked<GlobPol>(c, a, grid, block, s); break;
 		}
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
@@ -424,6 +454,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_TINY: out->table_bytes = 256 * 8; break;
 	case FSM_HIP_LAYOUT_LDS: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4; break;
+	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
 	LaunchCfg c = pick_cfg(d, true, 1024);
@@ -439,7 +470,8 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
-	case FSM_HIP_KNOB_NONTEMPORAL: d->knob_nt = value; break;
+	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;
+	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
 	case FSM_HIP_KNOB_WAVES: d->knob_waves = value; break;
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
@@ -490,8 +522,8 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_SCALARS:
 		scalars[0] = p.nstates; scalars[1] = p.S1; scalars[2] = p.start; scalars[3] = p.C;
 		scalars[4] = p.abs_min; scalars[5] = p.nabsorbing; scalars[6] = p.layout; scalars[7] = p.row_bytes;
-		scalars[8] = p.comb_abs_min_off;
-		*data = scalars; *count = 9; return 0;
+		scalars[8] = p.comb_abs_min_off; scalars[9] = p.comb256_abs_min_off; scalars[10] = p.comb256_dflt;
+		*data = scalars; *count = 11; return 0;
 	case FSM_HIP_PLAN_CLS: *data = p.cls; *count = 256; return 0;
 	case FSM_HIP_PLAN_NEW2OLD: *data = p.new2old.data(); *count = p.new2old.size(); return 0;
 	case FSM_HIP_PLAN_FIN: *data = p.fin.data(); *count = p.fin.size(); return 0;
@@ -503,6 +535,9 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB_OFF: *data = p.comb_off.data(); *count = p.comb_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB_FIN: *data = p.comb_fin.data(); *count = p.comb_fin.size(); return 0;
 	case FSM_HIP_PLAN_GLOB_TAB: *data = p.glob_tab.data(); *count = p.glob_tab.size(); return 0;
+	case FSM_HIP_PLAN_COMB256: *data = p.comb256.data(); *count = p.comb256.size(); return 0;
+	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
+	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;
 	default: errno = EINVAL; return -1;
 	}
 }

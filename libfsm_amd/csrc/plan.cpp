@@ -27,7 +27,7 @@ static const uint32_t NOEDGE = 0xFFFFFFFFu;
 uint32_t lds_bytes_tiny() { return 256u * 32u * 8u; }
 uint32_t lds_bytes_btab() { return 256u * 32u * 4u; }
 
-static int build_comb(Plan &p, uint32_t max_entries);
+static int build_comb(Plan &p, uint32_t max_entries, bool bytewise);
 
 int build_plan(const fsm_hip_dfa_desc *d, unsigned flags, uint32_t lds_limit, Plan &p)
 try {
@@ -199,9 +199,17 @@ try {
 	};
 	auto emit_comb = [&]() -> int {
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 4u, 65535u);
-		int r = build_comb(p, max_entries);
+		int r = build_comb(p, max_entries, false);
 		if (r) return r;
 		p.layout = FSM_HIP_LAYOUT_COMB;
+		return 0;
+	};
+	auto emit_comb256 = [&]() -> int {
+		/* no byte->class table in LDS for this layout */
+		uint32_t max_entries = (uint32_t)std::min<uint64_t>((lds_room + lds_bytes_btab()) / 4u, 65535u);
+		int r = build_comb(p, max_entries, true);
+		if (r) return r;
+		p.layout = FSM_HIP_LAYOUT_COMB256;
 		return 0;
 	};
 	auto emit_glob = [&]() -> int {
@@ -217,8 +225,10 @@ try {
 	case FSM_HIP_LAYOUT_LDS:    return emit_lds();
 	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
 	case FSM_HIP_LAYOUT_GLOBAL: return emit_glob();
+	case FSM_HIP_LAYOUT_COMB256: return emit_comb256();
 	case FSM_HIP_LAYOUT_AUTO:
 		if (emit_tiny() == 0) return 0;
+		if (emit_comb256() == 0) return 0;
 		if (emit_lds() == 0) return 0;
 		if (emit_comb() == 0) return 0;
 		return emit_glob();
@@ -241,14 +251,18 @@ try {
  * section 6's 4 609-state union) and Aho-Corasick rows mostly equal the root
  * row, so both shrink by an order of magnitude and fit LDS.
  */
-static int build_comb(Plan &p, uint32_t max_entries)
+static int build_comb(Plan &p, uint32_t max_entries, bool bytewise)
 {
-	const uint32_t S1 = p.S1, C = p.C;
-	if (max_entries < C + 1) return ENOTSUP;
+	/* W columns: byte classes (CombPol) or raw bytes (Comb256Pol) */
+	const uint32_t S1 = p.S1, C = p.C, W = bytewise ? 256u : C;
+	if (max_entries < W + 1) return ENOTSUP;
+	auto cell = [&](uint32_t n, uint32_t w) -> uint32_t {
+		return p.dense[(size_t)n * C + (bytewise ? p.cls[w] : w)];
+	};
 
-	std::vector<uint32_t> dflt(C);
+	std::vector<uint32_t> dflt(W);
 	{
-		std::vector<uint32_t> cnt(S1);
+		std::vector<uint32_t> cdf(C), cnt(S1);
 		for (uint32_t c = 0; c < C; c++) {
 			std::fill(cnt.begin(), cnt.end(), 0);
 			uint32_t best = 0;
@@ -256,17 +270,22 @@ static int build_comb(Plan &p, uint32_t max_entries)
 				uint32_t t = p.dense[(size_t)n * C + c];
 				if (++cnt[t] > cnt[best]) best = t;
 			}
-			dflt[c] = best;
+			cdf[c] = best;
 		}
+		for (uint32_t w = 0; w < W; w++) dflt[w] = cdf[bytewise ? p.cls[w] : w];
+	}
+	if (bytewise) {
+		/* one default for every column, else the walk would need a per-byte lookup */
+		for (uint32_t w = 1; w < W; w++) if (dflt[w] != dflt[0]) return ENOTSUP;
 	}
 	std::vector<uint32_t> nexc(S1, 0);
 	uint64_t total = 0;
 	for (uint32_t n = 0; n < S1; n++) {
-		for (uint32_t c = 0; c < C; c++)
-			if (p.dense[(size_t)n * C + c] != dflt[c]) nexc[n]++;
+		for (uint32_t w = 0; w < W; w++)
+			if (cell(n, w) != dflt[w]) nexc[n]++;
 		total += nexc[n];
 	}
-	if (total + C > max_entries || S1 > max_entries) return ENOTSUP;
+	if (total + W > max_entries || S1 > max_entries) return ENOTSUP;
 
 	/* place non-absorbing states densest first, then absorbing ones above */
 	std::vector<uint32_t> order(S1);
@@ -278,31 +297,33 @@ static int build_comb(Plan &p, uint32_t max_entries)
 		return nexc[a] > nexc[b];
 	});
 
-	/* exception class lists (CSR) so the fit test touches only real entries */
+	/* exception column lists (CSR) so the fit test touches only real entries */
 	std::vector<uint32_t> exo(S1 + 1, 0);
 	for (uint32_t n = 0; n < S1; n++) exo[n + 1] = exo[n] + nexc[n];
 	std::vector<uint16_t> exc(exo[S1]);
 	for (uint32_t n = 0; n < S1; n++) {
 		uint32_t k = exo[n];
-		for (uint32_t c = 0; c < C; c++)
-			if (p.dense[(size_t)n * C + c] != dflt[c]) exc[k++] = (uint16_t)c;
+		for (uint32_t w = 0; w < W; w++)
+			if (cell(n, w) != dflt[w]) exc[k++] = (uint16_t)w;
 	}
 
-	std::vector<uint8_t> slot_used(max_entries + C, 0), off_used(max_entries + 1, 0);
-	p.comb_off.assign(S1, 0);
+	std::vector<uint8_t> slot_used(max_entries + W, 0), off_used(max_entries + 1, 0);
+	std::vector<uint32_t> &off = bytewise ? p.comb256_off : p.comb_off;
+	off.assign(S1, 0);
 	uint32_t hi = 0;         /* 1 + highest offset handed out so far */
 	uint32_t first_free = 0; /* lowest offset not yet handed out */
+	uint32_t abs_min_off = 0;
 	bool in_abs = false;
 	for (uint32_t idx = 0; idx < S1; idx++) {
 		uint32_t n = order[idx];
 		if (!in_abs && n >= p.abs_min) {
 			in_abs = true;
-			p.comb_abs_min_off = hi; /* absorbing states get offsets >= every other state's */
+			abs_min_off = hi; /* absorbing states get offsets >= every other state's */
 		}
 		/* absorbing offsets keep increasing so one compare identifies them */
 		uint32_t o = in_abs ? hi : first_free;
 		for (;; o++) {
-			if (o + C > max_entries) return ENOTSUP;
+			if (o + W > max_entries) return ENOTSUP;
 			if (off_used[o]) continue;
 			bool ok = true;
 			for (uint32_t k = exo[n]; k < exo[n + 1] && ok; k++)
@@ -311,26 +332,33 @@ static int build_comb(Plan &p, uint32_t max_entries)
 		}
 		off_used[o] = 1;
 		for (uint32_t k = exo[n]; k < exo[n + 1]; k++) slot_used[o + exc[k]] = 1;
-		p.comb_off[n] = o;
+		off[n] = o;
 		if (o + 1 > hi) hi = o + 1;
 		while (first_free < max_entries && off_used[first_free]) first_free++;
 	}
-	if (!in_abs) p.comb_abs_min_off = hi; /* cannot happen: DEAD is absorbing */
-	uint32_t size = hi + C;
+	uint32_t size = hi + W;
 	if (size > max_entries || size > 0xFFFFu) return ENOTSUP;
 
-	p.comb.assign(size, 0xFFFF0000u); /* owner 0xFFFF never matches a real offset */
-	p.comb_fin.assign(size, FSM_HIP_NO_MATCH);
+	std::vector<uint32_t> &comb = bytewise ? p.comb256 : p.comb;
+	std::vector<uint32_t> &cfin = bytewise ? p.comb256_fin : p.comb_fin;
+	comb.assign(size, 0xFFFF0000u); /* owner 0xFFFF never matches a real offset */
+	cfin.assign(size, FSM_HIP_NO_MATCH);
 	for (uint32_t n = 0; n < S1; n++) {
-		uint32_t o = p.comb_off[n];
-		p.comb_fin[o] = p.fin[n];
-		for (uint32_t c = 0; c < C; c++) {
-			uint32_t t = p.dense[(size_t)n * C + c];
-			if (t != dflt[c]) p.comb[o + c] = (o << 16) | p.comb_off[t];
+		uint32_t o = off[n];
+		cfin[o] = p.fin[n];
+		for (uint32_t w = 0; w < W; w++) {
+			uint32_t t = cell(n, w);
+			if (t != dflt[w]) comb[o + w] = (o << 16) | off[t];
 		}
 	}
-	p.comb_dflt.resize(C);
-	for (uint32_t c = 0; c < C; c++) p.comb_dflt[c] = p.comb_off[dflt[c]];
+	if (bytewise) {
+		p.comb256_dflt = off[dflt[0]];
+		p.comb256_abs_min_off = abs_min_off;
+	} else {
+		p.comb_dflt.resize(C);
+		for (uint32_t c = 0; c < C; c++) p.comb_dflt[c] = off[dflt[c]];
+		p.comb_abs_min_off = abs_min_off;
+	}
 	return 0;
 }
 

@@ -51,6 +51,10 @@ struct Plan {
 	std::vector<uint32_t> comb_off;       /* [S1] row offset of each renumbered state */
 	std::vector<uint32_t> comb_fin;       /* [comb.size()] fin by row offset (NO_MATCH elsewhere) */
 	uint32_t comb_abs_min_off = 0;        /* row offsets >= this are absorbing */
+	/* COMB256: the same over raw bytes (256-wide rows), one default state for
+	 * every column: no byte->class lookup at all in the walk.                */
+	std::vector<uint32_t> comb256, comb256_off, comb256_fin;
+	uint32_t comb256_dflt = 0, comb256_abs_min_off = 0;
 	/* GLOBAL: u32 entries [S1][C], entry = next_state * C * 4 (byte offset) */
 	std::vector<uint32_t> glob_tab;
 };

@@ -5,28 +5,38 @@
  * against the same DFA (the data-parallel form of the reference's per-input
  * loop `while ((c = getc()) != EOF) state = delta(state, c)`,
  * src/libfsm/exec.c:132-151).  No MFMA: there is no contraction here; the
- * kernel is bound by HBM input bandwidth and by LDS lookup rate.
+ * kernel is bound by HBM input bandwidth and by the LDS lookup rate.
  *
- * Table policies (how delta(state, byte) is evaluated):
- *   TinyPol   <=16 states.  LDS holds, per byte value, the whole transition
- *             COLUMN (16 x 4-bit next states in one 64-bit word), replicated
- *             once per LDS bank pair so lane l always reads bank 2*(l%32):
- *             conflict-free by construction.  The lookup depends only on the
- *             input byte, never on the state, so all 16 lookups of a 16-byte
- *             chunk are in flight together and the state chain is pure VALU.
- *   LdsPol    class-compressed dense table T[state][class] (u16) in LDS plus a
- *             bank-private byte->class table B[256][32] (conflict-free).
- *   CombPol   column-default + comb exceptions in LDS (see plan.cpp).
- *   GlobPol   T[state][class] (u32) in HBM/L2, B in LDS.
+ * Table policies (how delta(state, byte) is evaluated).  Each policy splits a
+ * step into  pre(byte)  -- independent of the state, so all 16 of a 16-byte
+ * chunk are issued together --  and  next(state, pre)  -- the dependent chain:
+ *   TinyPol<W> <=8 (W=uint32) or <=16 (W=uint64) states.  LDS holds, per byte
+ *              value, the whole transition COLUMN (4-bit next states packed in
+ *              one word), replicated once per LDS bank so lane l always reads
+ *              bank l%32: conflict-free by construction.  pre = the column,
+ *              next = shift+mask: the state chain never touches memory.
+ *   LdsPol     class-compressed dense table T[state][class] (u16) in LDS plus a
+ *              bank-private byte->class table B[256][32] (conflict-free).
+ *   CombPol    column-default + comb exceptions over byte CLASSES (B table
+ *              carries class and per-class default), see plan.cpp.
+ *   Comb256Pol comb exceptions over raw BYTES with one default state for every
+ *              column (typically DEAD): pre is the byte itself, one LDS lookup
+ *              per input byte in total.
+ *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS.
+ * MASK: lanes already in an absorbing state skip the state-dependent lookup
+ * (exec-masked), which takes their addresses out of the LDS bank arbitration.
  *
- * Input staging modes (uniform-length, 16-byte aligned rows):
- *   IN_DIRECT  every lane reads its own row 16 bytes at a time, NB chunks in
- *              flight (global_load_dwordx4 at row stride).
- *   IN_LDSDMA  rows are fetched as whole 64-byte segments (4 adjacent lanes per
- *              row) by global_load_lds_dwordx4 straight into a 4 KiB per-wave
- *              LDS tile, piece-rotated so the row-per-lane ds_read_b128 that
- *              follows is bank-conflict-free; no VGPR staging, no ds_write.
- * plus IN_GENERIC for ragged lengths / arbitrary alignment / packed offsets.
+ * Input staging (uniform-length, 16-byte aligned rows):
+ *   walk_direct  every lane reads its own row(s) 16 bytes at a time, NB chunks
+ *                in flight, ROWS independent rows per lane (two interleaved
+ *                state chains hide LDS latency when the table leaves room for
+ *                one workgroup per CU only).
+ *   walk_ldsdma  rows are fetched as whole 64-byte segments (4 adjacent lanes
+ *                per row) by global_load_lds_dwordx4 straight into a 4 KiB
+ *                per-wave LDS tile, piece-rotated so the row-per-lane
+ *                ds_read_b128 that follows is bank-conflict-free; no VGPR
+ *                staging, no ds_write.
+ *   walk_generic ragged lengths / arbitrary alignment / packed offsets.
  */
 #ifndef FSM_HIP_WALK_KERNELS_H
 #define FSM_HIP_WALK_KERNELS_H
@@ -52,11 +62,13 @@ struct WalkArgs {
 	uint32_t        abs_min;  /* encoded states >= abs_min are absorbing              */
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
 	uint32_t        early;    /* retire a wavefront once every lane is absorbing      */
+	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
 };
 
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2 };
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
+#define FSMHIP_BTAB_BYTES (256u * 32u * 4u)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -70,143 +82,166 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 /* table policies                                                     */
 /* ------------------------------------------------------------------ */
 
+template <class W>
 struct TinyPol {
-	static constexpr uint32_t kLdsBytes = 256u * 32u * 8u;
-	const uint64_t *colp; /* LDS column table, already offset by lane%32 */
+	typedef W P;
+	const W *colp; /* LDS column table, already offset by lane%32 */
 
-	__device__ static uint32_t lds_bytes(const WalkArgs &) { return kLdsBytes; }
+	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 32u * (uint32_t)sizeof(W); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		uint64_t *col = reinterpret_cast<uint64_t *>(lds);
+		W *col = reinterpret_cast<W *>(lds);
 		const uint64_t *src = static_cast<const uint64_t *>(a.tab);
-		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) col[i] = src[i >> 5];
+		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) col[i] = (W)src[i >> 5];
 		colp = col + (threadIdx.x & 31u);
 	}
-	__device__ __forceinline__ uint32_t step1(uint32_t st, uint32_t b) const
-	{
-		const uint64_t v = colp[b * 32u];
-		return (uint32_t)(v >> (st * 4u)) & 15u;
-	}
-	__device__ __forceinline__ void step16(uint32_t &st, const u32x4 &w) const
-	{
-		uint64_t v[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) v[k] = colp[byte_of(w, k) * 32u];
-#pragma unroll
-		for (int k = 0; k < 16; k++) st = (uint32_t)(v[k] >> (st * 4u)) & 15u;
-	}
+	__device__ __forceinline__ P pre(uint32_t b) const { return colp[b * 32u]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const { return (uint32_t)(v >> (st * 4u)) & 15u; }
 };
 
+__device__ __forceinline__ const uint32_t *setup_btab(unsigned char *lds, const WalkArgs &a)
+{
+	uint32_t *B = reinterpret_cast<uint32_t *>(lds);
+	for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) B[i] = a.btab[i >> 5];
+	return B + (threadIdx.x & 31u);
+}
+
+__device__ __forceinline__ void copy_table(unsigned char *dst, const WalkArgs &a)
+{
+	uint32_t *T = reinterpret_cast<uint32_t *>(dst);
+	const uint32_t *src = static_cast<const uint32_t *>(a.tab);
+	for (uint32_t i = threadIdx.x; i < (a.tab_bytes + 3u) / 4u; i += blockDim.x) T[i] = src[i];
+}
+
+template <bool MASK>
 struct LdsPol {
+	typedef uint32_t P;
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 2      */
 	const unsigned char *tab;  /* LDS table; state is a byte offset into it      */
+	uint32_t abs_min;
 
-	__device__ static uint32_t lds_bytes(const WalkArgs &a) { return 256u * 32u * 4u + ((a.tab_bytes + 15u) & ~15u); }
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		uint32_t *B = reinterpret_cast<uint32_t *>(lds);
-		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) B[i] = a.btab[i >> 5];
-		uint32_t *T = reinterpret_cast<uint32_t *>(lds + 256u * 32u * 4u);
-		const uint32_t *src = static_cast<const uint32_t *>(a.tab);
-		for (uint32_t i = threadIdx.x; i < (a.tab_bytes + 3u) / 4u; i += blockDim.x) T[i] = src[i];
-		bp = B + (threadIdx.x & 31u);
-		tab = lds + 256u * 32u * 4u;
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		tab = lds + FSMHIP_BTAB_BYTES;
+		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ uint32_t step1(uint32_t st, uint32_t b) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P ca) const
 	{
-		const uint32_t ca = bp[b * 32u];
+		if (MASK) {
+			if (st < abs_min) st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + ca)) << 2;
+			return st;
+		}
 		return (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + ca)) << 2;
-	}
-	__device__ __forceinline__ void step16(uint32_t &st, const u32x4 &w) const
-	{
-		uint32_t ca[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) ca[k] = bp[byte_of(w, k) * 32u];
-#pragma unroll
-		for (int k = 0; k < 16; k++)
-			st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + ca[k])) << 2;
 	}
 };
 
+template <bool MASK>
 struct CombPol {
+	typedef uint32_t P;
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
+	uint32_t abs_min;
 
-	__device__ static uint32_t lds_bytes(const WalkArgs &a) { return 256u * 32u * 4u + ((a.tab_bytes + 15u) & ~15u); }
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		uint32_t *B = reinterpret_cast<uint32_t *>(lds);
-		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) B[i] = a.btab[i >> 5];
-		uint32_t *T = reinterpret_cast<uint32_t *>(lds + 256u * 32u * 4u);
-		const uint32_t *src = static_cast<const uint32_t *>(a.tab);
-		for (uint32_t i = threadIdx.x; i < a.tab_bytes / 4u; i += blockDim.x) T[i] = src[i];
-		bp = B + (threadIdx.x & 31u);
-		comb = T;
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
+		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ uint32_t step1(uint32_t st, uint32_t b) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P be) const
 	{
-		const uint32_t be = bp[b * 32u];
+		if (MASK && st >= abs_min) return st;
 		const uint32_t x = comb[st + (be & 0xffffu)] ^ (st << 16);
 		return x < 0x10000u ? x : (be >> 16);
 	}
-	__device__ __forceinline__ void step16(uint32_t &st, const u32x4 &w) const
-	{
-		uint32_t be[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) be[k] = bp[byte_of(w, k) * 32u];
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const uint32_t x = comb[st + (be[k] & 0xffffu)] ^ (st << 16);
-			st = x < 0x10000u ? x : (be[k] >> 16);
-		}
-	}
 };
 
-struct GlobPol {
-	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4       */
-	const unsigned char *tab;  /* device table; state is a byte offset into it    */
+template <bool MASK>
+struct Comb256Pol {
+	typedef uint32_t P;
+	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte */
+	uint32_t abs_min, dflt;
 
-	__device__ static uint32_t lds_bytes(const WalkArgs &) { return 256u * 32u * 4u; }
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		uint32_t *B = reinterpret_cast<uint32_t *>(lds);
-		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) B[i] = a.btab[i >> 5];
-		bp = B + (threadIdx.x & 31u);
-		tab = static_cast<const unsigned char *>(a.tab);
+		copy_table(lds, a);
+		comb = reinterpret_cast<const uint32_t *>(lds);
+		abs_min = a.abs_min;
+		dflt = a.dflt;
 	}
-	__device__ __forceinline__ uint32_t step1(uint32_t st, uint32_t b) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return b; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P b) const
 	{
-		const uint32_t ca = bp[b * 32u];
-		return *reinterpret_cast<const uint32_t *>(tab + st + ca);
-	}
-	__device__ __forceinline__ void step16(uint32_t &st, const u32x4 &w) const
-	{
-		uint32_t ca[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) ca[k] = bp[byte_of(w, k) * 32u];
-#pragma unroll
-		for (int k = 0; k < 16; k++) st = *reinterpret_cast<const uint32_t *>(tab + st + ca[k]);
+		if (MASK && st >= abs_min) return st;
+		const uint32_t x = comb[st + b] ^ (st << 16);
+		return x < 0x10000u ? x : dflt;
 	}
 };
+
+template <bool MASK>
+struct GlobPol {
+	typedef uint32_t P;
+	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4       */
+	const unsigned char *tab;  /* device table; state is a byte offset into it    */
+	uint32_t abs_min;
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return FSMHIP_BTAB_BYTES; }
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		bp = setup_btab(lds, a);
+		tab = static_cast<const unsigned char *>(a.tab);
+		abs_min = a.abs_min;
+	}
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P ca) const
+	{
+		if (MASK && st >= abs_min) return st;
+		return *reinterpret_cast<const uint32_t *>(tab + st + ca);
+	}
+};
+
+/* 16 input bytes of ROWS independent rows: all state-independent lookups
+ * first, then the ROWS state chains interleaved byte by byte. */
+template <class Pol, int ROWS>
+__device__ __forceinline__ void step16(const Pol &pol, uint32_t (&st)[ROWS], const u32x4 (&w)[ROWS])
+{
+	typename Pol::P pre[ROWS][16];
+#pragma unroll
+	for (int r = 0; r < ROWS; r++)
+#pragma unroll
+		for (int k = 0; k < 16; k++) pre[r][k] = pol.pre(byte_of(w[r], k));
+#pragma unroll
+	for (int k = 0; k < 16; k++)
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) st[r] = pol.next(st[r], pre[r][k]);
+}
 
 /* ------------------------------------------------------------------ */
 /* result write-back                                                  */
 /* ------------------------------------------------------------------ */
 
-__device__ __forceinline__ void write_result(const WalkArgs &a, uint64_t tile, uint64_t i, bool valid, uint32_t st)
+__device__ __forceinline__ void write_result(const WalkArgs &a, uint64_t word, uint64_t i, bool valid, uint32_t st)
 {
 	uint32_t end = FSMHIP_NO_MATCH;
 	if (valid) end = a.fin[st / a.fin_div];
 	if (valid && a.end_out != nullptr) a.end_out[i] = end;
 	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
-	if (a.bitmap != nullptr && (threadIdx.x & 63u) == 0) a.bitmap[tile] = m;
+	if (a.bitmap != nullptr && (threadIdx.x & 63u) == 0 && word * 64u < a.n) a.bitmap[word] = m;
 }
 
 /* ------------------------------------------------------------------ */
-/* IN_DIRECT: per-lane 16-byte loads, NB chunks in flight             */
+/* walk_direct: per-lane 16-byte loads, NB chunks in flight, ROWS rows */
 /* ------------------------------------------------------------------ */
 
-template <class Pol, int NB, bool NT>
+template <class Pol, int NB, int ROWS>
 __global__ void __launch_bounds__(1024)
 walk_direct(const WalkArgs a)
 {
@@ -216,36 +251,52 @@ walk_direct(const WalkArgs a)
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	const uint64_t ntiles = (a.n + 63u) / 64u;
+	const uint64_t ntiles = (a.n + 64u * ROWS - 1u) / (64u * ROWS);
 	const uint32_t nchunks = (uint32_t)(a.stride / 16u);
 	const uint32_t ngroups = nchunks / NB; /* host guarantees nchunks % NB == 0 */
 
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
-		const uint64_t i = tile * 64u + lane;
-		const bool valid = i < a.n;
-		const u32x4 *q = reinterpret_cast<const u32x4 *>(a.base + (valid ? i : a.n - 1) * a.stride);
-		uint32_t st = a.start;
-		u32x4 cur[NB], nxt[NB];
+		uint64_t i[ROWS];
+		const u32x4 *q[ROWS];
+		uint32_t st[ROWS];
+		u32x4 cur[NB][ROWS], nxt[NB][ROWS];
 #pragma unroll
-		for (int j = 0; j < NB; j++) cur[j] = NT ? __builtin_nontemporal_load(q + j) : q[j];
+		for (int r = 0; r < ROWS; r++) {
+			i[r] = (tile * ROWS + r) * 64u + lane;
+			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
+			st[r] = a.start;
+		}
+#pragma unroll
+		for (int j = 0; j < NB; j++)
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) cur[j][r] = q[r][j];
 		for (uint32_t g = 0; g < ngroups; g++) {
 			if (g + 1 < ngroups) {
 #pragma unroll
 				for (int j = 0; j < NB; j++)
-					nxt[j] = NT ? __builtin_nontemporal_load(q + (g + 1) * NB + j) : q[(g + 1) * NB + j];
+#pragma unroll
+					for (int r = 0; r < ROWS; r++) nxt[j][r] = q[r][(g + 1) * NB + j];
 			}
 #pragma unroll
-			for (int j = 0; j < NB; j++) pol.step16(st, cur[j]);
-			if (a.early && __all(st >= a.abs_min)) break;
+			for (int j = 0; j < NB; j++) step16<Pol, ROWS>(pol, st, cur[j]);
+			if (a.early) {
+				bool done = true;
 #pragma unroll
-			for (int j = 0; j < NB; j++) cur[j] = nxt[j];
+				for (int r = 0; r < ROWS; r++) done = done && st[r] >= a.abs_min;
+				if (__all(done)) break;
+			}
+#pragma unroll
+			for (int j = 0; j < NB; j++)
+#pragma unroll
+				for (int r = 0; r < ROWS; r++) cur[j][r] = nxt[j][r];
 		}
-		write_result(a, tile, i, valid, st);
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + r, i[r], i[r] < a.n, st[r]);
 	}
 }
 
 /* ------------------------------------------------------------------ */
-/* IN_LDSDMA: coalesced 64-byte row segments DMA'd into a per-wave     */
+/* walk_ldsdma: coalesced 64-byte row segments DMA'd into a per-wave   */
 /* LDS tile, read back row-per-lane                                   */
 /* ------------------------------------------------------------------ */
 
@@ -262,7 +313,7 @@ walk_ldsdma(const WalkArgs a)
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	unsigned char *stg = lds + ((Pol::lds_bytes(a) + 15u) & ~15u) + wave * 4096u;
+	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * 4096u;
 	const uint64_t ntiles = (a.n + 63u) / 64u;
 	const uint32_t nseg = (uint32_t)(a.stride / 64u); /* host guarantees stride % 64 == 0 */
 
@@ -288,17 +339,17 @@ walk_ldsdma(const WalkArgs a)
 			if (row >= a.n) row = a.n - 1;
 			src[j] = a.base + row * a.stride + lpiece * 16u;
 		}
-		uint32_t st = a.start;
+		uint32_t st[1] = { a.start };
 #pragma unroll
 		for (int j = 0; j < 4; j++)
 			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
 		for (uint32_t s = 0; s < nseg; s++) {
 			__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the tile has landed */
 			__asm__ volatile("" ::: "memory");
-			u32x4 w[4];
+			u32x4 w[4][1];
 #pragma unroll
 			for (int p = 0; p < 4; p++)
-				w[p] = *reinterpret_cast<const u32x4 *>(rd + (((uint32_t)p + rot) & 3u) * 16u);
+				w[p][0] = *reinterpret_cast<const u32x4 *>(rd + (((uint32_t)p + rot) & 3u) * 16u);
 			__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile is in registers, slot reusable */
 			__asm__ volatile("" ::: "memory");
 			if (s + 1 < nseg) {
@@ -308,18 +359,18 @@ walk_ldsdma(const WalkArgs a)
 					                                 (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
 			}
 #pragma unroll
-			for (int p = 0; p < 4; p++) pol.step16(st, w[p]);
-			if (a.early && __all(st >= a.abs_min)) {
+			for (int p = 0; p < 4; p++) step16<Pol, 1>(pol, st, w[p]);
+			if (a.early && __all(st[0] >= a.abs_min)) {
 				__builtin_amdgcn_s_waitcnt(0x0F70); /* drain the prefetch before the tile is reused */
 				break;
 			}
 		}
-		write_result(a, tile, i, valid, st);
+		write_result(a, tile, i, valid, st[0]);
 	}
 }
 
 /* ------------------------------------------------------------------ */
-/* IN_GENERIC: ragged lengths, any alignment, fixed stride or packed  */
+/* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
 
 template <class Pol>
@@ -357,7 +408,7 @@ walk_generic(const WalkArgs a)
 #pragma unroll
 				for (int k = 0; k < 16; k++) {
 					const uint64_t pos = c * 16u + k - head; /* wraps below head: huge, fails the test */
-					const uint32_t nx = pol.step1(st, byte_of(w, k));
+					const uint32_t nx = pol.next(st, pol.pre(byte_of(w, k)));
 					st = pos < len ? nx : st;
 				}
 			}
@@ -468,6 +519,5 @@ gen_affix_kernel(const GenArgs g, const AffixArgs x)
 }
 
 } // namespace fsmhip
-
 
 #endif

@@ -31,7 +31,7 @@ def hip(built):
 
 def layouts_for(hip, flat):
     out = []
-    for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_COMB, hip.LAYOUT_GLOBAL):
+    for L in hip.ALL_LAYOUTS:
         try:
             out.append((L, hip.HipDfa(flat, L)))
         except OSError:
@@ -65,23 +65,25 @@ def test_golden_vectors_all_layouts(hip, path):
 
 @pytest.mark.parametrize("name", ["c1.npz", "c3.npz"])
 def test_fast_paths_every_mode(hip, name):
-    """Fixed-stride aligned rows: direct (NB=1,2,4,8, +nontemporal), LDS-DMA, generic; 1..16 waves."""
+    """Fixed-stride aligned rows: direct (NB=1,2,4,8; 1 or 2 rows per lane), LDS-DMA, generic; 1..16 waves;
+    absorbing-lane masking on/off; early retire on/off."""
     g = Golden(os.path.join(GOLDEN, name))
     rows = g.rows
     n = len(rows)
     for L, dfa in layouts_for(hip, g.flat):
-        variants = [(hip.IN_GENERIC, 0, 0, 0), (hip.IN_LDSDMA, 0, 0, 0), (hip.IN_LDSDMA, 0, 0, 4)]
-        variants += [(hip.IN_DIRECT, nb, nt, 0) for nb in (1, 2, 4, 8) for nt in (0, 1)]
-        variants += [(hip.IN_DIRECT, 4, 0, w) for w in (1, 2, 8)]
-        for mode, nb, nt, waves in variants:
+        variants = [(hip.IN_GENERIC, 0, 1, 0), (hip.IN_LDSDMA, 0, 1, 0), (hip.IN_LDSDMA, 0, 1, 4)]
+        variants += [(hip.IN_DIRECT, nb, rows_, 0) for nb in (1, 2, 4, 8) for rows_ in (1, 2)]
+        variants += [(hip.IN_DIRECT, 4, 1, w) for w in (1, 2, 8)]
+        for mode, nb, rows_, waves in variants:
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
             dfa.tune(hip.KNOB_NB, nb)
-            dfa.tune(hip.KNOB_NONTEMPORAL, nt)
+            dfa.tune(hip.KNOB_ROWS, rows_)
             dfa.tune(hip.KNOB_WAVES, waves)
-            for early in (0, 1):
+            for early, mask in ((0, 0), (1, 1), (0, 1)):
                 dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                dfa.tune(hip.KNOB_MASK, mask)
                 end, bm = dfa.exec_batch(rows)
-                assert np.array_equal(end, g.end), (name, L, mode, nb, nt, waves, early)
+                assert np.array_equal(end, g.end), (name, L, mode, nb, rows_, waves, early, mask)
                 assert np.array_equal(bits(bm, n), g.ret == 1)
         dfa.close()
 
@@ -93,10 +95,11 @@ def test_batch_sizes(hip, n):
     rows = hip.gen_inputs_host(n, 128, 5, 77, None, b"libffsm", 3)
     want = Oracle(g.flat).table_walk(rows) if n else np.zeros(0, np.uint32)
     for L, dfa in layouts_for(hip, g.flat):
-        for mode in (hip.IN_DIRECT, hip.IN_LDSDMA, hip.IN_GENERIC):
+        for mode, rows_ in ((hip.IN_DIRECT, 1), (hip.IN_DIRECT, 2), (hip.IN_LDSDMA, 1), (hip.IN_GENERIC, 1)):
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            dfa.tune(hip.KNOB_ROWS, rows_)
             end, bm = dfa.exec_batch(rows)
-            assert np.array_equal(end, want), (n, L, mode)
+            assert np.array_equal(end, want), (n, L, mode, rows_)
             assert np.array_equal(bits(bm, n), want != NO)
         dfa.close()
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from common import Golden, all_golden_paths, golden_id
-from libfsm_amd import LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
+from libfsm_amd import ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
 
 NO = 0xFFFFFFFF
 
@@ -67,6 +67,19 @@ def check_plan(flat, layout):
         got = back[nxt_off]
         assert np.array_equal(cfin[off], fin)
         assert ((off >= p.comb_abs_min_off) == absorbing).all()
+    elif p.layout == LAYOUT_COMB256:
+        comb = p.get("comb256").astype(np.int64)
+        off = p.get("comb256_off").astype(np.int64)
+        cfin = p.get("comb256_fin")
+        assert len(set(off.tolist())) == S1
+        st = off[:, None]
+        x = comb[st + bytes_[None, :]] ^ (st << 16)
+        nxt_off = np.where(x < 0x10000, x, p.comb256_dflt)
+        back = np.full(len(comb), -1, np.int64)
+        back[off] = np.arange(S1)
+        got = back[nxt_off]
+        assert np.array_equal(cfin[off], fin)
+        assert ((off >= p.comb256_abs_min_off) == absorbing).all()
     else:
         tab = p.get("glob_tab").astype(np.int64)
         st = np.arange(S1)[:, None] * Cn * 4
@@ -79,8 +92,8 @@ def check_plan(flat, layout):
 @pytest.mark.parametrize("path", all_golden_paths(), ids=golden_id)
 def test_layouts_encode_delta(path, built):
     flat = Golden(path).flat
-    ok = [check_plan(flat, L) for L in (LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL)]
-    assert ok[3], "the global layout must hold any DFA"
+    ok = {L: check_plan(flat, L) for L in ALL_LAYOUTS}
+    assert ok[LAYOUT_GLOBAL], "the global layout must hold any DFA"
     assert check_plan(flat, 0)
 
 
@@ -89,7 +102,7 @@ def test_auto_layout_choices(built):
     from common import GOLDEN
     assert Plan(Golden(os.path.join(GOLDEN, "c1.npz")).flat).layout == LAYOUT_TINY
     c3 = Plan(Golden(os.path.join(GOLDEN, "c3.npz")).flat)
-    assert c3.layout in (LAYOUT_LDS, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
+    assert c3.layout in (LAYOUT_COMB256, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
 
 
 def test_rejects_non_dfa(built):
@@ -114,5 +127,5 @@ def test_random_dfas_all_layouts(built):
         colmap = rng.randint(0, ncls, 256)
         nt = nt[:, colmap]                                     # force few byte classes
         flat = FlatDfa.from_dense(nt, int(rng.randint(S)), rng.randint(0, 2, S))
-        for L in (0, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL):
+        for L in (0,) + tuple(ALL_LAYOUTS):
             check_plan(flat, L)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--workloads", default="c2,c3")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--set", default="full")
+    ap.add_argument("--layouts", default="all")
     a = ap.parse_args()
     import torch
     import bench
@@ -41,7 +42,7 @@ def main():
         bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
         torch.cuda.synchronize()
         first = True
-        layouts = [hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_COMB, hip.LAYOUT_GLOBAL]
+        layouts = hip.ALL_LAYOUTS if a.layouts == "all" else [int(x) for x in a.layouts.split(",")]
         for layout in layouts:
             try:
                 dfa = hip.HipDfa(flat, layout)
@@ -50,22 +51,26 @@ def main():
             info = dfa.info()
             print(f"## {wl} layout={info['layout_name']} states={info['nstates']} classes={info['nclasses']} "
                   f"table_bytes={info['table_bytes']} lds={info['lds_bytes']}", flush=True)
+            tiny = info["layout_name"] == "tiny"
+            # (mode, nb, rows, waves, bpc, mask, early)
+            variants = [(-1, 0, 0, 0, 0, -1, 1)]  # library defaults
             if a.set == "full":
-                variants = [(hip.IN_DIRECT, nb, nt, w, 0) for nb in (1, 2, 4, 8) for nt in (0, 1) for w in (16,)]
-                variants += [(hip.IN_DIRECT, 4, 0, w, 0) for w in (4, 8)]
-                variants += [(hip.IN_DIRECT, 4, 1, 16, b) for b in (1, 2)]
-                variants += [(hip.IN_LDSDMA, 0, 0, w, b) for w in (4, 8, 16) for b in (0, 1)]
-                variants += [(hip.IN_GENERIC, 0, 0, 16, 0)]
-            else:
-                variants = [(hip.IN_DIRECT, 4, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 8, 0)]
-            for mode, nb, nt, waves, bpc in variants:
-                for early in ((1, 0) if (mode, nb, nt, waves, bpc) in ((hip.IN_DIRECT, 4, 0, 16, 0), (hip.IN_LDSDMA, 0, 0, 16, 0)) else (1,)):
+                masks = (0,) if tiny else (0, 1)
+                variants += [(hip.IN_DIRECT, nb, r, 16, 0, m, 1) for nb in (4, 8) for r in (1, 2) for m in masks if not (nb == 8 and r == 2)]
+                variants += [(hip.IN_DIRECT, 2, 2, 16, 0, masks[-1], 1), (hip.IN_DIRECT, 8, 1, 8, 0, masks[-1], 1)]
+                variants += [(hip.IN_LDSDMA, 0, 1, w, 0, m, 1) for w in (4, 8, 16) for m in masks]
+                variants += [(hip.IN_LDSDMA, 0, 1, 8, 0, masks[-1], 0), (hip.IN_DIRECT, 8, 1, 16, 0, masks[-1], 0)]
+                variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
+            for mode, nb, rows_, waves, bpc, mask, early in variants:
+                if True:
                     dfa.tune(hip.KNOB_INPUT_MODE, mode)
                     dfa.tune(hip.KNOB_NB, nb)
-                    dfa.tune(hip.KNOB_NONTEMPORAL, nt)
+                    dfa.tune(hip.KNOB_ROWS, rows_)
                     dfa.tune(hip.KNOB_WAVES, waves)
                     dfa.tune(hip.KNOB_BLOCKS_PER_CU, bpc)
+                    dfa.tune(hip.KNOB_MASK, mask)
                     dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                    nt = rows_
                     ms = []
                     try:
                         for r in range(a.reps + 1):
@@ -74,7 +79,7 @@ def main():
                             if r:
                                 ms.append(t)
                     except OSError as e:
-                        print(f"{wl} {info['layout_name']:6s} mode={mode} nb={nb} nt={nt} waves={waves} bpc={bpc} early={early} ERROR {e}", flush=True)
+                        print(f"{wl} {info['layout_name']:6s} mode={mode} nb={nb} rows={rows_} waves={waves} bpc={bpc} mask={mask} early={early} ERROR {e}", flush=True)
                         continue
                     torch.cuda.synchronize()
                     if first:
@@ -88,7 +93,7 @@ def main():
                     else:
                         same = bool(torch.equal(end, ref_end))
                     best = min(ms)
-                    print(f"{wl} {info['layout_name']:6s} mode={mode} nb={nb} nt={nt} waves={waves:2d} bpc={bpc} early={early} "
+                    print(f"{wl} {info['layout_name']:6s} mode={mode:2d} nb={nb} rows={rows_} waves={waves:2d} bpc={bpc} mask={mask:2d} early={early} "
                           f"ms={best:8.3f} GB/s={n * L / best / 1e6:8.1f} frac_hbm={n * (L + 4) / best / 1e6 / 8000:.3f} {'ok' if same else 'DIFF'}", flush=True)
             dfa.close()
 
