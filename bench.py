@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--len", type=int, default=1024, help="bytes per input")
     ap.add_argument("--input-mode", type=int, default=-1)
     ap.add_argument("--nb", type=int, default=0)
-    ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--mask", type=int, default=-1)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0)
@@ -134,9 +135,9 @@ def main():
     flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if a.workload == "c2" else "c3.npz"))
     flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
     dfa = hip.HipDfa(flat, flags)
-    for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_NONTEMPORAL, a.nt),
-                    (hip.KNOB_WAVES, a.waves), (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu)):
-        if v > 0 or (knob == hip.KNOB_INPUT_MODE and v >= 0):
+    for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_ROWS, a.rows),
+                    (hip.KNOB_WAVES, a.waves), (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu), (hip.KNOB_MASK, a.mask)):
+        if v > 0 or (knob in (hip.KNOB_INPUT_MODE, hip.KNOB_MASK) and v >= 0):
             dfa.tune(knob, v)
     info = dfa.info()
 
@@ -146,7 +147,10 @@ def main():
     need = n * (L + 4) + n // 8 + (1 << 30)
     if need > free * 0.92:  # shrink rather than risk an OOM strike; reported in config
         n = int((free * 0.92 - (1 << 30)) // (L + 5)) // 64 * 64
-    first = rank * n
+    from libfsm_amd.shard import shard_range
+    first, cnt = shard_range(n * world, rank, world)  # weak scaling: the global batch is world x n inputs
+    assert cnt == n or n % 64 != 0
+    n = cnt
     buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
     end = torch.empty(n, dtype=torch.int32, device="cuda")
     nwords = (n + 63) // 64
@@ -163,7 +167,7 @@ def main():
         if record:
             kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
         if world > 1:
-            dist.all_gather_into_tensor(gathered, bm)  # the match bitmap over RCCL/xGMI
+            dist.all_gather_into_tensor(gathered, bm)  # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
 
     for _ in range(a.warmup):
         step(False)
