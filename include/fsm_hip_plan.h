@@ -23,7 +23,8 @@ enum {
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
-	FSM_HIP_KNOB_MASK          = 7   /* 0/1: absorbing lanes skip the state-dependent table lookup    */
+	FSM_HIP_KNOB_MASK          = 7,  /* 0/1: absorbing lanes skip the state-dependent table lookup    */
+	FSM_HIP_KNOB_HOT_BYTES     = 8   /* global layout: bytes of the table head mirrored in LDS        */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);

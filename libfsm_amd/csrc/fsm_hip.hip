@@ -37,6 +37,8 @@ struct fsm_hip_dfa {
 	/* tuning knobs (fsm_hip_dfa_tune) */
 	int knob_input_mode = -1;    /* -1 auto */
 	int knob_nb = 0;             /* 0 auto */
+	uint32_t glob_row_bytes = 4;
+	uint64_t glob_tab_bytes = 0;
 	int knob_rows = 0;           /* 0 auto */
 	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
@@ -44,6 +46,19 @@ struct fsm_hip_dfa {
 	int knob_early = -1;         /* -1: from flags */
 	unsigned flags = 0;
 };
+
+/* GLOBAL layout: how much of the table head (rows nearest the start state) every workgroup
+ * keeps in LDS.  40 KiB + the 32 KiB byte->class table still lets two 16-wave workgroups share a
+ * CU, which the HBM/L2 gathers of the cold rows need for latency hiding. */
+static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
+{
+	uint64_t hot = want;
+	if (hot > d->glob_tab_bytes) hot = d->glob_tab_bytes;
+	if (hot + lds_bytes_btab() + 8u * 4096u > d->lds_limit) hot = d->lds_limit - lds_bytes_btab() - 8u * 4096u;
+	hot -= hot % d->glob_row_bytes;
+	d->proto.tab_bytes = (uint32_t)hot;
+	d->table_lds = GlobPol<false>::lds_bytes((uint32_t)hot);
+}
 
 static int hip_errno(hipError_t e)
 {
@@ -164,11 +179,12 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.fin));
 			for (int b = 0; b < 256; b++) btab[b] = p.cls[b] * 4u;
-			a.tab_bytes = 0;
 			a.start = p.start * p.C * 4u;
 			a.abs_min = p.abs_min * p.C * 4u;
 			a.fin_div = p.C * 4u;
-			d->table_lds = lds_bytes_btab();
+			d->glob_row_bytes = p.C * 4u;
+			d->glob_tab_bytes = (uint64_t)p.glob_tab.size() * 4u;
+			set_hot_bytes(d, 40u * 1024u);
 			break;
 		}
 		default:
@@ -472,6 +488,10 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
 	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;
 	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
+	case FSM_HIP_KNOB_HOT_BYTES:
+		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
+		set_hot_bytes(d, (uint32_t)value);
+		break;
 	case FSM_HIP_KNOB_WAVES: d->knob_waves = value; break;
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;

@@ -189,14 +189,19 @@ struct Comb256Pol {
 template <bool MASK>
 struct GlobPol {
 	typedef uint32_t P;
-	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4       */
-	const unsigned char *tab;  /* device table; state is a byte offset into it    */
+	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4                */
+	const unsigned char *tab;  /* device table; state is a byte offset into it             */
+	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
+	uint32_t hot_bytes;        /* nearest the start state (breadth-first numbering)        */
 	uint32_t abs_min;
 
-	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return FSMHIP_BTAB_BYTES; }
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		hot = lds + FSMHIP_BTAB_BYTES;
+		hot_bytes = a.tab_bytes;
 		tab = static_cast<const unsigned char *>(a.tab);
 		abs_min = a.abs_min;
 	}
@@ -204,6 +209,7 @@ struct GlobPol {
 	__device__ __forceinline__ uint32_t next(uint32_t st, P ca) const
 	{
 		if (MASK && st >= abs_min) return st;
+		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + ca);
 		return *reinterpret_cast<const uint32_t *>(tab + st + ca);
 	}
 };

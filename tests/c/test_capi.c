@@ -1,0 +1,120 @@
+/*
+ * tests/c/test_capi.c -- the drop-in boundary exercised from plain C, written
+ * the way the reference's own unit tests are (cf. match_string() in
+ * tests/endids/utils.c:6-48 and run_test() in tests/re_strings/testutil.c:15-70):
+ * build an fsm with libre/libfsm, run every input through BOTH fsm_exec() and
+ * the HIP path (fsm_hip_compile + fsm_hip_exec / fsm_hip_exec_batch_offsets),
+ * assert identical return codes, end states and end-id sets.
+ *
+ * Links the real reference (oracle/_ref/libfsm_ref.so) -- test code may -- and
+ * libfsm_hip.so.  Prototypes of the reference's public API are restated here
+ * (include/fsm/fsm.h, include/re/re.h) because its headers do not travel to
+ * the GPU box.  Exit status 0 = PASS, like the reference's tests/ *.c programs.
+ */
+#include <assert.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fsm_hip.h"
+
+/* include/re/re.h:13-20, :137-140; include/fsm/fsm.h:65,199,223-228,473,503,560-562,579 */
+enum re_dialect { RE_LIKE, RE_LITERAL, RE_GLOB, RE_NATIVE, RE_SQL, RE_PCRE };
+struct re_err { int e; char buf[256]; };
+struct fsm *re_comp(enum re_dialect, int (*)(void *), void *, const void *alloc, int flags, struct re_err *);
+int fsm_sgetc(void *opaque);
+int fsm_determinise(struct fsm *);
+int fsm_minimise(struct fsm *);
+int fsm_setendid(struct fsm *, fsm_end_id_t);
+struct fsm *fsm_union(struct fsm *, struct fsm *, void *);
+int fsm_exec(const struct fsm *, int (*)(void *), void *, fsm_state_t *, struct fsm_capture *);
+size_t fsm_endid_count(const struct fsm *, fsm_state_t);
+int fsm_endid_get(const struct fsm *, fsm_state_t, size_t, fsm_end_id_t *);
+void fsm_free(struct fsm *);
+
+static struct fsm *
+compile(const char *re, fsm_end_id_t id)
+{
+	const char *s = re;
+	struct fsm *fsm = re_comp(RE_PCRE, fsm_sgetc, &s, NULL, 0, NULL);
+	assert(fsm != NULL);
+	assert(fsm_determinise(fsm));
+	assert(fsm_minimise(fsm));
+	assert(fsm_setendid(fsm, id));
+	return fsm;
+}
+
+int
+main(void)
+{
+	static const char *patterns[] = { "^abc$", "^ab*c$", "^a.c$", "[Ll]ibf+(sm)*", "^x(yz)+$" };
+	static const char *inputs[] = { "abc", "ac", "abbbc", "axc", "libfsm", "xxLibffsm", "xyzyz", "xy", "", "abcd", "zzz" };
+	enum { NP = sizeof patterns / sizeof *patterns, NI = sizeof inputs / sizeof *inputs };
+	struct fsm *fsm = NULL;
+	struct fsm_hip_dfa *dfa;
+	uint64_t off[NI + 1];
+	unsigned char buf[1024];
+	uint32_t end[NI];
+	uint64_t bitmap[(NI + 63) / 64];
+	size_t i, total = 0;
+	int npass = 0;
+
+	for (i = 0; i < NP; i++) {
+		struct fsm *f = compile(patterns[i], (fsm_end_id_t) (100 + i));
+		fsm = fsm == NULL ? f : fsm_union(fsm, f, NULL);
+		assert(fsm != NULL);
+	}
+	assert(fsm_determinise(fsm)); /* rx-style: union + determinise, end-ids kept (src/rx/main.c:1338-1385) */
+
+	dfa = fsm_hip_compile(fsm, 0);
+	if (dfa == NULL) {
+		perror("fsm_hip_compile");
+		return EXIT_FAILURE;
+	}
+
+	/* one input at a time: fsm_hip_exec has fsm_exec's signature and contract */
+	for (i = 0; i < NI; i++) {
+		const char *s1 = inputs[i], *s2 = inputs[i];
+		fsm_state_t e1 = 0xDEAD, e2 = 0xDEAD;
+		int r1 = fsm_exec(fsm, fsm_sgetc, &s1, &e1, NULL);
+		int r2 = fsm_hip_exec(dfa, fsm_sgetc, &s2, &e2, NULL);
+		assert(r1 == r2);
+		assert(e1 == e2); /* both untouched (0xDEAD) on reject */
+		assert(fsm_hip_match_buffer(dfa, inputs[i], strlen(inputs[i])) == r1);
+		off[i] = total;
+		memcpy(buf + total, inputs[i], strlen(inputs[i]));
+		total += strlen(inputs[i]);
+		npass += r1;
+	}
+	off[NI] = total;
+
+	/* the whole set as one batch: what retest's per-line loop becomes */
+	assert(fsm_hip_exec_batch_offsets(dfa, buf, off, NI, end, bitmap) == 0);
+	for (i = 0; i < NI; i++) {
+		const char *s = inputs[i];
+		fsm_state_t e = 0;
+		int r = fsm_exec(fsm, fsm_sgetc, &s, &e, NULL);
+		assert((end[i] != FSM_HIP_NO_MATCH) == (r == 1));
+		assert(((bitmap[i / 64] >> (i % 64)) & 1) == (uint64_t) (r == 1));
+		if (r == 1) {
+			fsm_end_id_t a[16], b[16];
+			size_t n = fsm_endid_count(fsm, e), k;
+			assert(end[i] == e);
+			assert(fsm_hip_endid_count(dfa, end[i]) == n && n <= 16);
+			assert(fsm_endid_get(fsm, e, n, a) == 1);
+			assert(fsm_hip_endid_get(dfa, end[i], n, b) == 1);
+			assert(n == 0 || fsm_hip_endid_get(dfa, end[i], n - 1, b) == 0); /* 0 = buffer too small */
+			for (k = 0; k < n; k++) {
+				assert(a[k] == b[k]);
+			}
+		}
+	}
+	assert(npass >= 6);
+
+	fsm_free(fsm); /* the device table is self-contained (retest frees the fsm early, main.c:1056-1058) */
+	assert(fsm_hip_match_buffer(dfa, "abc", 3) == 1);
+	fsm_hip_dfa_free(dfa);
+	printf("PASS %d/%d inputs matched, fsm_exec == fsm_hip on all\n", npass, (int) NI);
+	return EXIT_SUCCESS;
+}

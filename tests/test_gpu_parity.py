@@ -300,3 +300,21 @@ def test_aho_corasick_union_big_table(hip):
     from oracle.pyoracle import Oracle
     assert np.array_equal(end, Oracle(f.flatten()).table_walk(rows))
     dfa.close()
+
+
+def test_c_program_through_the_abi(hip, tmp_path):
+    """tests/c/test_capi.c: plain C host code (the reference's own test style) -- re_comp, fsm_union,
+    fsm_determinise from the real libfsm, then fsm_exec vs fsm_hip_exec / batch / end-ids."""
+    _need_ref()
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_capi")
+    ref_dir, lib_dir = os.path.join(root, "oracle", "_ref"), os.path.join(root, "libfsm_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-UNDEBUG", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "test_capi.c"), "-o", exe,
+                           "-L" + ref_dir, "-lfsm_ref", "-L" + lib_dir, "-lfsm_hip",
+                           "-Wl,-rpath," + ref_dir, "-Wl,-rpath," + lib_dir])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout
