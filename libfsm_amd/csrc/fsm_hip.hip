@@ -40,6 +40,7 @@ struct fsm_hip_dfa {
 	uint32_t glob_row_bytes = 4;
 	uint64_t glob_tab_bytes = 0;
 	int knob_rows = 0;           /* 0 auto */
+	int knob_seg = 0;            /* 0 auto (128) */
 	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
@@ -225,7 +226,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 struct LaunchCfg {
-	int mode, nb, rows, mask, waves, blocks_per_cu;
+	int mode, nb, rows, mask, waves, blocks_per_cu, seg;
 	uint32_t lds;
 };
 
@@ -236,8 +237,11 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.mode = IN_GENERIC;
 	c.nb = 1;
 	c.rows = 1;
+	c.seg = 64;
 	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
-	c.mask = d->knob_mask >= 0 ? d->knob_mask : (layout == FSM_HIP_LAYOUT_TINY ? 0 : 1);
+	/* measured: the exec-mask bookkeeping costs more than the bank conflicts it removes
+	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
+	c.mask = d->knob_mask > 0 ? 1 : 0;
 	if (fast_ok) {
 		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging wins while the table leaves room for
 		 * per-wave tiles; per-lane loads with 8 chunks in flight win next to a big LDS table */
@@ -245,6 +249,10 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 		if (d->knob_input_mode >= 0) mode = d->knob_input_mode;
 		if (mode == IN_LDSDMA && stride % 64u != 0) mode = IN_DIRECT;
 		c.mode = mode;
+		if (c.mode == IN_LDSDMA) {
+			c.seg = d->knob_seg == 64 ? 64 : 128;
+			if (stride % 128u != 0) c.seg = 64;
+		}
 		if (c.mode == IN_DIRECT) {
 			c.nb = d->knob_nb > 0 ? d->knob_nb : 8;
 			while (c.nb > 1 && (stride / 16u) % (unsigned)c.nb != 0) c.nb >>= 1;
@@ -252,7 +260,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 			if (c.rows == 2 && c.nb > 4) c.nb = 4;
 		}
 	}
-	const uint32_t per_wave = c.mode == IN_LDSDMA ? 4096u : 0u;
+	const uint32_t per_wave = c.mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : 0u;
 	/* waves per block: as many as LDS allows, 16 at most */
 	int waves = d->knob_waves > 0 ? d->knob_waves : (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY ? 8 : 16);
 	if (waves > 16) waves = 16;
@@ -272,7 +280,7 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 {
 	void (*k)(const WalkArgs) = nullptr;
 	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
-	else if (c.mode == IN_LDSDMA) k = walk_ldsdma<Pol>;
+	else if (c.mode == IN_LDSDMA) k = c.seg == 128 ? walk_ldsdma<Pol, 128> : walk_ldsdma<Pol, 64>;
 	else if (c.rows == 2) {
 		switch (c.nb) {
 		case 1: k = walk_direct<Pol, 1, 2>; break;
@@ -488,6 +496,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
 	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;
 	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
+	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_HOT_BYTES:
 		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
 		set_hot_bytes(d, (uint32_t)value);

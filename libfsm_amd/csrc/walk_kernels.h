@@ -31,11 +31,11 @@
  *                in flight, ROWS independent rows per lane (two interleaved
  *                state chains hide LDS latency when the table leaves room for
  *                one workgroup per CU only).
- *   walk_ldsdma  rows are fetched as whole 64-byte segments (4 adjacent lanes
- *                per row) by global_load_lds_dwordx4 straight into a 4 KiB
- *                per-wave LDS tile, piece-rotated so the row-per-lane
- *                ds_read_b128 that follows is bank-conflict-free; no VGPR
- *                staging, no ds_write.
+ *   walk_ldsdma  rows are fetched as whole 64- or 128-byte segments (4 / 8
+ *                adjacent lanes per row) by global_load_lds_dwordx4 straight
+ *                into a 4 / 8 KiB per-wave LDS tile, piece-rotated so the
+ *                row-per-lane ds_read_b128 that follows is bank-conflict-free;
+ *                no VGPR staging, no ds_write.
  *   walk_generic ragged lengths / arbitrary alignment / packed offsets.
  */
 #ifndef FSM_HIP_WALK_KERNELS_H
@@ -96,7 +96,16 @@ struct TinyPol {
 		colp = col + (threadIdx.x & 31u);
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return colp[b * 32u]; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const { return (uint32_t)(v >> (st * 4u)) & 15u; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const
+	{
+		if (sizeof(W) == 8) {
+			/* 32-bit ops only: pick the dword holding nibble `st`, then shift */
+			const uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+			const uint32_t h = (st & 8u) ? hi : lo;
+			return (h >> ((st & 7u) * 4u)) & 15u;
+		}
+		return (uint32_t)(v >> (st * 4u)) & 15u;
+	}
 };
 
 __device__ __forceinline__ const uint32_t *setup_btab(unsigned char *lds, const WalkArgs &a)
@@ -302,70 +311,85 @@ walk_direct(const WalkArgs a)
 }
 
 /* ------------------------------------------------------------------ */
-/* walk_ldsdma: coalesced 64-byte row segments DMA'd into a per-wave   */
+/* walk_ldsdma: coalesced SEG-byte row segments DMA'd into a per-wave  */
 /* LDS tile, read back row-per-lane                                   */
 /* ------------------------------------------------------------------ */
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-template <class Pol>
+/*
+ * SEG = 64 or 128 bytes of every row per tile (tile = 64 rows x SEG = 4 / 8 KiB per wave).
+ * One global_load_lds_dwordx4 moves 1 KiB: 64/PIECES rows x PIECES 16-byte pieces, PIECES = SEG/16
+ * adjacent lanes per row, so every request is a whole 64- or 128-byte run of one row.  With SEG = 128
+ * each 128-byte line is fetched by exactly one instruction (SEG = 64 splits a line over two
+ * instructions a whole tile apart; rocprofv3 FETCH_SIZE showed 16 % re-fetch, profiles/r01a_c2*).
+ *
+ * LDS placement is fixed by the hardware (M0 base + lane*16), so the loader picks WHICH piece each
+ * lane fetches: loader lane (row r, slot q) of DMA instruction j fetches piece (q - rot(i)) mod PIECES
+ * of row i = j*RPI + r, and reader lane i finds piece p of its row in slot (p + rot(i)) mod PIECES,
+ * rot(i) = (i >> ROTSH) mod PIECES.  For both SEG values every ds_read_b128 lane group
+ * ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-byte slots: conflict-free.
+ */
+template <class Pol, int SEG>
 __global__ void __launch_bounds__(1024)
 walk_ldsdma(const WalkArgs a)
 {
+	constexpr uint32_t PIECES = SEG / 16u;      /* 4 | 8 */
+	constexpr uint32_t RPI = 64u / PIECES;      /* rows per DMA instruction: 16 | 8 */
+	constexpr uint32_t NDMA = PIECES;           /* DMA instructions per tile: 4 | 8 */
+	constexpr uint32_t ROTSH = SEG == 64 ? 2u : 1u;
+	constexpr uint32_t TILE = 64u * SEG;
+
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * 4096u;
+	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * TILE;
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	const uint32_t nseg = (uint32_t)(a.stride / 64u); /* host guarantees stride % 64 == 0 */
+	const uint32_t nseg = (uint32_t)(a.stride / SEG); /* host guarantees stride % SEG == 0 */
 
-	/* loader role: lane = 4*r + q fetches, in DMA instruction j, the piece
-	 * p = (q - (r>>2)) & 3 of row 16*j + r, landing at stg + j*1024 + lane*16.
-	 * reader role: lane i = 16*j + r finds piece p of its own row at
-	 * stg + j*1024 + (4*r + ((p + (r>>2)) & 3)) * 16: within every
-	 * ds_read_b128 lane group the 16-byte slots are all distinct. */
-	const uint32_t lr = lane >> 2, lq = lane & 3u;
-	const uint32_t lpiece = (lq - (lr >> 2)) & 3u;
-	const uint32_t rj = lane >> 4, rr = lane & 15u;
-	const unsigned char *rd = stg + rj * 1024u + rr * 64u;
-	const uint32_t rot = rr >> 2;
+	const uint32_t lr = lane / PIECES, lq = lane % PIECES;          /* loader role */
+	const uint32_t rj = lane / RPI, rr = lane % RPI;                /* reader role */
+	const unsigned char *rd = stg + rj * 1024u + rr * SEG;
+	const uint32_t rot = (lane >> ROTSH) & (PIECES - 1u);
 
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
 		const uint64_t i = tile * 64u + lane;
 		const bool valid = i < a.n;
 		const uint64_t row0 = tile * 64u;
-		const unsigned char *src[4];
+		const unsigned char *src[NDMA];
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			uint64_t row = row0 + 16u * j + lr;
+		for (uint32_t j = 0; j < NDMA; j++) {
+			const uint32_t ri = j * RPI + lr; /* the reader lane this row belongs to */
+			uint64_t row = row0 + ri;
 			if (row >= a.n) row = a.n - 1;
-			src[j] = a.base + row * a.stride + lpiece * 16u;
+			const uint32_t piece = (lq - ((ri >> ROTSH) & (PIECES - 1u))) & (PIECES - 1u);
+			src[j] = a.base + row * a.stride + piece * 16u;
 		}
 		uint32_t st[1] = { a.start };
 #pragma unroll
-		for (int j = 0; j < 4; j++)
+		for (uint32_t j = 0; j < NDMA; j++)
 			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
 		for (uint32_t s = 0; s < nseg; s++) {
 			__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the tile has landed */
 			__asm__ volatile("" ::: "memory");
-			u32x4 w[4][1];
+			u32x4 w[PIECES][1];
 #pragma unroll
-			for (int p = 0; p < 4; p++)
-				w[p][0] = *reinterpret_cast<const u32x4 *>(rd + (((uint32_t)p + rot) & 3u) * 16u);
+			for (uint32_t p = 0; p < PIECES; p++)
+				w[p][0] = *reinterpret_cast<const u32x4 *>(rd + ((p + rot) & (PIECES - 1u)) * 16u);
 			__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile is in registers, slot reusable */
 			__asm__ volatile("" ::: "memory");
 			if (s + 1 < nseg) {
 #pragma unroll
-				for (int j = 0; j < 4; j++)
-					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * 64u),
+				for (uint32_t j = 0; j < NDMA; j++)
+					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * SEG),
 					                                 (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
 			}
 #pragma unroll
-			for (int p = 0; p < 4; p++) step16<Pol, 1>(pol, st, w[p]);
+			for (uint32_t p = 0; p < PIECES; p++) step16<Pol, 1>(pol, st, w[p]);
 			if (a.early && __all(st[0] >= a.abs_min)) {
 				__builtin_amdgcn_s_waitcnt(0x0F70); /* drain the prefetch before the tile is reused */
 				break;

@@ -71,12 +71,14 @@ def test_fast_paths_every_mode(hip, name):
     rows = g.rows
     n = len(rows)
     for L, dfa in layouts_for(hip, g.flat):
-        variants = [(hip.IN_GENERIC, 0, 1, 0), (hip.IN_LDSDMA, 0, 1, 0), (hip.IN_LDSDMA, 0, 1, 4)]
+        variants = [(hip.IN_GENERIC, 0, 1, 0), (hip.IN_LDSDMA, 64, 1, 0), (hip.IN_LDSDMA, 64, 1, 4),
+                    (hip.IN_LDSDMA, 128, 1, 0), (hip.IN_LDSDMA, 128, 1, 2)]
         variants += [(hip.IN_DIRECT, nb, rows_, 0) for nb in (1, 2, 4, 8) for rows_ in (1, 2)]
         variants += [(hip.IN_DIRECT, 4, 1, w) for w in (1, 2, 8)]
         for mode, nb, rows_, waves in variants:
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
-            dfa.tune(hip.KNOB_NB, nb)
+            dfa.tune(hip.KNOB_SEG, nb if mode == hip.IN_LDSDMA else 0)
+            dfa.tune(hip.KNOB_NB, nb if mode == hip.IN_DIRECT else 0)
             dfa.tune(hip.KNOB_ROWS, rows_)
             dfa.tune(hip.KNOB_WAVES, waves)
             for early, mask in ((0, 0), (1, 1), (0, 1)):
@@ -95,9 +97,10 @@ def test_batch_sizes(hip, n):
     rows = hip.gen_inputs_host(n, 128, 5, 77, None, b"libffsm", 3)
     want = Oracle(g.flat).table_walk(rows) if n else np.zeros(0, np.uint32)
     for L, dfa in layouts_for(hip, g.flat):
-        for mode, rows_ in ((hip.IN_DIRECT, 1), (hip.IN_DIRECT, 2), (hip.IN_LDSDMA, 1), (hip.IN_GENERIC, 1)):
+        for mode, rows_, seg in ((hip.IN_DIRECT, 1, 0), (hip.IN_DIRECT, 2, 0), (hip.IN_LDSDMA, 1, 64), (hip.IN_LDSDMA, 1, 128), (hip.IN_GENERIC, 1, 0)):
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
             dfa.tune(hip.KNOB_ROWS, rows_)
+            dfa.tune(hip.KNOB_SEG, seg)
             end, bm = dfa.exec_batch(rows)
             assert np.array_equal(end, want), (n, L, mode, rows_)
             assert np.array_equal(bits(bm, n), want != NO)
@@ -261,6 +264,29 @@ def test_shim_compile_vs_reference_fsm_exec(hip, dialect, regex, flags):
         r0, e0 = f.exec_one(s)
         assert r == r0
         assert endv.value == (e0 if r0 == 1 else 0xDEAD)   # *end untouched on reject (exec.c:133-138)
+    dfa.close()
+
+
+def test_sixteen_state_columns_under_full_occupancy(hip):
+    """Regression: 9..16-state DFAs use 64-bit transition columns.  A v_lshrrev_b64 whose
+    destination overlapped its shift-amount register gave wrong states in ~45 % of launches with
+    16 waves per workgroup (never with 4); the column is now decoded with 32-bit ops only."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    f = RefFsm.re_comp("glob", b"foo*bar?", 0, True, True, endid=5)
+    f.shuffle(1234)
+    flat = f.flatten()
+    assert 9 <= flat.nstates + 1 <= 16
+    rng = np.random.RandomState(17)
+    alpha = np.frombuffer(b"abcdefgxLlibsm0123456789:? \0\xff", np.uint8)
+    strings = [bytes(alpha[rng.randint(0, len(alpha), rng.randint(0, 40))]) for _ in range(3000)] + [b"fooXXbarz", b"foobar"]
+    ret, want = f.exec_strings(strings)
+    dfa = hip.HipDfa(flat, hip.LAYOUT_TINY)
+    for waves in (16, 8):
+        dfa.tune(hip.KNOB_WAVES, waves)
+        for _ in range(25):
+            end, _bm = dfa.exec_strings(strings)
+            assert np.array_equal(end, want), waves
     dfa.close()
 
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""tools/rocpd_summary.py -- condense tools/profile.sh output (rocprofv3 rocpd .db files) into a
+small JSON summary under profiles/, plus profiles/pmc_<workload>.json that bench.py reads for
+`roofline.traffic`.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts 128-byte
+requests as 64 bytes for 16-byte-per-lane coalesced streams (MI355X_MICROARCH.md section HBM), so the
+read side is doubled; WRITE_SIZE is taken as reported (uncalibrated).
+usage: rocpd_summary.py <prof_dir> <workload> <out_prefix>
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def rows(db, sql):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    cur.execute(sql)
+    cols = [d[0] for d in cur.description]
+    return [dict(zip(cols, r)) for r in cur.fetchall()]
+
+
+def main():
+    prof, wl, out = sys.argv[1:4]
+    bench = json.loads(open(os.path.join(prof, "bench_trace.json")).read().strip().splitlines()[-1])
+    top = rows(glob.glob(os.path.join(prof, "trace", "*.db"))[0], "select name, total_calls, total_duration, average, percentage from top_kernels")
+    walk = [t for t in top if "walk_" in t["name"]][0]
+    pmc = {}
+    for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        r = rows(glob.glob(os.path.join(prof, which, "*.db"))[0],
+                 f"select name, counter_name, counter_value, duration from pmc_events where counter_name = '{ctr}' and name like '%walk_%'")
+        pmc[ctr] = [x["counter_value"] for x in r]
+    n, L = bench["config"]["inputs_per_gpu"], bench["config"]["input_len"]
+    fetch_kib = sum(pmc["FETCH_SIZE"]) / len(pmc["FETCH_SIZE"])
+    write_kib = sum(pmc["WRITE_SIZE"]) / len(pmc["WRITE_SIZE"])
+    hbm = fetch_kib * 1024 * 2 + write_kib * 1024
+    alg = n * (L + 4)
+    summary = {
+        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline  (then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
+        "bench_line_under_trace": bench,
+        "kernel_stats_top": [{"name": t["name"][:120], "calls": t["total_calls"], "avg_us": round(t["average"], 1), "pct": round(t["percentage"], 2)} for t in top[:4]],
+        "walk_kernel": {"name": walk["name"], "calls": walk["total_calls"], "avg_ms": round(walk["average"] / 1e3, 4),
+                        "algorithmic_GBps": round(alg / (walk["average"] * 1e-6) / 1e9, 1)},
+        "pmc": {"FETCH_SIZE_KiB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": pmc["WRITE_SIZE"],
+                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
+                "note": "read side = FETCH_SIZE KiB x 1024 x 2 (gfx950: 128-B requests tallied as 64 B for 16-B/lane streams); write side as reported"},
+    }
+    json.dump(summary, open(out + "_rocprof_summary.json", "w"), indent=1)
+    json.dump({"n": n, "len": L, "hbm_bytes_per_launch": hbm, "kernel": walk["name"], "source": os.path.basename(out) + "_rocprof_summary.json"},
+              open(os.path.join(os.path.dirname(out), f"pmc_{wl}.json"), "w"))
+    print(json.dumps(summary["walk_kernel"]), json.dumps(summary["pmc"]["traffic_over_algorithmic"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -55,16 +55,18 @@ def main():
             # (mode, nb, rows, waves, bpc, mask, early)
             variants = [(-1, 0, 0, 0, 0, -1, 1)]  # library defaults
             if a.set == "full":
-                masks = (0,) if tiny else (0, 1)
+                masks = (0,)
                 variants += [(hip.IN_DIRECT, nb, r, 16, 0, m, 1) for nb in (4, 8) for r in (1, 2) for m in masks if not (nb == 8 and r == 2)]
                 variants += [(hip.IN_DIRECT, 2, 2, 16, 0, masks[-1], 1), (hip.IN_DIRECT, 8, 1, 8, 0, masks[-1], 1)]
-                variants += [(hip.IN_LDSDMA, 0, 1, w, 0, m, 1) for w in (4, 8, 16) for m in masks]
-                variants += [(hip.IN_LDSDMA, 0, 1, 8, 0, masks[-1], 0), (hip.IN_DIRECT, 8, 1, 16, 0, masks[-1], 0)]
+                variants += [(hip.IN_LDSDMA, seg, 1, w, 0, 0, 1) for w in (2, 4, 8, 16) for seg in (64, 128)]
+                variants += [(hip.IN_LDSDMA, 128, 1, 4, b, 0, 1) for b in (1, 2, 3, 4)]
+                variants += [(hip.IN_LDSDMA, 128, 1, 8, 0, 0, 0), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 0)]
                 variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
             for mode, nb, rows_, waves, bpc, mask, early in variants:
                 if True:
                     dfa.tune(hip.KNOB_INPUT_MODE, mode)
-                    dfa.tune(hip.KNOB_NB, nb)
+                    dfa.tune(hip.KNOB_NB, nb if mode != hip.IN_LDSDMA else 0)
+                    dfa.tune(hip.KNOB_SEG, nb if mode == hip.IN_LDSDMA else 0)
                     dfa.tune(hip.KNOB_ROWS, rows_)
                     dfa.tune(hip.KNOB_WAVES, waves)
                     dfa.tune(hip.KNOB_BLOCKS_PER_CU, bpc)
