@@ -262,7 +262,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	}
 	const uint32_t per_wave = c.mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : 0u;
 	/* waves per block: as many as LDS allows, 16 at most */
-	int waves = d->knob_waves > 0 ? d->knob_waves : (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY ? 8 : 16);
+	/* tiny + LDS-DMA is HBM-bound: small workgroups (4 waves, two per CU) measured best
+	 * (profiles/r01_sweep3*); tables that fill LDS want all 16 waves behind one copy */
+	int waves = d->knob_waves > 0 ? d->knob_waves : (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY ? 4 : 16);
 	if (waves > 16) waves = 16;
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves >>= 1;
 	c.waves = waves;
@@ -270,6 +272,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
 	if (bpc * waves > 32) bpc = 32 / waves;
 	if (bpc < 1) bpc = 1;
+	/* twice the resident workgroups: the tail of the persistent grid balances better */
+	if (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY) bpc *= 2;
 	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
 	c.blocks_per_cu = bpc;
 	return c;
