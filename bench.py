@@ -196,6 +196,11 @@ def main():
             dist.destroy_process_group()
         return
 
+    stream_gbps = None
+    try:  # what a trivially coalesced read-only kernel sustains over the same resident buffer
+        stream_gbps = hip.stream_read_probe_gbps(buf.data_ptr(), n * L, bm.data_ptr(), 3, stream)
+    except Exception:
+        pass
     ms_step = elapsed / a.steps * 1e3
     total_bytes = float(n) * L * world
     value = total_bytes / (elapsed / a.steps) / 1e9
@@ -227,6 +232,8 @@ def main():
         },
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "measured_read_stream_GBps": None if stream_gbps is None else round(stream_gbps, 1),
+                     "frac_of_measured_stream": None if not stream_gbps else round(achieved / stream_gbps, 4),
                      "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }

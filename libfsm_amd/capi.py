@@ -414,3 +414,13 @@ def gen_affix_inputs_device(d_base: int, n: int, stride: int, first_index: int, 
                                             C.c_void_p(stream or None))
     if r != 0:
         raise _oserr("fsm_hip_gen_affix_inputs_device")
+
+
+def stream_read_probe_gbps(d_base: int, nbytes: int, d_scratch4: int, reps: int = 3, stream: int = 0) -> float:
+    """GB/s of a trivially coalesced read-only kernel over the same buffer (measured HBM ceiling)."""
+    lib = load_library()
+    lib.fsm_hip_stream_read_probe_ms.restype = C.c_double
+    ms = lib.fsm_hip_stream_read_probe_ms(C.c_void_p(d_base), C.c_size_t(nbytes), C.c_void_p(d_scratch4), C.c_int(reps), C.c_void_p(stream or None))
+    if ms <= 0:
+        raise _oserr("fsm_hip_stream_read_probe_ms")
+    return nbytes / (ms * 1e-3) / 1e9

@@ -721,3 +721,33 @@ extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride
 		}
 	}
 }
+
+/* ---- HBM read-stream probe ---- */
+
+extern "C" double fsm_hip_stream_read_probe_ms(const void *d_base, size_t bytes, void *d_scratch4, int reps, void *hip_stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	float ms = -1.f;
+	if (d_base == nullptr || d_scratch4 == nullptr || bytes < 16 || reps <= 0 ||
+	    (reinterpret_cast<uintptr_t>(d_base) % 16u) != 0) { errno = EINVAL; return -1.0; }
+	int dev = 0, ncu = 256;
+	(void)hipGetDevice(&dev);
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)ncu * 8u), dim3(256), 0, s,
+	                   static_cast<const u32x4 *>(d_base), (uint64_t)(bytes / 16u), static_cast<uint32_t *>(d_scratch4));
+	HIP_TRY(hipEventRecord(e0, s));
+	for (int r = 0; r < reps; r++)
+		hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)ncu * 8u), dim3(256), 0, s,
+		                   static_cast<const u32x4 *>(d_base), (uint64_t)(bytes / 16u), static_cast<uint32_t *>(d_scratch4));
+	HIP_TRY(hipEventRecord(e1, s));
+	HIP_TRY(hipEventSynchronize(e1));
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	ms /= (float)reps;
+fail:
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return (double)ms;
+}

@@ -548,6 +548,24 @@ gen_affix_kernel(const GenArgs g, const AffixArgs x)
 	}
 }
 
+/* Read-only streaming probe: the HBM read rate a trivially coalesced kernel reaches on this
+ * device (16 B per lane, grid-stride), reported by bench.py next to the spec peak. */
+__global__ void __launch_bounds__(256)
+stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
+{
+	u32x4 acc = {0u, 0u, 0u, 0u};
+	const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (; i + 3 * step < nvec; i += 4 * step) {
+		const u32x4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+		acc ^= a ^ b ^ c ^ d;
+	}
+	for (; i < nvec; i += step) acc ^= src[i];
+	const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	if (x == 0x9E3779B9u) out[0] = x; /* practically never: keeps the loads alive */
+}
+
 } // namespace fsmhip
+
 
 #endif
