@@ -48,7 +48,8 @@ enum {
 	FSM_HIP_PLAN_GLOB_TAB  = 11, /* u32[S1*C] */
 	FSM_HIP_PLAN_COMB256     = 12, /* u32[] */
 	FSM_HIP_PLAN_COMB256_OFF = 13, /* u32[S1] */
-	FSM_HIP_PLAN_COMB256_FIN = 14  /* u32[] */
+	FSM_HIP_PLAN_COMB256_FIN = 14, /* u32[] */
+	FSM_HIP_PLAN_COMB_SMASK  = 15  /* u32[] by comb row offset */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

@@ -135,6 +135,21 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			d->table_lds = p.S1 <= 8 ? TinyPol<uint32_t>::lds_bytes(0) : TinyPol<uint64_t>::lds_bytes(0);
 			break;
 		}
+		case FSM_HIP_LAYOUT_COMBSELF: {
+			uint32_t *t = nullptr;
+			std::vector<uint32_t> img(p.comb);
+			img.insert(img.end(), p.comb_smask.begin(), p.comb_smask.end());
+			HIP_TRY(upload(&t, img));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.comb_fin));
+			for (int b = 0; b < 256; b++) btab[b] = (p.comb_dflt[p.cls[b]] << 16) | p.cls[b];
+			a.tab_bytes = (uint32_t)(img.size() * 4);
+			a.start = p.comb_off[p.start];
+			a.abs_min = p.comb_abs_min_off;
+			a.fin_div = 1;
+			d->table_lds = CombSelfPol::lds_bytes(a.tab_bytes);
+			break;
+		}
 		case FSM_HIP_LAYOUT_COMB256: {
 			uint32_t *t = nullptr;
 			HIP_TRY(upload(&t, p.comb256));
@@ -332,6 +347,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		case FSM_HIP_LAYOUT_LDS:     e = launch_masked<LdsPol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_COMB:    e = launch_masked<CombPol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_COMB256: e = launch_masked<Comb256Pol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMBSELF: e = launch_pol<CombSelfPol>(c, a, grid, block, s); break;
 		default:                     e = launch_masked<GlobPol>(c, a, grid, block, s); break;
 		}
 	}
@@ -483,6 +499,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_LDS: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
+	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
 	LaunchCfg c = pick_cfg(d, true, 1024);
@@ -571,6 +588,7 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB256: *data = p.comb256.data(); *count = p.comb256.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;
+	case FSM_HIP_PLAN_COMB_SMASK: *data = p.comb_smask.data(); *count = p.comb_smask.size(); return 0;
 	default: errno = EINVAL; return -1;
 	}
 }

@@ -204,6 +204,32 @@ try {
 		p.layout = FSM_HIP_LAYOUT_COMB;
 		return 0;
 	};
+	auto emit_combself = [&]() -> int {
+		if (C > 32) return ENOTSUP;
+		/* image = comb + masks: half the room each */
+		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 8u, 65535u);
+		int r = build_comb(p, max_entries, false);
+		if (r) return r;
+		p.comb_smask.assign(p.comb.size(), 0u);
+		for (uint32_t n = 0; n < S1; n++) {
+			uint32_t m = 0;
+			for (uint32_t c = 0; c < C; c++)
+				if (p.dense[(size_t)n * C + c] == n) m |= 1u << c;
+			if (n >= p.abs_min) m = 0xFFFFFFFFu;
+			p.comb_smask[p.comb_off[n]] = m;
+		}
+		p.layout = FSM_HIP_LAYOUT_COMBSELF;
+		return 0;
+	};
+	{
+		uint32_t with_loop = 0;
+		for (uint32_t n = 0; n < p.abs_min; n++) {
+			bool any = false;
+			for (uint32_t c = 0; c < C && !any; c++) any = p.dense[(size_t)n * C + c] == n;
+			with_loop += any;
+		}
+		p.selfloop_fraction = p.abs_min ? (double)with_loop / p.abs_min : 0.0;
+	}
 	auto emit_comb256 = [&]() -> int {
 		/* no byte->class table in LDS for this layout */
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>((lds_room + lds_bytes_btab()) / 4u, 65535u);
@@ -226,8 +252,12 @@ try {
 	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
 	case FSM_HIP_LAYOUT_GLOBAL: return emit_glob();
 	case FSM_HIP_LAYOUT_COMB256: return emit_comb256();
+	case FSM_HIP_LAYOUT_COMBSELF: return emit_combself();
 	case FSM_HIP_LAYOUT_AUTO:
 		if (emit_tiny() == 0) return 0;
+		/* many states sit in self-loops ([0-9]+, .*): bytes that do not change the state then
+		 * cost one conflict-free lookup (CombSelfPol) */
+		if (p.selfloop_fraction >= 0.15 && emit_combself() == 0) return 0;
 		if (emit_comb256() == 0) return 0;
 		if (emit_lds() == 0) return 0;
 		if (emit_comb() == 0) return 0;

@@ -51,6 +51,10 @@ struct Plan {
 	std::vector<uint32_t> comb_off;       /* [S1] row offset of each renumbered state */
 	std::vector<uint32_t> comb_fin;       /* [comb.size()] fin by row offset (NO_MATCH elsewhere) */
 	uint32_t comb_abs_min_off = 0;        /* row offsets >= this are absorbing */
+	/* COMBSELF: comb + per-row-offset self-loop masks (bit c: class c loops to the same state;
+	 * absorbing states: all ones).  Device image = comb[] followed by comb_smask[].   */
+	std::vector<uint32_t> comb_smask;
+	double selfloop_fraction = 0.0;   /* non-absorbing states owning at least one self-loop class */
 	/* COMB256: the same over raw bytes (256-wide rows), one default state for
 	 * every column: no byte->class lookup at all in the walk.                */
 	std::vector<uint32_t> comb256, comb256_off, comb256_fin;

@@ -22,7 +22,9 @@
  *   Comb256Pol comb exceptions over raw BYTES with one default state for every
  *              column (typically DEAD): pre is the byte itself, one LDS lookup
  *              per input byte in total.
- *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS.
+ *   CombSelfPol CombPol + a self-loop mask per state kept in a register: bytes on
+ *              which the state does not change cost only the conflict-free B lookup.
+ *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS (+ LDS mirror of its head).
  * MASK: lanes already in an absorbing state skip the state-dependent lookup
  * (exec-masked), which takes their addresses out of the LDS bank arbitration.
  *
@@ -85,6 +87,9 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 template <class W>
 struct TinyPol {
 	typedef W P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 32u * (uint32_t)sizeof(W); }
@@ -125,6 +130,9 @@ __device__ __forceinline__ void copy_table(unsigned char *dst, const WalkArgs &a
 template <bool MASK>
 struct LdsPol {
 	typedef uint32_t P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 2      */
 	const unsigned char *tab;  /* LDS table; state is a byte offset into it      */
 	uint32_t abs_min;
@@ -151,6 +159,9 @@ struct LdsPol {
 template <bool MASK>
 struct CombPol {
 	typedef uint32_t P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
 	uint32_t abs_min;
@@ -175,6 +186,9 @@ struct CombPol {
 template <bool MASK>
 struct Comb256Pol {
 	typedef uint32_t P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte */
 	uint32_t abs_min, dflt;
 
@@ -195,9 +209,55 @@ struct Comb256Pol {
 	}
 };
 
+/*
+ * CombSelfPol: CombPol plus a per-state SELF-LOOP MASK carried in a register next to the state:
+ * bit c of sm says delta(state, class c) == state.  Regex DFAs spend most bytes in self-loops
+ * ([0-9]+, .*, the absorbing DEAD/accept states), and for those bytes the walk needs only the
+ * conflict-free byte->class lookup: the comb lookup (random banks, ~3.5-way conflicts) and the
+ * reload of the mask run under an exec mask for the few lanes that really change state, and are
+ * skipped by the whole wavefront when none does.  Absorbing states have every bit set, so
+ * retired lanes drop out of the LDS traffic for free.  Needs <= 32 byte classes.
+ */
+struct CombSelfState { uint32_t st, sm; };
+
+struct CombSelfPol {
+	typedef uint32_t P;
+	typedef CombSelfState S;
+	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
+	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
+	const uint32_t *smask;  /* LDS, indexed by row offset: self-loop mask of that state */
+	uint32_t start_sm;
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a); /* image = comb[n] followed by smask[n] */
+		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
+		smask = comb + a.tab_bytes / 8u;
+		start_sm = static_cast<const uint32_t *>(a.tab)[a.tab_bytes / 8u + a.start];
+	}
+	__device__ __forceinline__ S init(const WalkArgs &a) const { S s = { a.start, start_sm }; return s; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
+	__device__ __forceinline__ S next(S s, P be) const
+	{
+		const uint32_t c = be & 0xffffu;
+		if (!((s.sm >> c) & 1u)) {
+			const uint32_t x = comb[s.st + c] ^ (s.st << 16);
+			s.st = x < 0x10000u ? x : (be >> 16);
+			s.sm = smask[s.st];
+		}
+		return s;
+	}
+};
+
 template <bool MASK>
 struct GlobPol {
 	typedef uint32_t P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4                */
 	const unsigned char *tab;  /* device table; state is a byte offset into it             */
 	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
@@ -226,7 +286,7 @@ struct GlobPol {
 /* 16 input bytes of ROWS independent rows: all state-independent lookups
  * first, then the ROWS state chains interleaved byte by byte. */
 template <class Pol, int ROWS>
-__device__ __forceinline__ void step16(const Pol &pol, uint32_t (&st)[ROWS], const u32x4 (&w)[ROWS])
+__device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
 	typename Pol::P pre[ROWS][16];
 #pragma unroll
@@ -273,13 +333,13 @@ walk_direct(const WalkArgs a)
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
 		uint64_t i[ROWS];
 		const u32x4 *q[ROWS];
-		uint32_t st[ROWS];
+		typename Pol::S st[ROWS];
 		u32x4 cur[NB][ROWS], nxt[NB][ROWS];
 #pragma unroll
 		for (int r = 0; r < ROWS; r++) {
 			i[r] = (tile * ROWS + r) * 64u + lane;
 			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
-			st[r] = a.start;
+			st[r] = pol.init(a);
 		}
 #pragma unroll
 		for (int j = 0; j < NB; j++)
@@ -297,7 +357,7 @@ walk_direct(const WalkArgs a)
 			if (a.early) {
 				bool done = true;
 #pragma unroll
-				for (int r = 0; r < ROWS; r++) done = done && st[r] >= a.abs_min;
+				for (int r = 0; r < ROWS; r++) done = done && Pol::code(st[r]) >= a.abs_min;
 				if (__all(done)) break;
 			}
 #pragma unroll
@@ -306,7 +366,7 @@ walk_direct(const WalkArgs a)
 				for (int r = 0; r < ROWS; r++) cur[j][r] = nxt[j][r];
 		}
 #pragma unroll
-		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + r, i[r], i[r] < a.n, st[r]);
+		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + r, i[r], i[r] < a.n, Pol::code(st[r]));
 	}
 }
 
@@ -369,7 +429,7 @@ walk_ldsdma(const WalkArgs a)
 			const uint32_t piece = (lq - ((ri >> ROTSH) & (PIECES - 1u))) & (PIECES - 1u);
 			src[j] = a.base + row * a.stride + piece * 16u;
 		}
-		uint32_t st[1] = { a.start };
+		typename Pol::S st[1] = { pol.init(a) };
 #pragma unroll
 		for (uint32_t j = 0; j < NDMA; j++)
 			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
@@ -390,12 +450,12 @@ walk_ldsdma(const WalkArgs a)
 			}
 #pragma unroll
 			for (uint32_t p = 0; p < PIECES; p++) step16<Pol, 1>(pol, st, w[p]);
-			if (a.early && __all(st[0] >= a.abs_min)) {
+			if (a.early && __all(Pol::code(st[0]) >= a.abs_min)) {
 				__builtin_amdgcn_s_waitcnt(0x0F70); /* drain the prefetch before the tile is reused */
 				break;
 			}
 		}
-		write_result(a, tile, i, valid, st[0]);
+		write_result(a, tile, i, valid, Pol::code(st[0]));
 	}
 }
 
@@ -431,20 +491,20 @@ walk_generic(const WalkArgs a)
 		const uint32_t head = (uint32_t)(p0 - q0);
 		const uint64_t span = len ? head + len : 0;
 		const uint64_t nchunks = (span + 15u) / 16u;
-		uint32_t st = a.start;
+		typename Pol::S st = pol.init(a);
 		for (uint64_t c = 0; __any(c < nchunks); c++) {
 			if (c < nchunks) {
 				const u32x4 w = *reinterpret_cast<const u32x4 *>(q0 + c * 16u);
 #pragma unroll
 				for (int k = 0; k < 16; k++) {
 					const uint64_t pos = c * 16u + k - head; /* wraps below head: huge, fails the test */
-					const uint32_t nx = pol.next(st, pol.pre(byte_of(w, k)));
+					const typename Pol::S nx = pol.next(st, pol.pre(byte_of(w, k)));
 					st = pos < len ? nx : st;
 				}
 			}
-			if (a.early && __all(st >= a.abs_min || c + 1 >= nchunks)) break;
+			if (a.early && __all(Pol::code(st) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
-		write_result(a, tile, i, valid, st);
+		write_result(a, tile, i, valid, Pol::code(st));
 	}
 }
 

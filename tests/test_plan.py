@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from common import Golden, all_golden_paths, golden_id
-from libfsm_amd import ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
+from libfsm_amd import ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
 
 NO = 0xFFFFFFFF
 
@@ -53,7 +53,7 @@ def check_plan(flat, layout):
         e = tab[(st + cls[bytes_][None, :] * 2) // 2]
         got = (e << 2) // rb
         assert ((e << 2) % rb == 0).all()
-    elif p.layout == LAYOUT_COMB:
+    elif p.layout in (LAYOUT_COMB, LAYOUT_COMBSELF):
         comb = p.get("comb").astype(np.int64)
         off = p.get("comb_off").astype(np.int64)
         dfl = p.get("comb_dflt").astype(np.int64)
@@ -67,6 +67,15 @@ def check_plan(flat, layout):
         got = back[nxt_off]
         assert np.array_equal(cfin[off], fin)
         assert ((off >= p.comb_abs_min_off) == absorbing).all()
+        if p.layout == LAYOUT_COMBSELF:
+            sm = p.get("comb_smask").astype(np.int64)
+            assert len(sm) == len(comb) and Cn <= 32
+            # bit c of the mask at a state's row offset <=> class c loops to the state itself
+            rep = np.array([np.nonzero(cls == c)[0][0] for c in range(Cn)])
+            loops = want[:, rep] == np.arange(S1)[:, None]
+            bits = (sm[off][:, None] >> np.arange(Cn)[None, :]) & 1
+            assert np.array_equal(bits[~absorbing].astype(bool), loops[~absorbing])
+            assert (sm[off][absorbing] == 0xFFFFFFFF).all()
     elif p.layout == LAYOUT_COMB256:
         comb = p.get("comb256").astype(np.int64)
         off = p.get("comb256_off").astype(np.int64)
@@ -102,7 +111,7 @@ def test_auto_layout_choices(built):
     from common import GOLDEN
     assert Plan(Golden(os.path.join(GOLDEN, "c1.npz")).flat).layout == LAYOUT_TINY
     c3 = Plan(Golden(os.path.join(GOLDEN, "c3.npz")).flat)
-    assert c3.layout in (LAYOUT_COMB256, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
+    assert c3.layout in (LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
 
 
 def test_rejects_non_dfa(built):
