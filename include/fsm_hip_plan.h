@@ -25,7 +25,8 @@ enum {
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
 	FSM_HIP_KNOB_MASK          = 7,  /* 0/1: absorbing lanes skip the state-dependent table lookup    */
 	FSM_HIP_KNOB_HOT_BYTES     = 8,  /* global layout: bytes of the table head mirrored in LDS        */
-	FSM_HIP_KNOB_SEG           = 9   /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */
+	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */
+	FSM_HIP_KNOB_PREFETCH      = 10  /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);

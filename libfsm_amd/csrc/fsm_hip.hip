@@ -41,6 +41,7 @@ struct fsm_hip_dfa {
 	uint64_t glob_tab_bytes = 0;
 	int knob_rows = 0;           /* 0 auto */
 	int knob_seg = 0;            /* 0 auto (128) */
+	int knob_prefetch = -1;      /* -1 auto (on) */
 	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
@@ -241,7 +242,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 struct LaunchCfg {
-	int mode, nb, rows, mask, waves, blocks_per_cu, seg;
+	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch;
 	uint32_t lds;
 };
 
@@ -253,6 +254,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
+	c.prefetch = d->knob_prefetch == 0 ? 0 : 1;
 	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
 	/* measured: the exec-mask bookkeeping costs more than the bank conflicts it removes
 	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
@@ -300,7 +302,9 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	void (*k)(const WalkArgs) = nullptr;
 	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
 	else if (c.mode == IN_LDSDMA) k = c.seg == 128 ? walk_ldsdma<Pol, 128> : walk_ldsdma<Pol, 64>;
-	else if (c.rows == 2) {
+	else if (!c.prefetch && c.rows == 1 && c.nb >= 4) {
+		k = c.nb == 4 ? walk_direct_np<Pol, 4> : walk_direct_np<Pol, 8>;
+	} else if (c.rows == 2) {
 		switch (c.nb) {
 		case 1: k = walk_direct<Pol, 1, 2>; break;
 		case 2: k = walk_direct<Pol, 2, 2>; break;
@@ -518,6 +522,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;
 	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
+	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;
 	case FSM_HIP_KNOB_HOT_BYTES:
 		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
 		set_hot_bytes(d, (uint32_t)value);

@@ -370,6 +370,38 @@ walk_direct(const WalkArgs a)
 	}
 }
 
+/* walk_direct_np: same loads, NO register double-buffer: 8 chunks (one full 128-byte line per
+ * lane) are loaded, waited for and walked; latency is hidden by occupancy instead (<= 64 VGPRs so
+ * two 16-wave workgroups share a CU when their LDS tables fit twice). */
+template <class Pol, int NB>
+__global__ void __launch_bounds__(1024, 8)
+walk_direct_np(const WalkArgs a)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	Pol pol;
+	pol.setup(lds, a);
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	const uint64_t ntiles = (a.n + 63u) / 64u;
+	const uint32_t ngroups = (uint32_t)(a.stride / 16u) / NB; /* host guarantees divisibility */
+
+	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
+		const uint64_t i = tile * 64u + lane;
+		const u32x4 *q = reinterpret_cast<const u32x4 *>(a.base + (i < a.n ? i : a.n - 1) * a.stride);
+		typename Pol::S st[1] = { pol.init(a) };
+		for (uint32_t g = 0; g < ngroups; g++) {
+			u32x4 cur[NB][1];
+#pragma unroll
+			for (int j = 0; j < NB; j++) cur[j][0] = q[g * NB + j];
+#pragma unroll
+			for (int j = 0; j < NB; j++) step16<Pol, 1>(pol, st, cur[j]);
+			if (a.early && __all(Pol::code(st[0]) >= a.abs_min)) break;
+		}
+		write_result(a, tile, i, i < a.n, Pol::code(st[0]));
+	}
+}
+
 /* ------------------------------------------------------------------ */
 /* walk_ldsdma: coalesced SEG-byte row segments DMA'd into a per-wave  */
 /* LDS tile, read back row-per-lane                                   */

@@ -81,9 +81,10 @@ def test_fast_paths_every_mode(hip, name):
             dfa.tune(hip.KNOB_NB, nb if mode == hip.IN_DIRECT else 0)
             dfa.tune(hip.KNOB_ROWS, rows_)
             dfa.tune(hip.KNOB_WAVES, waves)
-            for early, mask in ((0, 0), (1, 1), (0, 1)):
+            for early, mask in ((0, 0), (1, 1), (0, 1), (1, 2)):
                 dfa.tune(hip.KNOB_EARLY_RETIRE, early)
-                dfa.tune(hip.KNOB_MASK, mask)
+                dfa.tune(hip.KNOB_MASK, mask & 1)
+                dfa.tune(hip.KNOB_PREFETCH, 0 if mask & 2 else 1)
                 end, bm = dfa.exec_batch(rows)
                 assert np.array_equal(end, g.end), (name, L, mode, nb, rows_, waves, early, mask)
                 assert np.array_equal(bits(bm, n), g.ret == 1)

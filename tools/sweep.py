@@ -61,6 +61,7 @@ def main():
                 variants += [(hip.IN_LDSDMA, seg, 1, w, 0, 0, 1) for w in (2, 4, 8, 16) for seg in (64, 128)]
                 variants += [(hip.IN_LDSDMA, 128, 1, 4, b, 0, 1) for b in (1, 2, 3, 4)]
                 variants += [(hip.IN_LDSDMA, 128, 1, 8, 0, 0, 0), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 0)]
+                variants += [(hip.IN_DIRECT, nb, 1, w, b, 2, 1) for nb in (4, 8) for w in (16, 8) for b in (0, 4)]  # mask=2: no-prefetch kernel
                 variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
             for mode, nb, rows_, waves, bpc, mask, early in variants:
                 if True:
@@ -70,7 +71,8 @@ def main():
                     dfa.tune(hip.KNOB_ROWS, rows_)
                     dfa.tune(hip.KNOB_WAVES, waves)
                     dfa.tune(hip.KNOB_BLOCKS_PER_CU, bpc)
-                    dfa.tune(hip.KNOB_MASK, mask)
+                    dfa.tune(hip.KNOB_MASK, mask & 1)
+                    dfa.tune(hip.KNOB_PREFETCH, 0 if mask & 2 else 1)
                     dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                     nt = rows_
                     ms = []
