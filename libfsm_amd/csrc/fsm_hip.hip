@@ -254,7 +254,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
-	c.prefetch = d->knob_prefetch == 0 ? 0 : 1;
+	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
+	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
+	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF ? 0 : 1);
 	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
 	/* measured: the exec-mask bookkeeping costs more than the bank conflicts it removes
 	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
@@ -290,7 +292,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	if (bpc * waves > 32) bpc = 32 / waves;
 	if (bpc < 1) bpc = 1;
 	/* twice the resident workgroups: the tail of the persistent grid balances better */
-	if (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY) bpc *= 2;
+	if (c.mode != IN_GENERIC) bpc *= 2;
 	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
 	c.blocks_per_cu = bpc;
 	return c;
