@@ -345,3 +345,64 @@ def test_c_program_through_the_abi(hip, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+def test_config0_full_size_vs_reference(hip):
+    """BASELINE configs[0] at its stated size: [Ll]ibf+(sm)* over 1e6 random 256-byte strings,
+    GPU vs the reference's fsm_exec on every one of them (and vs the oracle)."""
+    _need_ref()
+    from oracle.pyoracle import Oracle, RefFsm
+    f = RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
+    dfa = hip.HipDfa.compile_fsm(f.ptr)
+    rows = hip.gen_inputs_host(1_000_000, 256, 0, 0x5EEDF5A1, None, b"Libfsm", 8)
+    ret, want = f.exec_stride(rows)
+    assert 124_000 < int((ret == 1).sum()) < 127_000           # 1/8 planted + a few random hits
+    end, bm = dfa.exec_batch(rows)
+    assert np.array_equal(end, want)
+    assert np.array_equal(bits(bm, len(rows)), ret == 1)
+    assert np.array_equal(Oracle(f.flatten()).table_walk(rows), want)
+    assert np.array_equal(dfa.endids(int(want[0])), [0])
+    dfa.close()
+
+
+def test_config5_aho_corasick_100k_literals(hip):
+    """BASELINE configs[4]: re_strings over 1e5 literals (~3e5 states, table >> LDS): the
+    HBM/L2-resident layout, checked against the oracle walker and, on a few inputs, fsm_exec."""
+    _need_ref()
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import threading
+    from oracle.pyoracle import Oracle, RefFsm
+    rng = np.random.RandomState(5)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 26, rng.randint(4, 9))]) for _ in range(100000)))
+    out = {}
+
+    def work():                       # ac.c recurses per trie node: needs a big stack
+        out["f"] = RefFsm.re_strings(words, 0, True)
+        out["flat"] = out["f"].flatten()
+
+    threading.stack_size(1 << 30)
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    f, flat = out["f"], out["flat"]
+    assert flat.nstates > 250_000
+    dfa = hip.HipDfa(flat)
+    assert dfa.info()["layout_name"] == "global"
+    rows = alpha[rng.randint(0, 26, (20000, 1024))]
+    for i in range(0, 20000, 2):      # end half of the rows on a word so they accept
+        w = words[rng.randint(len(words))]
+        rows[i, 1024 - len(w):] = np.frombuffer(w, np.uint8)
+    want = Oracle(flat).table_walk(rows)
+    assert (want != NO).sum() >= 10000
+    for mode in (hip.IN_DIRECT, hip.IN_LDSDMA, hip.IN_GENERIC):
+        dfa.tune(hip.KNOB_INPUT_MODE, mode)
+        end, _ = dfa.exec_batch(rows)
+        assert np.array_equal(end, want), mode
+    ret, e5 = f.exec_stride(rows[:5])  # literal fsm_exec sweeps all 3e5 states per call
+    assert np.array_equal(e5, want[:5])
+    for e in set(int(x) for x in want[:200] if x != NO):
+        assert np.array_equal(dfa.endids(e), f.endids(e))
+    dfa.close()

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""tools/sweep.py -- time many kernel variants in ONE process (GPU minutes are scarce).
+"""tests/tools/sweep.py -- time many kernel variants in ONE process (GPU minutes are scarce).
+(Lives under tests/ because it uses the oracle as its checker.)
 
 Every variant's end states are compared with the first variant's (and the first
 is sample-checked against the oracle), so a fast-but-wrong variant is flagged.
-Usage: python tools/sweep.py [--n 8000000] [--workloads c2,c3] [--quick]
+Usage: python tests/tools/sweep.py [--n 8000000] [--workloads c2,c3] [--quick]
 """
 import argparse
 import itertools
@@ -12,8 +13,31 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+
+
+def c5_dfa(nwords=100000, seed=5):
+    """BASELINE configs[4]: Aho-Corasick DFA over 1e5 random 4-8 letter words, built by the real
+    reference (re_strings, src/libre/ac.c) -- its recursion needs a big stack, hence the thread."""
+    import threading
+    from oracle.pyoracle import RefFsm
+    rng = np.random.RandomState(seed)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 26, rng.randint(4, 9))]) for _ in range(nwords)))
+    out = {}
+
+    def work():
+        f = RefFsm.re_strings(words, 0, True)
+        out["flat"] = f.flatten()
+        out["f"] = f
+
+    threading.stack_size(1 << 30)
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    return out["flat"]
 
 
 def main():
@@ -38,8 +62,12 @@ def main():
     bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
     print(f"# n={n} len={L} bytes={n * L / 1e9:.2f} GB  device={torch.cuda.get_device_name(0)}", flush=True)
     for wl in a.workloads.split(","):
-        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
-        bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
+        if wl == "c5":
+            flat = c5_dfa()
+            hip.gen_inputs_device(buf.data_ptr(), n, L, 0, 0x5EEDF5A1, b"abcdefghijklmnopqrstuvwxyz")
+        else:
+            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
+            bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
         torch.cuda.synchronize()
         first = True
         layouts = hip.ALL_LAYOUTS if a.layouts == "all" else [int(x) for x in a.layouts.split(",")]
@@ -63,7 +91,16 @@ def main():
                 variants += [(hip.IN_LDSDMA, 128, 1, 8, 0, 0, 0), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 0)]
                 variants += [(hip.IN_DIRECT, nb, 1, w, b, 2, 1) for nb in (4, 8) for w in (16, 8) for b in (0, 4)]  # mask=2: no-prefetch kernel
                 variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
-            for mode, nb, rows_, waves, bpc, mask, early in variants:
+            if a.set == "hot":  # global layout: how much of the table head to mirror in LDS
+                variants = [(hip.IN_DIRECT, 8, 1, w, 0, pf, 1) for w in (16, 8) for pf in (0, 2)]
+                variants += [(hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_LDSDMA, 128, 1, 8, 0, 0, 1)]
+            hots = (0, 16384, 40960, 98304) if (a.set == "hot" and info["layout_name"] == "global") else (None,)
+            for hot in hots:
+              if hot is not None:
+                dfa.tune(hip.KNOB_HOT_BYTES, hot)
+                print(f"### hot_bytes={hot}", flush=True)
+              variants_ = variants
+              for mode, nb, rows_, waves, bpc, mask, early in variants_:
                 if True:
                     dfa.tune(hip.KNOB_INPUT_MODE, mode)
                     dfa.tune(hip.KNOB_NB, nb if mode != hip.IN_LDSDMA else 0)
