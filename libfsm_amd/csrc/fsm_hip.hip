@@ -42,6 +42,7 @@ struct fsm_hip_dfa {
 	int knob_rows = 0;           /* 0 auto */
 	int knob_seg = 0;            /* 0 auto (128) */
 	int knob_prefetch = -1;      /* -1 auto (on) */
+	int knob_nt = -1;            /* -1 auto */
 	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
@@ -242,7 +243,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 struct LaunchCfg {
-	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch;
+	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch, nt;
 	uint32_t lds;
 };
 
@@ -254,6 +255,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
+	c.nt = d->knob_nt > 0 ? 1 : 0;
 	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
 	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
 	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF ? 0 : 1);
@@ -303,7 +305,10 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 {
 	void (*k)(const WalkArgs) = nullptr;
 	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
-	else if (c.mode == IN_LDSDMA) k = c.seg == 128 ? walk_ldsdma<Pol, 128> : walk_ldsdma<Pol, 64>;
+	else if (c.mode == IN_LDSDMA) {
+		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2> : walk_ldsdma<Pol, 128, 0>;
+		else k = walk_ldsdma<Pol, 64, 0>;
+	}
 	else if (!c.prefetch && c.rows == 1 && c.nb >= 4) {
 		k = c.nb == 4 ? walk_direct_np<Pol, 4> : walk_direct_np<Pol, 8>;
 	} else if (c.rows == 2) {
@@ -525,6 +530,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;
+	case FSM_HIP_KNOB_NT: d->knob_nt = value; break;
 	case FSM_HIP_KNOB_HOT_BYTES:
 		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
 		set_hot_bytes(d, (uint32_t)value);

@@ -422,8 +422,10 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
  * of row i = j*RPI + r, and reader lane i finds piece p of its row in slot (p + rot(i)) mod PIECES,
  * rot(i) = (i >> ROTSH) mod PIECES.  For both SEG values every ds_read_b128 lane group
  * ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-byte slots: conflict-free.
+ * AUX = 2 marks the DMA loads nontemporal: every input line is used exactly once (SEG = 128), so
+ * it need not displace the transition table from L2.
  */
-template <class Pol, int SEG>
+template <class Pol, int SEG, int AUX>
 __global__ void __launch_bounds__(1024)
 walk_ldsdma(const WalkArgs a)
 {
@@ -464,7 +466,7 @@ walk_ldsdma(const WalkArgs a)
 		typename Pol::S st[1] = { pol.init(a) };
 #pragma unroll
 		for (uint32_t j = 0; j < NDMA; j++)
-			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
+			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
 		for (uint32_t s = 0; s < nseg; s++) {
 			__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the tile has landed */
 			__asm__ volatile("" ::: "memory");
@@ -478,7 +480,7 @@ walk_ldsdma(const WalkArgs a)
 #pragma unroll
 				for (uint32_t j = 0; j < NDMA; j++)
 					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * SEG),
-					                                 (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
+					                                 (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
 			}
 #pragma unroll
 			for (uint32_t p = 0; p < PIECES; p++) step16<Pol, 1>(pol, st, w[p]);

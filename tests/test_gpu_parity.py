@@ -85,6 +85,7 @@ def test_fast_paths_every_mode(hip, name):
                 dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                 dfa.tune(hip.KNOB_MASK, mask & 1)
                 dfa.tune(hip.KNOB_PREFETCH, 0 if mask & 2 else 1)
+                dfa.tune(hip.KNOB_NT, early)
                 end, bm = dfa.exec_batch(rows)
                 assert np.array_equal(end, g.end), (name, L, mode, nb, rows_, waves, early, mask)
                 assert np.array_equal(bits(bm, n), g.ret == 1)
