@@ -255,7 +255,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
-	c.nt = d->knob_nt > 0 ? 1 : 0;
+	/* every input line is consumed by exactly one DMA instruction (SEG = 128): nontemporal loads
+	 * measured +7.5 % on the HBM-bound tiny layout (profiles/r01_sweep8*), neutral elsewhere */
+	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : (layout == FSM_HIP_LAYOUT_TINY ? 1 : 0);
 	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
 	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
 	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF ? 0 : 1);
@@ -283,9 +285,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	}
 	const uint32_t per_wave = c.mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : 0u;
 	/* waves per block: as many as LDS allows, 16 at most */
-	/* tiny + LDS-DMA is HBM-bound: small workgroups (4 waves, two per CU) measured best
-	 * (profiles/r01_sweep3*); tables that fill LDS want all 16 waves behind one copy */
-	int waves = d->knob_waves > 0 ? d->knob_waves : (c.mode == IN_LDSDMA && layout == FSM_HIP_LAYOUT_TINY ? 4 : 16);
+	/* 16 waves behind one table copy; with nontemporal DMA loads the 16-wave workgroup (32 KiB
+	 * table + 16 x 8 KiB tiles = all 160 KiB of LDS) measured best for tiny (profiles/r01_sweep8*) */
+	int waves = d->knob_waves > 0 ? d->knob_waves : 16;
 	if (waves > 16) waves = 16;
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves >>= 1;
 	c.waves = waves;
