@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.fsm_hip_flatten.restype = C.POINTER(_Desc)
     lib.fsm_hip_flatten.argtypes = [vp]
     lib.fsm_hip_desc_free.argtypes = [C.POINTER(_Desc)]
+    lib.fsm_hip_desc_read.restype = C.POINTER(_Desc)
     lib.fsm_hip_gen_inputs_device.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint, vp]
     lib.fsm_hip_gen_inputs_host.restype = None
     lib.fsm_hip_gen_inputs_host.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint]
@@ -195,6 +196,37 @@ class FlatDfa:
 
     def endids_of(self, state: int) -> np.ndarray:
         return self.endids[int(self.endid_off[state]):int(self.endid_off[state + 1])]
+
+    def write_c(self, path: str):
+        """fsm_hip_desc_write(): the library's own on-disk form ("FSMHIP01")."""
+        lib = load_library()
+        libc = C.CDLL(None, use_errno=True)
+        libc.fopen.restype = C.c_void_p
+        f = libc.fopen(path.encode(), b"wb")
+        assert f
+        d = self.desc()
+        r = lib.fsm_hip_desc_write(C.byref(d), C.c_void_p(f))
+        libc.fclose(C.c_void_p(f))
+        if r != 0:
+            raise _oserr("fsm_hip_desc_write")
+
+    @classmethod
+    def read_c(cls, path: str) -> "FlatDfa":
+        lib = load_library()
+        libc = C.CDLL(None, use_errno=True)
+        libc.fopen.restype = C.c_void_p
+        f = libc.fopen(path.encode(), b"rb")
+        if not f:
+            raise OSError(C.get_errno(), "fopen")
+        C.set_errno(0)
+        d = lib.fsm_hip_desc_read(C.c_void_p(f))
+        libc.fclose(C.c_void_p(f))
+        if not d:
+            raise _oserr("fsm_hip_desc_read")
+        try:
+            return cls.from_desc(d.contents)
+        finally:
+            lib.fsm_hip_desc_free(d)
 
     def save(self, path: str, **extra):
         np.savez_compressed(path, nstates=np.uint32(self.nstates), start=np.uint32(self.start), edge_off=self.edge_off,
@@ -340,6 +372,29 @@ class HipDfa:
         C.set_errno(0)
         if self._lib.fsm_hip_exec_batch_offsets_device(self._h, d_base, d_off, n, d_end or None, d_bitmap or None, stream or None) != 0:
             raise _oserr("fsm_hip_exec_batch_offsets_device")
+
+    def exec_batch_ids(self, data: np.ndarray, mode: int, lens: Optional[np.ndarray] = None) -> np.ndarray:
+        """Device-side end-id delivery: mode 1 = lowest id (AMBIG_EARLIEST), 2 = index into ret sets."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, stride = data.shape
+        out = np.empty(n, dtype=np.uint32)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_ids(C.c_void_p(self._h), _ptr(data), C.c_size_t(stride), _ptr(lens), C.c_size_t(n),
+                                            C.c_int(mode), _ptr(out)) != 0:
+            raise _oserr("fsm_hip_exec_batch_ids")
+        return out
+
+    def ret_sets(self):
+        """The de-duplicated end-id sets, in retlist order."""
+        self._lib.fsm_hip_ret_count.restype = C.c_size_t
+        out = []
+        for k in range(self._lib.fsm_hip_ret_count(C.c_void_p(self._h))):
+            p, n = C.c_void_p(), C.c_size_t()
+            assert self._lib.fsm_hip_ret_get(C.c_void_p(self._h), C.c_uint32(k), C.byref(p), C.byref(n)) == 0
+            out.append(np.frombuffer((C.c_char * (n.value * 4)).from_address(p.value), dtype=np.uint32).copy() if n.value else np.zeros(0, np.uint32))
+        return out
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.fsm_hip_last_kernel_ms(self._h))

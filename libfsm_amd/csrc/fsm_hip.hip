@@ -30,6 +30,11 @@ struct fsm_hip_dfa {
 	void *d_tab = nullptr;
 	uint32_t *d_fin = nullptr;
 	uint32_t *d_btab = nullptr;
+	/* device end-id delivery (built on first use) */
+	std::vector<uint32_t> fin_host;                 /* copy of the fin table uploaded to d_fin */
+	uint32_t *d_fin_earliest = nullptr, *d_fin_ret = nullptr;
+	std::vector<uint32_t> ret_off, ret_ids;          /* de-duplicated id sets, CSR */
+	bool ids_ready = false;
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -210,6 +215,8 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			goto fail;
 		}
 		HIP_TRY(upload(&d->d_btab, btab));
+		d->fin_host = (p.layout == FSM_HIP_LAYOUT_COMB || p.layout == FSM_HIP_LAYOUT_COMBSELF) ? p.comb_fin
+			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : p.fin;
 		a.tab = d->d_tab;
 		a.fin = d->d_fin;
 		a.btab = d->d_btab;
@@ -233,6 +240,8 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_tab) (void)hipFree(d->d_tab);
 	if (d->d_fin) (void)hipFree(d->d_fin);
 	if (d->d_btab) (void)hipFree(d->d_btab);
+	if (d->d_fin_earliest) (void)hipFree(d->d_fin_earliest);
+	if (d->d_fin_ret) (void)hipFree(d->d_fin_ret);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -783,4 +792,132 @@ fail:
 	if (e0) (void)hipEventDestroy(e0);
 	if (e1) (void)hipEventDestroy(e1);
 	return (double)ms;
+}
+
+/* ------------------------------------------------------------------ */
+/* end-ids delivered by the device                                    */
+/* ------------------------------------------------------------------ */
+
+#include <algorithm>
+#include <map>
+
+/* Build, once, the per-encoded-state tables the kernel copies into id_out[]:
+ *   earliest: lowest end-id of the state (AMBIG_EARLIEST, src/libfsm/print/c.c:67-85)
+ *   ret:      index of the state's id set in the de-duplicated list of sets, ordered by
+ *             count, then lexicographically -- the order build_retlist() produces
+ *             (src/libfsm/vm/retlist.c:93-138, cmp_ret). */
+static int ensure_ids(fsm_hip_dfa *d)
+{
+	if (d->ids_ready) return 0;
+	const Plan &p = d->plan;
+	typedef std::vector<uint32_t> Set;
+	std::vector<Set> sets;
+	/* end states = those appearing in fin */
+	std::vector<uint8_t> is_end(p.nstates, 0);
+	for (uint32_t v : p.fin) if (v != FSM_HIP_NO_MATCH) is_end[v] = 1;
+	for (uint32_t s = 0; s < p.nstates; s++)
+		if (is_end[s]) sets.emplace_back(p.endids.begin() + p.endid_off[s], p.endids.begin() + p.endid_off[s + 1]);
+	std::sort(sets.begin(), sets.end(), [](const Set &a, const Set &b) {
+		if (a.size() != b.size()) return a.size() < b.size();
+		return a < b;
+	});
+	sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
+	std::map<Set, uint32_t> index;
+	d->ret_off.assign(1, 0);
+	d->ret_ids.clear();
+	for (uint32_t k = 0; k < sets.size(); k++) {
+		index[sets[k]] = k;
+		d->ret_ids.insert(d->ret_ids.end(), sets[k].begin(), sets[k].end());
+		d->ret_off.push_back((uint32_t)d->ret_ids.size());
+	}
+	std::vector<uint32_t> fe(d->fin_host.size(), FSM_HIP_NO_MATCH), fr(d->fin_host.size(), FSM_HIP_NO_MATCH);
+	for (size_t i = 0; i < d->fin_host.size(); i++) {
+		const uint32_t s = d->fin_host[i];
+		if (s == FSM_HIP_NO_MATCH) continue;
+		const uint32_t a = p.endid_off[s], b = p.endid_off[s + 1];
+		fe[i] = b > a ? p.endids[a] : FSM_HIP_NO_ID;
+		fr[i] = index[Set(p.endids.begin() + a, p.endids.begin() + b)];
+	}
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	HIP_TRY(upload(&d->d_fin_earliest, fe));
+	HIP_TRY(upload(&d->d_fin_ret, fr));
+	d->ids_ready = true;
+	return 0;
+fail:
+	return -1;
+}
+
+extern "C" int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	int mode, uint32_t *d_id_out, void *hip_stream)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr || d_id_out == nullptr || (mode != FSM_HIP_IDS_EARLIEST && mode != FSM_HIP_IDS_RET) ||
+	    (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (ensure_ids(d) != 0) return -1;
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = stride;
+	a.len = d_len;
+	a.n = n;
+	a.fin2 = mode == FSM_HIP_IDS_EARLIEST ? d->d_fin_earliest : d->d_fin_ret;
+	a.out2 = d_id_out;
+	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int fsm_hip_exec_batch_ids(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	int mode, uint32_t *id_out)
+{
+	if (d == nullptr || id_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (len != nullptr)
+		for (size_t i = 0; i < n; i++)
+			if (len[i] > stride) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	unsigned char *d_in = nullptr;
+	uint32_t *d_len = nullptr, *d_out = nullptr;
+	int rc = -1;
+	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
+	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
+	if (len) {
+		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMalloc((void **)&d_out, n * sizeof(uint32_t)));
+	if (fsm_hip_exec_batch_ids_device(d, d_in, stride, d_len, n, mode, d_out, nullptr) != 0) goto fail;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(id_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	rc = 0;
+fail:
+	{
+		int e = errno;
+		if (d_in) (void)hipFree(d_in);
+		if (d_len) (void)hipFree(d_len);
+		if (d_out) (void)hipFree(d_out);
+		errno = e;
+	}
+	return rc;
+}
+
+extern "C" size_t fsm_hip_ret_count(const struct fsm_hip_dfa *dc)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr || ensure_ids(d) != 0) return 0;
+	return d->ret_off.size() - 1;
+}
+
+extern "C" int fsm_hip_ret_get(const struct fsm_hip_dfa *dc, uint32_t ret_index, const uint32_t **ids, size_t *count)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr || ids == nullptr || count == nullptr || ensure_ids(d) != 0 || ret_index + 1 >= d->ret_off.size()) {
+		errno = EINVAL;
+		return -1;
+	}
+	*ids = d->ret_ids.data() + d->ret_off[ret_index];
+	*count = d->ret_off[ret_index + 1] - d->ret_off[ret_index];
+	return 0;
 }

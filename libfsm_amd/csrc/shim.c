@@ -371,3 +371,135 @@ fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f)
 	free(buf);
 	return r;
 }
+
+/* ---- on-disk form of a flat DFA description -------------------------- */
+/*
+ * Little-endian, self-describing, no pointers:
+ *   char     magic[8] = "FSMHIP01"
+ *   uint32   nstates, start, nranges, nendids
+ *   uint32   edge_off[nstates + 1]
+ *   range    ranges[nranges]            (lo u8, hi u8, reserved u16, to u32)
+ *   uint8    is_end[nstates], zero padded to a multiple of 4
+ *   uint32   endid_off[nstates + 1]
+ *   uint32   endids[nendids]
+ * It serialises what fsm_hip_flatten() extracts from a struct fsm, i.e. the
+ * role the reference's DFAVM save/load has for its bytecode
+ * (fsm_dfavm_save/load, src/libfsm/vm.c:39-71, src/libfsm/vm/v1.c:19-82).
+ */
+static const char desc_magic[8] = { 'F', 'S', 'M', 'H', 'I', 'P', '0', '1' };
+
+int
+fsm_hip_desc_write(const struct fsm_hip_dfa_desc *d, FILE *f)
+{
+	uint32_t hdr[4], n, nr, nid, pad = 0;
+	static const uint32_t zero_off[1] = { 0 };
+
+	if (d == NULL || f == NULL || d->nstates == 0 || d->edge_off == NULL || d->is_end == NULL) {
+		errno = EINVAL;
+		return -1;
+	}
+	n = d->nstates;
+	nr = d->edge_off[n];
+	nid = d->endid_off != NULL ? d->endid_off[n] : 0;
+	hdr[0] = n;
+	hdr[1] = d->start;
+	hdr[2] = nr;
+	hdr[3] = nid;
+	if (fwrite(desc_magic, 1, 8, f) != 8 || fwrite(hdr, 4, 4, f) != 4 ||
+	    fwrite(d->edge_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+	    (nr > 0 && fwrite(d->ranges, sizeof *d->ranges, nr, f) != nr) ||
+	    fwrite(d->is_end, 1, n, f) != n ||
+	    ((n & 3u) != 0 && fwrite(&pad, 1, 4 - (n & 3u), f) != 4 - (n & 3u))) {
+		return -1;
+	}
+	if (d->endid_off != NULL) {
+		if (fwrite(d->endid_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+		    (nid > 0 && fwrite(d->endids, 4, nid, f) != nid)) {
+			return -1;
+		}
+	} else {
+		uint32_t i;
+		for (i = 0; i <= n; i++) {
+			if (fwrite(zero_off, 4, 1, f) != 1) {
+				return -1;
+			}
+		}
+	}
+	return 0;
+}
+
+struct fsm_hip_dfa_desc *
+fsm_hip_desc_read(FILE *f)
+{
+	struct flat *fl = NULL;
+	char magic[8];
+	uint32_t hdr[4], n, nr, nid, s;
+	unsigned char pad[4];
+
+	if (f == NULL) {
+		errno = EINVAL;
+		return NULL;
+	}
+	if (fread(magic, 1, 8, f) != 8 || memcmp(magic, desc_magic, 8) != 0 || fread(hdr, 4, 4, f) != 4) {
+		errno = EINVAL;
+		return NULL;
+	}
+	n = hdr[0];
+	nr = hdr[2];
+	nid = hdr[3];
+	if (n == 0 || n >= 0x00FFFFFFu || hdr[1] >= n) {
+		errno = EINVAL;
+		return NULL;
+	}
+	fl = calloc(1, sizeof *fl);
+	if (fl == NULL) {
+		errno = ENOMEM;
+		return NULL;
+	}
+	fl->edge_off = malloc(((size_t) n + 1) * 4);
+	fl->ranges = malloc(((size_t) nr ? nr : 1) * sizeof *fl->ranges);
+	fl->is_end = malloc(n);
+	fl->endid_off = malloc(((size_t) n + 1) * 4);
+	fl->endids = malloc(((size_t) nid ? nid : 1) * 4);
+	if (fl->edge_off == NULL || fl->ranges == NULL || fl->is_end == NULL || fl->endid_off == NULL || fl->endids == NULL) {
+		fsm_hip_desc_free(&fl->d);
+		errno = ENOMEM;
+		return NULL;
+	}
+	if (fread(fl->edge_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+	    (nr > 0 && fread(fl->ranges, sizeof *fl->ranges, nr, f) != nr) ||
+	    fread(fl->is_end, 1, n, f) != n ||
+	    ((n & 3u) != 0 && fread(pad, 1, 4 - (n & 3u), f) != 4 - (n & 3u)) ||
+	    fread(fl->endid_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+	    (nid > 0 && fread(fl->endids, 4, nid, f) != nid)) {
+		fsm_hip_desc_free(&fl->d);
+		errno = EINVAL; /* truncated */
+		return NULL;
+	}
+	/* structural checks: offsets monotone and consistent with the header */
+	if (fl->edge_off[0] != 0 || fl->edge_off[n] != nr || fl->endid_off[0] != 0 || fl->endid_off[n] != nid) {
+		goto bad;
+	}
+	for (s = 0; s < n; s++) {
+		if (fl->edge_off[s + 1] < fl->edge_off[s] || fl->endid_off[s + 1] < fl->endid_off[s]) {
+			goto bad;
+		}
+	}
+	for (s = 0; s < nr; s++) {
+		if (fl->ranges[s].lo > fl->ranges[s].hi || fl->ranges[s].to >= n) {
+			goto bad;
+		}
+	}
+	fl->d.nstates = n;
+	fl->d.start = hdr[1];
+	fl->d.edge_off = fl->edge_off;
+	fl->d.ranges = fl->ranges;
+	fl->d.is_end = fl->is_end;
+	fl->d.endid_off = fl->endid_off;
+	fl->d.endids = fl->endids;
+	return &fl->d;
+bad:
+	fsm_hip_desc_free(&fl->d);
+	errno = EINVAL;
+	return NULL;
+}

@@ -65,6 +65,8 @@ struct WalkArgs {
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
 	uint32_t        early;    /* retire a wavefront once every lane is absorbing      */
 	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
+	const uint32_t *fin2;     /* optional second per-state table (end-id / ret index) */
+	uint32_t       *out2;     /* n entries, written from fin2, or NULL                */
 };
 
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2 };
@@ -306,8 +308,10 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 __device__ __forceinline__ void write_result(const WalkArgs &a, uint64_t word, uint64_t i, bool valid, uint32_t st)
 {
 	uint32_t end = FSMHIP_NO_MATCH;
-	if (valid) end = a.fin[st / a.fin_div];
+	const uint32_t idx = st / a.fin_div;
+	if (valid) end = a.fin[idx];
 	if (valid && a.end_out != nullptr) a.end_out[i] = end;
+	if (valid && a.out2 != nullptr) a.out2[i] = a.fin2[idx];
 	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
 	if (a.bitmap != nullptr && (threadIdx.x & 63u) == 0 && word * 64u < a.n) a.bitmap[word] = m;
 }

@@ -74,3 +74,28 @@ def test_generator_host_properties(built):
     d = gen_inputs_host(64, 128, 0, 5, None, b"Libfsm", 8)
     for i in range(64):
         assert (b"Libfsm" in bytes(d[i])) or i % 8 != 0
+
+
+def test_on_disk_description_roundtrip(built, tmp_path):
+    """fsm_hip_desc_write / fsm_hip_desc_read ("FSMHIP01") reproduce every golden description
+    exactly, and reject corrupt or truncated files with EINVAL."""
+    import errno as _errno
+    from common import all_golden_paths
+    from libfsm_amd import FlatDfa
+    for k, path in enumerate(all_golden_paths()[::4] + [os.path.join(GOLDEN, "c3.npz")]):
+        flat = Golden(path).flat
+        p = str(tmp_path / f"d{k}.fsmhip")
+        flat.write_c(p)
+        back = FlatDfa.read_c(p)
+        assert (back.nstates, back.start) == (flat.nstates, flat.start)
+        for f in ("edge_off", "is_end", "endid_off", "endids"):
+            assert np.array_equal(getattr(back, f), getattr(flat, f)), f
+        assert np.array_equal(back.ranges, flat.ranges)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"FSMHIP01"
+    for bad in (raw[:len(raw) // 2], b"XXXXXXXX" + raw[8:], raw[:12] + b"\xff\xff\xff\x7f" + raw[16:]):
+        q = str(tmp_path / "bad.fsmhip")
+        open(q, "wb").write(bad)
+        with pytest.raises(OSError) as ei:
+            FlatDfa.read_c(q)
+        assert ei.value.errno == _errno.EINVAL

