@@ -212,6 +212,29 @@ int fsm_hip_desc_write(const struct fsm_hip_dfa_desc *desc, FILE *f);
 struct fsm_hip_dfa_desc *fsm_hip_desc_read(FILE *f);
 
 /* ------------------------------------------------------------------ */
+/* streaming: inputs that arrive in pieces                            */
+/* ------------------------------------------------------------------ */
+
+/* The batched form of fsm_vm_match_file()'s chunk carry (struct vm_state kept
+ * across 4 KiB fread chunks, src/libfsm/vm.c:188-216, src/libfsm/vm/vm.h:177-181):
+ * input i starts from state_io[i] -- FSM_HIP_STATE_START, FSM_HIP_STATE_DEAD
+ * (an earlier piece already hit a missing edge), or a state id of the caller's
+ * fsm returned by a previous call -- consumes its bytes, and state_io[i]
+ * receives the state reached.  end_out / accept_bitmap (optional) say whether
+ * that state is an end state, i.e. what fsm_exec would return if the input
+ * ended here. */
+#define FSM_HIP_STATE_START 0xFFFFFFFDu
+#define FSM_HIP_STATE_DEAD  0xFFFFFFFCu
+
+int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *state_io, uint32_t *end_out);
+
+int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+
+/* ------------------------------------------------------------------ */
 /* end-ids delivered by the device (no host lookup per input)         */
 /* ------------------------------------------------------------------ */
 

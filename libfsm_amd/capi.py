@@ -15,6 +15,9 @@ from typing import Optional, Sequence
 import numpy as np
 
 NO_MATCH = 0xFFFFFFFF
+NO_ID = 0xFFFFFFFE
+STATE_START = 0xFFFFFFFD
+STATE_DEAD = 0xFFFFFFFC
 
 LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF = 0, 1, 2, 3, 4, 5, 6
 LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself"}
@@ -385,6 +388,20 @@ class HipDfa:
                                             C.c_int(mode), _ptr(out)) != 0:
             raise _oserr("fsm_hip_exec_batch_ids")
         return out
+
+    def exec_batch_resume(self, data: np.ndarray, state_io: np.ndarray, lens: Optional[np.ndarray] = None):
+        """Streaming: start row i from state_io[i] (START/DEAD/state id); returns (state_out, end)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, stride = data.shape
+        st = np.ascontiguousarray(state_io, dtype=np.uint32).copy()
+        end = np.empty(n, dtype=np.uint32)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_resume(C.c_void_p(self._h), _ptr(data), C.c_size_t(stride), _ptr(lens), C.c_size_t(n),
+                                               _ptr(st), _ptr(end)) != 0:
+            raise _oserr("fsm_hip_exec_batch_resume")
+        return st, end
 
     def ret_sets(self):
         """The de-duplicated end-id sets, in retlist order."""

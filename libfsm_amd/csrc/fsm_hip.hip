@@ -35,6 +35,10 @@ struct fsm_hip_dfa {
 	uint32_t *d_fin_earliest = nullptr, *d_fin_ret = nullptr;
 	std::vector<uint32_t> ret_off, ret_ids;          /* de-duplicated id sets, CSR */
 	bool ids_ready = false;
+	/* resume tables (built on first use) */
+	uint32_t *d_enc_of = nullptr, *d_orig_of = nullptr;
+	std::vector<uint32_t> enc_host;                  /* [S1] encoded state per renumbered state */
+	bool resume_ready = false;
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -215,6 +219,17 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			goto fail;
 		}
 		HIP_TRY(upload(&d->d_btab, btab));
+		d->enc_host.resize(p.S1);
+		for (uint32_t n2 = 0; n2 < p.S1; n2++) {
+			switch (p.layout) {
+			case FSM_HIP_LAYOUT_TINY: d->enc_host[n2] = n2; break;
+			case FSM_HIP_LAYOUT_LDS: d->enc_host[n2] = n2 * p.row_bytes; break;
+			case FSM_HIP_LAYOUT_COMB:
+			case FSM_HIP_LAYOUT_COMBSELF: d->enc_host[n2] = p.comb_off[n2]; break;
+			case FSM_HIP_LAYOUT_COMB256: d->enc_host[n2] = p.comb256_off[n2]; break;
+			default: d->enc_host[n2] = n2 * p.C * 4u; break;
+			}
+		}
 		d->fin_host = (p.layout == FSM_HIP_LAYOUT_COMB || p.layout == FSM_HIP_LAYOUT_COMBSELF) ? p.comb_fin
 			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : p.fin;
 		a.tab = d->d_tab;
@@ -242,6 +257,8 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_btab) (void)hipFree(d->d_btab);
 	if (d->d_fin_earliest) (void)hipFree(d->d_fin_earliest);
 	if (d->d_fin_ret) (void)hipFree(d->d_fin_ret);
+	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
+	if (d->d_orig_of) (void)hipFree(d->d_orig_of);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -920,4 +937,90 @@ extern "C" int fsm_hip_ret_get(const struct fsm_hip_dfa *dc, uint32_t ret_index,
 	*ids = d->ret_ids.data() + d->ret_off[ret_index];
 	*count = d->ret_off[ret_index + 1] - d->ret_off[ret_index];
 	return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* resume: start every input from a given state, return the state reached */
+/* ------------------------------------------------------------------ */
+
+static int ensure_resume(fsm_hip_dfa *d)
+{
+	if (d->resume_ready) return 0;
+	const Plan &p = d->plan;
+	/* caller id (+ nstates = DEAD) -> encoded state */
+	std::vector<uint32_t> enc(p.nstates + 1);
+	for (uint32_t o = 0; o <= p.nstates; o++) enc[o] = d->enc_host[p.old2new[o]];
+	/* encoded index (as used for fin) -> caller id, DEAD marker for the synthetic state */
+	std::vector<uint32_t> orig(d->fin_host.size(), FSMHIP_STATE_DEAD);
+	for (uint32_t n2 = 0; n2 + 1 < p.S1; n2++) orig[d->enc_host[n2] / d->proto.fin_div] = p.new2old[n2];
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	HIP_TRY(upload(&d->d_enc_of, enc));
+	HIP_TRY(upload(&d->d_orig_of, orig));
+	d->resume_ready = true;
+	return 0;
+fail:
+	return -1;
+}
+
+extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (ensure_resume(d) != 0) return -1;
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = stride;
+	a.len = d_len;
+	a.n = n;
+	a.end_out = d_end_out;
+	a.bitmap = d_accept_bitmap;
+	a.state_io = d_state_io;
+	a.enc_of = d->d_enc_of;
+	a.orig_of = d->d_orig_of;
+	a.nstates = d->plan.nstates;
+	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *state_io, uint32_t *end_out)
+{
+	if (d == nullptr || state_io == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (len != nullptr)
+		for (size_t i = 0; i < n; i++)
+			if (len[i] > stride) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	unsigned char *d_in = nullptr;
+	uint32_t *d_len = nullptr, *d_st = nullptr, *d_end = nullptr;
+	int rc = -1;
+	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
+	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
+	if (len) {
+		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMalloc((void **)&d_st, n * sizeof(uint32_t)));
+	HIP_TRY(hipMemcpy(d_st, state_io, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
+	if (fsm_hip_exec_batch_resume_device(d, d_in, stride, d_len, n, d_st, d_end, nullptr, nullptr) != 0) goto fail;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(state_io, d_st, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	rc = 0;
+fail:
+	{
+		int e = errno;
+		if (d_in) (void)hipFree(d_in);
+		if (d_len) (void)hipFree(d_len);
+		if (d_st) (void)hipFree(d_st);
+		if (d_end) (void)hipFree(d_end);
+		errno = e;
+	}
+	return rc;
 }

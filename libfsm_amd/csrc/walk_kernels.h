@@ -67,7 +67,26 @@ struct WalkArgs {
 	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
 	const uint32_t *fin2;     /* optional second per-state table (end-id / ret index) */
 	uint32_t       *out2;     /* n entries, written from fin2, or NULL                */
+	/* resume (streaming): state_io[i] = caller's state id to start from (or START / DEAD), and
+	 * receives the state reached; enc_of[nstates+1] maps caller ids (+DEAD) to encoded states,
+	 * orig_of[] (indexed like fin) maps back. */
+	uint32_t       *state_io;
+	const uint32_t *enc_of;
+	const uint32_t *orig_of;
+	uint32_t        nstates;
 };
+
+#define FSMHIP_STATE_START 0xFFFFFFFDu
+#define FSMHIP_STATE_DEAD  0xFFFFFFFCu
+
+/* encoded state input i starts from */
+__device__ __forceinline__ uint32_t start_code(const WalkArgs &a, uint64_t i, bool valid)
+{
+	if (a.state_io == nullptr || !valid) return a.start;
+	const uint32_t sid = a.state_io[i];
+	if (sid == FSMHIP_STATE_START) return a.start;
+	return a.enc_of[sid == FSMHIP_STATE_DEAD || sid >= a.nstates ? a.nstates : sid];
+}
 
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2 };
 
@@ -90,7 +109,7 @@ template <class W>
 struct TinyPol {
 	typedef W P;
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
@@ -133,7 +152,7 @@ template <bool MASK>
 struct LdsPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 2      */
 	const unsigned char *tab;  /* LDS table; state is a byte offset into it      */
@@ -162,7 +181,7 @@ template <bool MASK>
 struct CombPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
@@ -189,7 +208,7 @@ template <bool MASK>
 struct Comb256Pol {
 	typedef uint32_t P;
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte */
 	uint32_t abs_min, dflt;
@@ -228,7 +247,6 @@ struct CombSelfPol {
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
 	const uint32_t *smask;  /* LDS, indexed by row offset: self-loop mask of that state */
-	uint32_t start_sm;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
@@ -237,9 +255,8 @@ struct CombSelfPol {
 		copy_table(lds + FSMHIP_BTAB_BYTES, a); /* image = comb[n] followed by smask[n] */
 		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
 		smask = comb + a.tab_bytes / 8u;
-		start_sm = static_cast<const uint32_t *>(a.tab)[a.tab_bytes / 8u + a.start];
 	}
-	__device__ __forceinline__ S init(const WalkArgs &a) const { S s = { a.start, start_sm }; return s; }
+	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask[code] }; return s; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
 	__device__ __forceinline__ S next(S s, P be) const
@@ -258,7 +275,7 @@ template <bool MASK>
 struct GlobPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(const WalkArgs &a) const { return a.start; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4                */
 	const unsigned char *tab;  /* device table; state is a byte offset into it             */
@@ -312,6 +329,7 @@ __device__ __forceinline__ void write_result(const WalkArgs &a, uint64_t word, u
 	if (valid) end = a.fin[idx];
 	if (valid && a.end_out != nullptr) a.end_out[i] = end;
 	if (valid && a.out2 != nullptr) a.out2[i] = a.fin2[idx];
+	if (valid && a.state_io != nullptr) a.state_io[i] = a.orig_of[idx];
 	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
 	if (a.bitmap != nullptr && (threadIdx.x & 63u) == 0 && word * 64u < a.n) a.bitmap[word] = m;
 }
@@ -343,7 +361,7 @@ walk_direct(const WalkArgs a)
 		for (int r = 0; r < ROWS; r++) {
 			i[r] = (tile * ROWS + r) * 64u + lane;
 			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
-			st[r] = pol.init(a);
+			st[r] = pol.init(start_code(a, i[r], i[r] < a.n));
 		}
 #pragma unroll
 		for (int j = 0; j < NB; j++)
@@ -393,7 +411,7 @@ walk_direct_np(const WalkArgs a)
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
 		const uint64_t i = tile * 64u + lane;
 		const u32x4 *q = reinterpret_cast<const u32x4 *>(a.base + (i < a.n ? i : a.n - 1) * a.stride);
-		typename Pol::S st[1] = { pol.init(a) };
+		typename Pol::S st[1] = { pol.init(start_code(a, i, i < a.n)) };
 		for (uint32_t g = 0; g < ngroups; g++) {
 			u32x4 cur[NB][1];
 #pragma unroll
@@ -467,7 +485,7 @@ walk_ldsdma(const WalkArgs a)
 			const uint32_t piece = (lq - ((ri >> ROTSH) & (PIECES - 1u))) & (PIECES - 1u);
 			src[j] = a.base + row * a.stride + piece * 16u;
 		}
-		typename Pol::S st[1] = { pol.init(a) };
+		typename Pol::S st[1] = { pol.init(start_code(a, i, valid)) };
 #pragma unroll
 		for (uint32_t j = 0; j < NDMA; j++)
 			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
@@ -529,7 +547,7 @@ walk_generic(const WalkArgs a)
 		const uint32_t head = (uint32_t)(p0 - q0);
 		const uint64_t span = len ? head + len : 0;
 		const uint64_t nchunks = (span + 15u) / 16u;
-		typename Pol::S st = pol.init(a);
+		typename Pol::S st = pol.init(start_code(a, i, valid));
 		for (uint64_t c = 0; __any(c < nchunks); c++) {
 			if (c < nchunks) {
 				const u32x4 w = *reinterpret_cast<const u32x4 *>(q0 + c * 16u);

@@ -312,3 +312,40 @@ oracle_endid_get(const struct oracle_dfa *d, uint32_t state, size_t n, uint32_t 
 	}
 	return 1;
 }
+
+/*
+ * Streaming form: start from state_io[i] (0xFFFFFFFD = start state, 0xFFFFFFFC = already dead),
+ * consume the bytes, leave the state reached (or 0xFFFFFFFC after a missing edge) in state_io[i].
+ * This is fsm_exec's loop (exec.c:132-151) with the state exposed, the way fsm_vm_match_file
+ * carries struct vm_state across chunks (vm.c:188-216).
+ */
+void
+oracle_state_walk_stride(const struct oracle_dfa *d, const unsigned char *base, size_t stride,
+	const uint32_t *len, size_t n, uint32_t *state_io)
+{
+	size_t i;
+	for (i = 0; i < n; i++) {
+		const unsigned char *p = base + i * stride;
+		size_t l = len ? len[i] : stride, t;
+		uint32_t st = state_io[i];
+		if (st == 0xFFFFFFFDu) {
+			st = d->start;
+		}
+		if (st == 0xFFFFFFFCu) {
+			continue;
+		}
+		for (t = 0; t < l; t++) {
+			if (!edge_set_transition(&d->states[st], p[t], &st)) {
+				st = 0xFFFFFFFCu;
+				break;
+			}
+		}
+		state_io[i] = st;
+	}
+}
+
+int
+oracle_isend(const struct oracle_dfa *d, uint32_t state)
+{
+	return state < d->statecount && d->states[state].end;
+}

@@ -65,6 +65,9 @@ class Oracle:
             L.oracle_exec_batch_stride.argtypes = [vp, vp, sz, vp, sz, vp, vp]
             L.oracle_table_walk_stride.restype = C.c_double
             L.oracle_table_walk_stride.argtypes = [vp, vp, sz, vp, sz, vp]
+            L.oracle_state_walk_stride.restype = None
+            L.oracle_state_walk_stride.argtypes = [vp, vp, sz, vp, sz, vp]
+            L.oracle_isend.argtypes = [vp, C.c_uint32]
             L.oracle_endid_count.restype = sz
             L.oracle_endid_count.argtypes = [vp, C.c_uint32]
             L.oracle_endid_get.argtypes = [vp, C.c_uint32, sz, vp]
@@ -125,6 +128,19 @@ class Oracle:
         if self.last_seconds < 0:
             raise RuntimeError("oracle_table_walk_stride")
         return end
+
+    def state_walk(self, data: np.ndarray, state_io: np.ndarray, lens=None) -> np.ndarray:
+        """Streaming walk: returns the states reached (0xFFFFFFFC = dead)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        st = np.ascontiguousarray(state_io, np.uint32).copy()
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, np.uint32)
+        self.lib().oracle_state_walk_stride(self._h, _p(data) if data.size else None, stride, _p(lens), n, _p(st))
+        return st
+
+    def isend(self, state: int) -> bool:
+        return bool(self.lib().oracle_isend(self._h, int(state)))
 
     def endids(self, state: int) -> np.ndarray:
         n = self.lib().oracle_endid_count(self._h, state)

@@ -439,3 +439,33 @@ def test_device_side_endids(hip):
                     assert np.array_equal(sets[int(e2[i])], want)
             dfa.close()
     assert any(len(s) > 1 for s in sets) or True
+
+
+def test_streaming_resume_in_pieces(hip):
+    """inputs fed in pieces with the state carried between calls (the batched form of
+    fsm_vm_match_file's chunk carry) end in the same state as one whole walk; every intermediate
+    state equals the oracle's."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(8)
+    for name in ("c1.npz", "c3.npz"):
+        g = Golden(os.path.join(GOLDEN, name))
+        rows = g.rows
+        n, L = rows.shape
+        o = Oracle(g.flat)
+        cuts = [0, 64, 64 + 37, L // 2, L // 2 + 128, L - 5, L]     # 16-aligned and odd piece sizes
+        for Ly, dfa in layouts_for(hip, g.flat):
+            st = np.full(n, hip.STATE_START, np.uint32)
+            ost = st.copy()
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                piece = np.ascontiguousarray(rows[:, a:b])
+                st, end = dfa.exec_batch_resume(piece, st)
+                ost = o.state_walk(piece, ost)
+                assert np.array_equal(st, ost), (name, Ly, a, b)
+                want_end = np.array([s if (s < g.flat.nstates and g.flat.is_end[s]) else NO for s in ost], np.uint32)
+                assert np.array_equal(end, want_end)
+            assert np.array_equal(end, g.end), (name, Ly)
+            # ragged pieces: every row advances by its own length
+            lens = rng.randint(0, 65, n).astype(np.uint32)
+            st2, _ = dfa.exec_batch_resume(np.ascontiguousarray(rows[:, :64]), np.full(n, hip.STATE_START, np.uint32), lens)
+            assert np.array_equal(st2, o.state_walk(np.ascontiguousarray(rows[:, :64]), np.full(n, hip.STATE_START, np.uint32), lens))
+            dfa.close()
