@@ -547,20 +547,33 @@ walk_generic(const WalkArgs a)
 		const uint32_t head = (uint32_t)(p0 - q0);
 		const uint64_t span = len ? head + len : 0;
 		const uint64_t nchunks = (span + 15u) / 16u;
-		typename Pol::S st = pol.init(start_code(a, i, valid));
+		typename Pol::S st[1] = { pol.init(start_code(a, i, valid)) };
+		u32x4 w[1] = { {0u, 0u, 0u, 0u} };
+		if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
 		for (uint64_t c = 0; __any(c < nchunks); c++) {
 			if (c < nchunks) {
-				const u32x4 w = *reinterpret_cast<const u32x4 *>(q0 + c * 16u);
+				u32x4 wn = {0u, 0u, 0u, 0u};
+				if (c + 1 < nchunks) wn = *reinterpret_cast<const u32x4 *>(q0 + (c + 1) * 16u); /* next chunk in flight */
+				/* valid bytes of this chunk: [lo, hi) */
+				const uint32_t lo = c == 0 ? head : 0u;
+				const uint64_t left = span - c * 16u;
+				const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
+				if (__all(lo == 0u && hi == 16u)) {
+					/* every lane still walking has a whole chunk: no per-byte predicate */
+					step16<Pol, 1>(pol, st, w);
+				} else {
+					const uint32_t cnt = hi - lo;
 #pragma unroll
-				for (int k = 0; k < 16; k++) {
-					const uint64_t pos = c * 16u + k - head; /* wraps below head: huge, fails the test */
-					const typename Pol::S nx = pol.next(st, pol.pre(byte_of(w, k)));
-					st = pos < len ? nx : st;
+					for (int k = 0; k < 16; k++) {
+						const typename Pol::S nx = pol.next(st[0], pol.pre(byte_of(w[0], k)));
+						st[0] = ((uint32_t)k - lo) < cnt ? nx : st[0]; /* k < lo wraps: fails the test */
+					}
 				}
+				w[0] = wn;
 			}
-			if (a.early && __all(Pol::code(st) >= a.abs_min || c + 1 >= nchunks)) break;
+			if (a.early && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
-		write_result(a, tile, i, valid, Pol::code(st));
+		write_result(a, tile, i, valid, Pol::code(st[0]));
 	}
 }
 

@@ -8,7 +8,7 @@
  * Parity pinning: this restatement is checked (tests/test_oracle.py) against
  *   - the reference's own retest fixtures tests/retest/*.tst (37 regexes,
  *     115 +/- cases) and the endids / re_strings known-answer programs,
- *     frozen as tests/golden/*.json + *.fdfa by tests/golden/make_golden.py
+ *     frozen as tests/golden/**.npz by tests/golden/make_golden.py
  *     from outputs of the REAL reference fsm_exec (oracle/_ref), and
  *   - live, against oracle/_ref's fsm_exec on seeded random inputs.
  *
