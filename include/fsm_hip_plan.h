@@ -35,8 +35,8 @@ int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
 struct fsm_hip_plan;
 
 enum {
-	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[11]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off,
-	                              *          comb256_abs_min_off,comb256_dflt */
+	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[13]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off,
+	                              *          comb256_abs_min_off,comb256_dflt,eager_lo_end,eager_hi_begin */
 	FSM_HIP_PLAN_CLS       = 1,  /* u8[256]  */
 	FSM_HIP_PLAN_NEW2OLD   = 2,  /* u32[S1]  */
 	FSM_HIP_PLAN_FIN       = 3,  /* u32[S1]  */
@@ -51,7 +51,9 @@ enum {
 	FSM_HIP_PLAN_COMB256     = 12, /* u32[] */
 	FSM_HIP_PLAN_COMB256_OFF = 13, /* u32[S1] */
 	FSM_HIP_PLAN_COMB256_FIN = 14, /* u32[] */
-	FSM_HIP_PLAN_COMB_SMASK  = 15  /* u32[] by comb row offset */
+	FSM_HIP_PLAN_COMB_SMASK  = 15, /* u32[] by comb row offset */
+	FSM_HIP_PLAN_EMASK       = 16, /* u64[S1] eager-output masks by renumbered state (empty: none) */
+	FSM_HIP_PLAN_EAGER_IDS   = 17  /* u32[K] ids in ascending order: bit k of a mask */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

@@ -42,6 +42,8 @@ class _Desc(C.Structure):
         ("is_end", C.c_void_p),
         ("endid_off", C.c_void_p),
         ("endids", C.c_void_p),
+        ("eager_off", C.c_void_p),
+        ("eager_ids", C.c_void_p),
     ]
 
 
@@ -127,8 +129,15 @@ class FlatDfa:
     is_end: np.ndarray  # u8 [nstates]
     endid_off: np.ndarray  # u32 [nstates+1]
     endids: np.ndarray  # u32 []
+    eager_off: Optional[np.ndarray] = None  # u32 [nstates+1] or None (no eager outputs)
+    eager_ids: Optional[np.ndarray] = None  # u32 []
 
     def __post_init__(self):
+        if self.eager_off is not None:
+            self.eager_off = np.ascontiguousarray(self.eager_off, dtype=np.uint32)
+            self.eager_ids = np.ascontiguousarray(self.eager_ids if self.eager_ids is not None else [], dtype=np.uint32)
+            if int(self.eager_off[-1]) == 0:
+                self.eager_off = self.eager_ids = None
         self.edge_off = np.ascontiguousarray(self.edge_off, dtype=np.uint32)
         self.ranges = np.ascontiguousarray(self.ranges, dtype=RANGE_DTYPE)
         self.is_end = np.ascontiguousarray(self.is_end, dtype=np.uint8)
@@ -143,6 +152,8 @@ class FlatDfa:
         d.is_end = self.is_end.ctypes.data
         d.endid_off = self.endid_off.ctypes.data
         d.endids = self.endids.ctypes.data if len(self.endids) else None
+        d.eager_off = self.eager_off.ctypes.data if self.eager_off is not None else None
+        d.eager_ids = self.eager_ids.ctypes.data if self.eager_off is not None and len(self.eager_ids) else None
         return d
 
     @classmethod
@@ -157,8 +168,10 @@ class FlatDfa:
 
         edge_off = arr(d.edge_off, n + 1, np.uint32)
         endid_off = arr(d.endid_off, n + 1, np.uint32) if d.endid_off else np.zeros(n + 1, np.uint32)
+        eo = arr(d.eager_off, n + 1, np.uint32) if d.eager_off else None
         return cls(n, d.start, edge_off, arr(d.ranges, int(edge_off[n]), RANGE_DTYPE), arr(d.is_end, n, np.uint8),
-                   endid_off, arr(d.endids, int(endid_off[n]), np.uint32))
+                   endid_off, arr(d.endids, int(endid_off[n]), np.uint32),
+                   eo, arr(d.eager_ids, int(eo[n]), np.uint32) if eo is not None else None)
 
     @classmethod
     def from_dense(cls, next_tab: np.ndarray, start: int, is_end: Sequence[int], endids=None) -> "FlatDfa":
@@ -234,14 +247,21 @@ class FlatDfa:
     def save(self, path: str, **extra):
         np.savez_compressed(path, nstates=np.uint32(self.nstates), start=np.uint32(self.start), edge_off=self.edge_off,
                             r_lo=self.ranges["lo"], r_hi=self.ranges["hi"], r_to=self.ranges["to"], is_end=self.is_end,
-                            endid_off=self.endid_off, endids=self.endids, **extra)
+                            endid_off=self.endid_off, endids=self.endids,
+                            **({"eager_off": self.eager_off, "eager_ids": self.eager_ids} if self.eager_off is not None else {}), **extra)
 
     @classmethod
     def load(cls, path_or_npz) -> "FlatDfa":
         z = np.load(path_or_npz) if isinstance(path_or_npz, (str, os.PathLike)) else path_or_npz
         r = np.zeros(len(z["r_lo"]), dtype=RANGE_DTYPE)
         r["lo"], r["hi"], r["to"] = z["r_lo"], z["r_hi"], z["r_to"]
-        return cls(int(z["nstates"]), int(z["start"]), z["edge_off"], r, z["is_end"], z["endid_off"], z["endids"])
+        return cls(int(z["nstates"]), int(z["start"]), z["edge_off"], r, z["is_end"], z["endid_off"], z["endids"],
+                   z["eager_off"] if "eager_off" in z else None, z["eager_ids"] if "eager_ids" in z else None)
+
+    def eager_of(self, state: int) -> np.ndarray:
+        if self.eager_off is None:
+            return np.zeros(0, np.uint32)
+        return self.eager_ids[int(self.eager_off[state]):int(self.eager_off[state + 1])]
 
 
 class Plan:
@@ -250,7 +270,8 @@ class Plan:
     _WHAT = dict(scalars=(0, np.uint32), cls=(1, np.uint8), new2old=(2, np.uint32), fin=(3, np.uint32),
                  dense=(4, np.uint32), tiny_col=(5, np.uint64), lds_tab=(6, np.uint16), comb=(7, np.uint32),
                  comb_dflt=(8, np.uint32), comb_off=(9, np.uint32), comb_fin=(10, np.uint32), glob_tab=(11, np.uint32),
-                 comb256=(12, np.uint32), comb256_off=(13, np.uint32), comb256_fin=(14, np.uint32), comb_smask=(15, np.uint32))
+                 comb256=(12, np.uint32), comb256_off=(13, np.uint32), comb256_fin=(14, np.uint32), comb_smask=(15, np.uint32),
+                 emask=(16, np.uint64), eager_ids=(17, np.uint32))
 
     def __init__(self, flat: FlatDfa, flags: int = 0, lds_limit: int = 0):
         lib = load_library()
@@ -262,7 +283,8 @@ class Plan:
         self._lib = lib
         s = self.get("scalars")
         (self.nstates, self.S1, self.start, self.C, self.abs_min, self.nabsorbing, self.layout, self.row_bytes,
-         self.comb_abs_min_off, self.comb256_abs_min_off, self.comb256_dflt) = (int(x) for x in s)
+         self.comb_abs_min_off, self.comb256_abs_min_off, self.comb256_dflt, self.eager_lo_end,
+         self.eager_hi_begin) = (int(x) for x in s)
 
     def get(self, what: str) -> np.ndarray:
         w, dt = self._WHAT[what]
@@ -402,6 +424,25 @@ class HipDfa:
                                                _ptr(st), _ptr(end)) != 0:
             raise _oserr("fsm_hip_exec_batch_resume")
         return st, end
+
+    def exec_batch_eager(self, data: np.ndarray, lens: Optional[np.ndarray] = None):
+        """Walk + eager outputs: returns (end u32[n], list of emitted-id arrays per input)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, stride = data.shape
+        end = np.empty(n, dtype=np.uint32)
+        eo = np.zeros(n, dtype=np.uint64)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_eager(C.c_void_p(self._h), _ptr(data), C.c_size_t(stride), _ptr(lens), C.c_size_t(n),
+                                              _ptr(end), _ptr(eo)) != 0:
+            raise _oserr("fsm_hip_exec_batch_eager")
+        self._lib.fsm_hip_eager_id_count.restype = C.c_size_t
+        self._lib.fsm_hip_eager_id.restype = C.c_uint32
+        k = self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h))
+        ids = np.array([self._lib.fsm_hip_eager_id(C.c_void_p(self._h), C.c_uint(b)) for b in range(k)], np.uint32)
+        sets = [ids[[b for b in range(k) if (int(m) >> b) & 1]] for m in eo]
+        return end, sets
 
     def ret_sets(self):
         """The de-duplicated end-id sets, in retlist order."""

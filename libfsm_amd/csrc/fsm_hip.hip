@@ -39,6 +39,7 @@ struct fsm_hip_dfa {
 	uint32_t *d_enc_of = nullptr, *d_orig_of = nullptr;
 	std::vector<uint32_t> enc_host;                  /* [S1] encoded state per renumbered state */
 	bool resume_ready = false;
+	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -232,6 +233,15 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		}
 		d->fin_host = (p.layout == FSM_HIP_LAYOUT_COMB || p.layout == FSM_HIP_LAYOUT_COMBSELF) ? p.comb_fin
 			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : p.fin;
+		if (!p.emask.empty()) {
+			/* eager masks indexed like fin; thresholds in encoded-state units */
+			std::vector<uint64_t> em(d->fin_host.size(), 0);
+			for (uint32_t n2 = 0; n2 < p.S1; n2++) em[d->enc_host[n2] / a.fin_div] = p.emask[n2];
+			HIP_TRY(upload(&d->d_emask, em));
+			a.emask = d->d_emask;
+			a.eager_lo_end = p.eager_lo_end < p.S1 ? d->enc_host[p.eager_lo_end] : 0xFFFFFFFFu;
+			a.eager_hi_begin = p.eager_hi_begin < p.S1 ? d->enc_host[p.eager_hi_begin] : 0xFFFFFFFFu;
+		}
 		a.tab = d->d_tab;
 		a.fin = d->d_fin;
 		a.btab = d->d_btab;
@@ -259,6 +269,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_fin_ret) (void)hipFree(d->d_fin_ret);
 	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
 	if (d->d_orig_of) (void)hipFree(d->d_orig_of);
+	if (d->d_emask) (void)hipFree(d->d_emask);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -359,6 +370,20 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	return hipGetLastError();
 }
 
+/* eager-output walks: the policy wrapped in EagerPol, two kernels only (per-lane loads with four
+ * chunks in flight, or the generic one) */
+template <class Pol>
+static hipError_t launch_eager(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	void (*k)(const WalkArgs) = nullptr;
+	if (c.mode == IN_GENERIC) k = walk_generic<EagerPol<Pol>>;
+	else k = walk_direct<EagerPol<Pol>, 4, 1>;
+	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
+	return hipGetLastError();
+}
+
 template <template <bool> class PolT>
 static hipError_t launch_masked(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
@@ -368,7 +393,15 @@ static hipError_t launch_masked(const LaunchCfg &c, const WalkArgs &a, dim3 grid
 static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s)
 {
 	if (a.n == 0) return 0;
+	const bool eager = a.eager_out != nullptr;
+	if (eager && (a.stride / 16u) % 4u != 0) fast_ok = false;
 	LaunchCfg c = pick_cfg(d, fast_ok, a.stride);
+	if (eager && c.mode != IN_GENERIC) {
+		/* the one fast eager kernel: per-lane loads, NB = 4, no LDS staging */
+		c.mode = IN_DIRECT; c.nb = 4; c.rows = 1;
+		c.waves = d->knob_waves > 0 && d->knob_waves <= 16 ? d->knob_waves : 16;
+		c.lds = d->table_lds;
+	}
 	const uint64_t ntiles = (a.n + 64u * c.rows - 1) / (64u * c.rows);
 	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
@@ -378,6 +411,16 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	hipError_t e = hipEventRecord(md->ev0, s);
 	if (e == hipSuccess) {
 		dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
+		if (eager) {
+			switch (d->plan.layout) {
+			case FSM_HIP_LAYOUT_TINY:
+				e = d->plan.S1 <= 8 ? launch_eager<TinyPol<uint32_t>>(c, a, grid, block, s)
+				                    : launch_eager<TinyPol<uint64_t>>(c, a, grid, block, s);
+				break;
+			case FSM_HIP_LAYOUT_LDS: e = launch_eager<LdsPol<false>>(c, a, grid, block, s); break;
+			default:                 e = launch_eager<GlobPol<false>>(c, a, grid, block, s); break;
+			}
+		} else
 		switch (d->plan.layout) {
 		case FSM_HIP_LAYOUT_TINY:
 			e = d->plan.S1 <= 8 ? launch_pol<TinyPol<uint32_t>>(c, a, grid, block, s)
@@ -614,7 +657,8 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 		scalars[0] = p.nstates; scalars[1] = p.S1; scalars[2] = p.start; scalars[3] = p.C;
 		scalars[4] = p.abs_min; scalars[5] = p.nabsorbing; scalars[6] = p.layout; scalars[7] = p.row_bytes;
 		scalars[8] = p.comb_abs_min_off; scalars[9] = p.comb256_abs_min_off; scalars[10] = p.comb256_dflt;
-		*data = scalars; *count = 11; return 0;
+		scalars[11] = p.eager_lo_end; scalars[12] = p.eager_hi_begin;
+		*data = scalars; *count = 13; return 0;
 	case FSM_HIP_PLAN_CLS: *data = p.cls; *count = 256; return 0;
 	case FSM_HIP_PLAN_NEW2OLD: *data = p.new2old.data(); *count = p.new2old.size(); return 0;
 	case FSM_HIP_PLAN_FIN: *data = p.fin.data(); *count = p.fin.size(); return 0;
@@ -630,6 +674,8 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;
 	case FSM_HIP_PLAN_COMB_SMASK: *data = p.comb_smask.data(); *count = p.comb_smask.size(); return 0;
+	case FSM_HIP_PLAN_EMASK: *data = p.emask.data(); *count = p.emask.size(); return 0;
+	case FSM_HIP_PLAN_EAGER_IDS: *data = p.eager_ids.data(); *count = p.eager_ids.size(); return 0;
 	default: errno = EINVAL; return -1;
 	}
 }
@@ -1020,6 +1066,84 @@ fail:
 		if (d_len) (void)hipFree(d_len);
 		if (d_st) (void)hipFree(d_st);
 		if (d_end) (void)hipFree(d_end);
+		errno = e;
+	}
+	return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* eager outputs                                                      */
+/* ------------------------------------------------------------------ */
+
+extern "C" size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *d)
+{
+	return d == nullptr ? 0 : d->plan.eager_ids.size();
+}
+
+extern "C" uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *d, unsigned bit)
+{
+	if (d == nullptr || bit >= d->plan.eager_ids.size()) return FSM_HIP_NO_MATCH;
+	return d->plan.eager_ids[bit];
+}
+
+extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	if (d == nullptr || d_eager_out == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	if (d->plan.emask.empty()) {
+		/* no state emits anything: the answer is all zeros, the walk is the plain one */
+		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
+		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+		return fsm_hip_exec_batch_device(d, d_base, stride, d_len, n, d_end_out, nullptr, hip_stream);
+	}
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = stride;
+	a.len = d_len;
+	a.n = n;
+	a.end_out = d_end_out;
+	a.eager_out = d_eager_out;
+	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *eager_out)
+{
+	if (d == nullptr || eager_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (len != nullptr)
+		for (size_t i = 0; i < n; i++)
+			if (len[i] > stride) { errno = EINVAL; return -1; }
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	unsigned char *d_in = nullptr;
+	uint32_t *d_len = nullptr, *d_end = nullptr;
+	uint64_t *d_eo = nullptr;
+	int rc = -1;
+	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
+	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
+	if (len) {
+		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **)&d_eo, n * sizeof(uint64_t)));
+	if (fsm_hip_exec_batch_eager_device(d, d_in, stride, d_len, n, d_end, d_eo, nullptr) != 0) goto fail;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(eager_out, d_eo, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	rc = 0;
+fail:
+	{
+		int e = errno;
+		if (d_in) (void)hipFree(d_in);
+		if (d_len) (void)hipFree(d_len);
+		if (d_end) (void)hipFree(d_end);
+		if (d_eo) (void)hipFree(d_eo);
 		errno = e;
 	}
 	return rc;

@@ -100,6 +100,25 @@ try {
 	uint8_t rep[256]; /* representative byte per class */
 	for (int c = 255; c >= 0; c--) rep[p.cls[c]] = (uint8_t)c;
 
+	/* eager outputs: id -> bit, per original state a mask */
+	std::vector<uint64_t> emask_old(S1, 0);
+	p.eager_ids.clear();
+	if (d->eager_off != nullptr && d->eager_off[S] > 0) {
+		if (d->eager_ids == nullptr) return EINVAL;
+		p.eager_ids.assign(d->eager_ids, d->eager_ids + d->eager_off[S]);
+		std::sort(p.eager_ids.begin(), p.eager_ids.end());
+		p.eager_ids.erase(std::unique(p.eager_ids.begin(), p.eager_ids.end()), p.eager_ids.end());
+		if (p.eager_ids.size() > 64) return ENOTSUP;
+		for (uint32_t s = 0; s < S; s++) {
+			if (d->eager_off[s + 1] < d->eager_off[s]) return EINVAL;
+			for (uint32_t k = d->eager_off[s]; k < d->eager_off[s + 1]; k++) {
+				size_t bit = std::lower_bound(p.eager_ids.begin(), p.eager_ids.end(), d->eager_ids[k]) - p.eager_ids.begin();
+				emask_old[s] |= (uint64_t)1 << bit;
+			}
+		}
+	}
+	const bool has_eager = !p.eager_ids.empty();
+
 	/* 4: renumber */
 	std::vector<uint8_t> absorbing(S1, 0);
 	for (uint32_t s = 0; s < S1; s++) {
@@ -127,10 +146,15 @@ try {
 		}
 		for (uint32_t s = 0; s < S; s++) if (!vis[s]) q.push_back(s); /* unreachable */
 		if (!vis[DEAD]) q.push_back(DEAD);
-		/* non-absorbing first (BFS order), absorbing after, DEAD last */
-		for (uint32_t s : q) if (!absorbing[s]) p.new2old.push_back(s);
+		/* non-absorbing first (BFS order; those with eager outputs ahead of the rest),
+		 * absorbing after (those with eager outputs last), DEAD very last */
+		for (uint32_t s : q) if (!absorbing[s] && emask_old[s] != 0) p.new2old.push_back(s);
+		p.eager_lo_end = (uint32_t)p.new2old.size();
+		for (uint32_t s : q) if (!absorbing[s] && emask_old[s] == 0) p.new2old.push_back(s);
 		p.abs_min = (uint32_t)p.new2old.size();
-		for (uint32_t s : q) if (absorbing[s] && s != DEAD) p.new2old.push_back(s);
+		for (uint32_t s : q) if (absorbing[s] && s != DEAD && emask_old[s] == 0) p.new2old.push_back(s);
+		p.eager_hi_begin = (uint32_t)p.new2old.size();
+		for (uint32_t s : q) if (absorbing[s] && s != DEAD && emask_old[s] != 0) p.new2old.push_back(s);
 		p.new2old.push_back(DEAD);
 		p.nabsorbing = S1 - p.abs_min;
 	}
@@ -140,6 +164,14 @@ try {
 	for (uint32_t n = 0; n + 1 < S1; n++) {
 		uint32_t o = p.new2old[n];
 		if (d->is_end[o]) p.fin[n] = o;
+	}
+	p.emask.clear();
+	if (has_eager) {
+		p.emask.assign(S1, 0);
+		for (uint32_t n = 0; n + 1 < S1; n++) p.emask[n] = emask_old[p.new2old[n]];
+	} else {
+		p.eager_lo_end = 0;
+		p.eager_hi_begin = 0xFFFFFFFFu;
 	}
 	p.new2old[S1 - 1] = FSM_HIP_NO_MATCH;
 	p.dense.assign((size_t)S1 * C, 0);
@@ -198,6 +230,7 @@ try {
 		return 0;
 	};
 	auto emit_comb = [&]() -> int {
+		if (has_eager) return ENOTSUP; /* comb offsets do not keep the eager ordering */
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 4u, 65535u);
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
@@ -205,7 +238,7 @@ try {
 		return 0;
 	};
 	auto emit_combself = [&]() -> int {
-		if (C > 32) return ENOTSUP;
+		if (C > 32 || has_eager) return ENOTSUP;
 		/* image = comb + masks: half the room each */
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 8u, 65535u);
 		int r = build_comb(p, max_entries, false);
@@ -232,6 +265,7 @@ try {
 	}
 	auto emit_comb256 = [&]() -> int {
 		/* no byte->class table in LDS for this layout */
+		if (has_eager) return ENOTSUP;
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>((lds_room + lds_bytes_btab()) / 4u, 65535u);
 		int r = build_comb(p, max_entries, true);
 		if (r) return r;

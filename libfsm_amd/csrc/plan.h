@@ -33,6 +33,14 @@ struct Plan {
 	/* end-ids by ORIGINAL state id (CSR) */
 	std::vector<uint32_t> endid_off, endids;
 
+	/* eager outputs: distinct ids ascending (bit k of a mask = eager_ids[k]); per renumbered
+	 * state the mask of ids it emits.  Renumbering puts eager non-absorbing states first and
+	 * eager absorbing states just below DEAD, so "has eager outputs" is
+	 *   state < eager_lo_end || state >= eager_hi_begin.                               */
+	std::vector<uint32_t> eager_ids;
+	std::vector<uint64_t> emask;      /* [S1], empty if the DFA has no eager outputs */
+	uint32_t eager_lo_end = 0, eager_hi_begin = 0xFFFFFFFFu;
+
 	uint32_t layout = 0;          /* FSM_HIP_LAYOUT_* chosen */
 
 	/* ---- device images (host copies) ---- */

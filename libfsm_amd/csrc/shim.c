@@ -38,6 +38,8 @@ struct api {
 	size_t (*endid_count)(const struct fsm *, fsm_state_t);
 	/* include/fsm/fsm.h:327 */
 	size_t (*eager_output_count)(const struct fsm *, fsm_state_t);
+	/* include/fsm/fsm.h:343-345 */
+	int (*eager_output_get)(const struct fsm *, fsm_state_t, size_t, unsigned int *);
 };
 
 static struct api A;
@@ -63,6 +65,7 @@ resolve(void)
 	SYM(endid_get, "fsm_endid_get");
 	SYM(endid_count, "fsm_endid_count");
 	SYM(eager_output_count, "fsm_eager_output_count");
+	SYM(eager_output_get, "fsm_eager_output_get");
 #undef SYM
 	return A.resolved > 0;
 }
@@ -76,6 +79,8 @@ struct flat {
 	uint8_t *is_end;
 	uint32_t *endid_off;
 	uint32_t *endids;
+	uint32_t *eager_off;
+	uint32_t *eager_ids;
 };
 
 struct walk_env {
@@ -120,6 +125,8 @@ fsm_hip_desc_free(struct fsm_hip_dfa_desc *desc)
 	free(f->is_end);
 	free(f->endid_off);
 	free(f->endids);
+	free(f->eager_off);
+	free(f->eager_ids);
 	free(f);
 }
 
@@ -156,12 +163,6 @@ fsm_hip_flatten(const struct fsm *fsm)
 	if (n == 0) {
 		errno = EINVAL;
 		return NULL;
-	}
-	for (s = 0; s < n; s++) {
-		if (A.eager_output_count(fsm, s) > 0) {
-			errno = ENOTSUP;
-			return NULL;
-		}
 	}
 
 	f = calloc(1, sizeof *f);
@@ -246,6 +247,32 @@ fsm_hip_flatten(const struct fsm *fsm)
 		}
 	}
 
+	/* eager outputs: sorted unique per state, as fsm_eager_output_get returns them
+	 * (src/libfsm/eager_output.c:240ff; on any state, end or not) */
+	nid = 0;
+	for (s = 0; s < n; s++) {
+		nid += A.eager_output_count(fsm, s);
+	}
+	if (nid > 0) {
+		size_t k = 0;
+		f->eager_off = malloc(((size_t) n + 1) * sizeof *f->eager_off);
+		f->eager_ids = malloc(nid * sizeof *f->eager_ids);
+		if (f->eager_off == NULL || f->eager_ids == NULL) {
+			goto oom;
+		}
+		for (s = 0; s < n; s++) {
+			size_t cnt = A.eager_output_count(fsm, s);
+			f->eager_off[s] = (uint32_t) k;
+			if (cnt > 0 && !A.eager_output_get(fsm, s, cnt, f->eager_ids + k)) {
+				fsm_hip_desc_free(&f->d);
+				errno = EINVAL;
+				return NULL;
+			}
+			k += cnt;
+		}
+		f->eager_off[n] = (uint32_t) k;
+	}
+
 	f->d.nstates = n;
 	f->d.start = start;
 	f->d.edge_off = f->edge_off;
@@ -253,6 +280,8 @@ fsm_hip_flatten(const struct fsm *fsm)
 	f->d.is_end = f->is_end;
 	f->d.endid_off = f->endid_off;
 	f->d.endids = f->endids;
+	f->d.eager_off = f->eager_off;
+	f->d.eager_ids = f->eager_ids;
 	return &f->d;
 
 oom:
@@ -382,11 +411,16 @@ fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f)
  *   uint8    is_end[nstates], zero padded to a multiple of 4
  *   uint32   endid_off[nstates + 1]
  *   uint32   endids[nendids]
+ * "FSMHIP02" appends the eager outputs:
+ *   uint32   neager
+ *   uint32   eager_off[nstates + 1]
+ *   uint32   eager_ids[neager]
  * It serialises what fsm_hip_flatten() extracts from a struct fsm, i.e. the
  * role the reference's DFAVM save/load has for its bytecode
  * (fsm_dfavm_save/load, src/libfsm/vm.c:39-71, src/libfsm/vm/v1.c:19-82).
  */
 static const char desc_magic[8] = { 'F', 'S', 'M', 'H', 'I', 'P', '0', '1' };
+static const char desc_magic2[8] = { 'F', 'S', 'M', 'H', 'I', 'P', '0', '2' };
 
 int
 fsm_hip_desc_write(const struct fsm_hip_dfa_desc *d, FILE *f)
@@ -405,7 +439,7 @@ fsm_hip_desc_write(const struct fsm_hip_dfa_desc *d, FILE *f)
 	hdr[1] = d->start;
 	hdr[2] = nr;
 	hdr[3] = nid;
-	if (fwrite(desc_magic, 1, 8, f) != 8 || fwrite(hdr, 4, 4, f) != 4 ||
+	if (fwrite(d->eager_off != NULL ? desc_magic2 : desc_magic, 1, 8, f) != 8 || fwrite(hdr, 4, 4, f) != 4 ||
 	    fwrite(d->edge_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
 	    (nr > 0 && fwrite(d->ranges, sizeof *d->ranges, nr, f) != nr) ||
 	    fwrite(d->is_end, 1, n, f) != n ||
@@ -425,6 +459,13 @@ fsm_hip_desc_write(const struct fsm_hip_dfa_desc *d, FILE *f)
 			}
 		}
 	}
+	if (d->eager_off != NULL) {
+		uint32_t ne = d->eager_off[n];
+		if (fwrite(&ne, 4, 1, f) != 1 || fwrite(d->eager_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+		    (ne > 0 && fwrite(d->eager_ids, 4, ne, f) != ne)) {
+			return -1;
+		}
+	}
 	return 0;
 }
 
@@ -440,10 +481,13 @@ fsm_hip_desc_read(FILE *f)
 		errno = EINVAL;
 		return NULL;
 	}
-	if (fread(magic, 1, 8, f) != 8 || memcmp(magic, desc_magic, 8) != 0 || fread(hdr, 4, 4, f) != 4) {
+	int v2;
+	if (fread(magic, 1, 8, f) != 8 || (memcmp(magic, desc_magic, 8) != 0 && memcmp(magic, desc_magic2, 8) != 0) ||
+	    fread(hdr, 4, 4, f) != 4) {
 		errno = EINVAL;
 		return NULL;
 	}
+	v2 = memcmp(magic, desc_magic2, 8) == 0;
 	n = hdr[0];
 	nr = hdr[2];
 	nid = hdr[3];
@@ -497,6 +541,31 @@ fsm_hip_desc_read(FILE *f)
 	fl->d.is_end = fl->is_end;
 	fl->d.endid_off = fl->endid_off;
 	fl->d.endids = fl->endids;
+	if (v2) {
+		uint32_t ne;
+		if (fread(&ne, 4, 1, f) != 1) {
+			goto bad;
+		}
+		fl->eager_off = malloc(((size_t) n + 1) * 4);
+		fl->eager_ids = malloc(((size_t) ne ? ne : 1) * 4);
+		if (fl->eager_off == NULL || fl->eager_ids == NULL) {
+			fsm_hip_desc_free(&fl->d);
+			errno = ENOMEM;
+			return NULL;
+		}
+		if (fread(fl->eager_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
+		    (ne > 0 && fread(fl->eager_ids, 4, ne, f) != ne) ||
+		    fl->eager_off[0] != 0 || fl->eager_off[n] != ne) {
+			goto bad;
+		}
+		for (s = 0; s < n; s++) {
+			if (fl->eager_off[s + 1] < fl->eager_off[s]) {
+				goto bad;
+			}
+		}
+		fl->d.eager_off = fl->eager_off;
+		fl->d.eager_ids = fl->eager_ids;
+	}
 	return &fl->d;
 bad:
 	fsm_hip_desc_free(&fl->d);

@@ -74,6 +74,10 @@ struct WalkArgs {
 	const uint32_t *enc_of;
 	const uint32_t *orig_of;
 	uint32_t        nstates;
+	/* eager outputs: emask indexed like fin; has-eager test on the encoded state */
+	const uint64_t *emask;
+	uint64_t       *eager_out;
+	uint32_t        eager_lo_end, eager_hi_begin;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu
@@ -111,6 +115,7 @@ struct TinyPol {
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 32u * (uint32_t)sizeof(W); }
@@ -154,6 +159,7 @@ struct LdsPol {
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 2      */
 	const unsigned char *tab;  /* LDS table; state is a byte offset into it      */
 	uint32_t abs_min;
@@ -183,6 +189,7 @@ struct CombPol {
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
 	uint32_t abs_min;
@@ -210,6 +217,7 @@ struct Comb256Pol {
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte */
 	uint32_t abs_min, dflt;
 
@@ -258,6 +266,7 @@ struct CombSelfPol {
 	}
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask[code] }; return s; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
 	__device__ __forceinline__ S next(S s, P be) const
 	{
@@ -277,6 +286,7 @@ struct GlobPol {
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4                */
 	const unsigned char *tab;  /* device table; state is a byte offset into it             */
 	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
@@ -299,6 +309,62 @@ struct GlobPol {
 		if (MASK && st >= abs_min) return st;
 		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + ca);
 		return *reinterpret_cast<const uint32_t *>(tab + st + ca);
+	}
+};
+
+/*
+ * EagerPol<Pol>: any policy plus the eager-output side channel of fsm_exec (exec.c:126-144): the
+ * ids attached to the start state and to every state entered are OR-ed into a 64-bit set carried
+ * next to the state.  States with outputs are numbered so that one range test on the encoded state
+ * finds them; only lanes entering such a state do the (exec-masked) mask lookup.
+ */
+template <class Pol>
+struct EagerState {
+	typename Pol::S s;
+	uint64_t acc;
+};
+
+template <class Pol>
+struct EagerPol : Pol {
+	typedef EagerState<Pol> S;
+	typedef typename Pol::P P;
+	const uint64_t *emask;
+	uint32_t lo_end, hi_begin, fin_div;
+
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		Pol::setup(lds, a);
+		emask = a.emask;
+		lo_end = a.eager_lo_end;
+		hi_begin = a.eager_hi_begin;
+		fin_div = a.fin_div;
+	}
+	__device__ __forceinline__ uint64_t outputs_of(uint32_t c) const
+	{
+		uint64_t m = 0;
+		if (c < lo_end || c >= hi_begin) m = emask[c / fin_div];
+		return m;
+	}
+	__device__ __forceinline__ S init(uint32_t code) const
+	{
+		S st;
+		st.s = Pol::init(code);
+		st.acc = outputs_of(code); /* the start state emits before any input (exec.c:126-130) */
+		return st;
+	}
+	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
+	__device__ __forceinline__ S next(S st, P p) const
+	{
+		const uint32_t before = Pol::code(st.s);
+		st.s = Pol::next(st.s, p);
+		const uint32_t c = Pol::code(st.s);
+		(void)before;
+		st.acc |= outputs_of(c);
+		return st;
+	}
+	__device__ __forceinline__ static void finish(const WalkArgs &a, uint64_t i, bool valid, const S &st)
+	{
+		if (valid && a.eager_out != nullptr) a.eager_out[i] = st.acc;
 	}
 };
 
@@ -388,7 +454,10 @@ walk_direct(const WalkArgs a)
 				for (int r = 0; r < ROWS; r++) cur[j][r] = nxt[j][r];
 		}
 #pragma unroll
-		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + r, i[r], i[r] < a.n, Pol::code(st[r]));
+		for (int r = 0; r < ROWS; r++) {
+			write_result(a, tile * ROWS + r, i[r], i[r] < a.n, Pol::code(st[r]));
+			Pol::finish(a, i[r], i[r] < a.n, st[r]);
+		}
 	}
 }
 
@@ -421,6 +490,7 @@ walk_direct_np(const WalkArgs a)
 			if (a.early && __all(Pol::code(st[0]) >= a.abs_min)) break;
 		}
 		write_result(a, tile, i, i < a.n, Pol::code(st[0]));
+		Pol::finish(a, i, i < a.n, st[0]);
 	}
 }
 
@@ -512,6 +582,7 @@ walk_ldsdma(const WalkArgs a)
 			}
 		}
 		write_result(a, tile, i, valid, Pol::code(st[0]));
+		Pol::finish(a, i, valid, st[0]);
 	}
 }
 
@@ -574,6 +645,7 @@ walk_generic(const WalkArgs a)
 			if (a.early && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
 		write_result(a, tile, i, valid, Pol::code(st[0]));
+		Pol::finish(a, i, valid, st[0]);
 	}
 }
 

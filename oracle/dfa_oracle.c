@@ -349,3 +349,54 @@ oracle_isend(const struct oracle_dfa *d, uint32_t state)
 {
 	return state < d->statecount && d->states[state].end;
 }
+
+/*
+ * fsm_exec with the eager-output side channel (exec.c:126-144): the ids attached to the start
+ * state are emitted before any input, then those of every state entered; a missing edge stops the
+ * walk (return 0) but what was emitted stays emitted.  ids[i*cap ...] receives the distinct ids in
+ * order of first emission, counts[i] how many.  eager_off/eager_ids: CSR by state.
+ */
+static void
+emit_state(const uint32_t *eager_off, const uint32_t *eager_ids, uint32_t state,
+	uint32_t *ids, uint32_t *used, uint32_t cap)
+{
+	uint32_t k, j;
+	for (k = eager_off[state]; k < eager_off[state + 1]; k++) {
+		for (j = 0; j < *used; j++) {
+			if (ids[j] == eager_ids[k]) {
+				break;
+			}
+		}
+		if (j == *used && *used < cap) {
+			ids[(*used)++] = eager_ids[k];
+		}
+	}
+}
+
+void
+oracle_exec_eager_stride(const struct oracle_dfa *d, const uint32_t *eager_off, const uint32_t *eager_ids,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	int8_t *ret, uint32_t *end, uint32_t *ids, uint32_t *counts, uint32_t cap)
+{
+	size_t i;
+	for (i = 0; i < n; i++) {
+		const unsigned char *p = base + i * stride;
+		size_t l = len ? len[i] : stride, t;
+		uint32_t st = d->start, used = 0;
+		int r = 1;
+		emit_state(eager_off, eager_ids, st, ids + i * cap, &used, cap);
+		for (t = 0; t < l; t++) {
+			if (!edge_set_transition(&d->states[st], p[t], &st)) {
+				r = 0;
+				break;
+			}
+			emit_state(eager_off, eager_ids, st, ids + i * cap, &used, cap);
+		}
+		if (r && !d->states[st].end) {
+			r = 0;
+		}
+		ret[i] = (int8_t) r;
+		end[i] = r ? st : 0xFFFFFFFFu;
+		counts[i] = used;
+	}
+}

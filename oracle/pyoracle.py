@@ -68,6 +68,8 @@ class Oracle:
             L.oracle_state_walk_stride.restype = None
             L.oracle_state_walk_stride.argtypes = [vp, vp, sz, vp, sz, vp]
             L.oracle_isend.argtypes = [vp, C.c_uint32]
+            L.oracle_exec_eager_stride.restype = None
+            L.oracle_exec_eager_stride.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, C.c_uint32]
             L.oracle_endid_count.restype = sz
             L.oracle_endid_count.argtypes = [vp, C.c_uint32]
             L.oracle_endid_get.argtypes = [vp, C.c_uint32, sz, vp]
@@ -139,6 +141,21 @@ class Oracle:
         self.lib().oracle_state_walk_stride(self._h, _p(data) if data.size else None, stride, _p(lens), n, _p(st))
         return st
 
+    def exec_eager(self, data: np.ndarray, lens=None, cap: int = 64):
+        """fsm_exec + eager outputs: (ret, end, [sorted emitted ids per input])."""
+        flat = self.flat
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        eo = flat.eager_off if flat.eager_off is not None else np.zeros(flat.nstates + 1, np.uint32)
+        ei = flat.eager_ids if flat.eager_off is not None and len(flat.eager_ids) else np.zeros(1, np.uint32)
+        ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
+        ids, cnt = np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, np.uint32)
+        self.lib().oracle_exec_eager_stride(self._h, _p(eo), _p(ei), _p(data) if data.size else None, stride, _p(lens), n,
+                                            _p(ret), _p(end), _p(ids), _p(cnt), cap)
+        return ret, end, [np.sort(ids[i, :cnt[i]]) for i in range(n)]
+
     def isend(self, state: int) -> bool:
         return bool(self.lib().oracle_isend(self._h, int(state)))
 
@@ -191,6 +208,10 @@ class Ref:
             H.rh_vm_match_batch_stride.argtypes = [vp, vp, sz, sz, vp]
             H.rh_vm_match_batch.restype = C.c_double
             H.rh_vm_match_batch.argtypes = [vp, vp, vp, sz, vp]
+            H.rh_union_repeated.restype = vp
+            H.rh_union_repeated.argtypes = [C.c_int, vp, sz, C.c_uint, C.c_int]
+            H.rh_exec_eager_batch.restype = None
+            H.rh_exec_eager_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint]
             ref.fsm_setendid.argtypes = [vp, C.c_uint]
             ref.fsm_union.restype = vp
             ref.fsm_union.argtypes = [vp, vp, vp]
@@ -236,6 +257,26 @@ class RefFsm:
         arr = (C.c_char_p * len(words))(*words)
         lens = np.array([len(w) for w in words], np.uint32)
         return cls(H.rh_re_strings(arr, _p(lens) if len(words) else None, len(words), flags, int(with_endids)))
+
+    @classmethod
+    def union_repeated(cls, dialect: str, regexes, id_base: int = 1, force_endids: bool = False):
+        """tests/eager_output/utils.c:57-131: RE_SAVE_LINKAGE_INFO + fsm_union_repeated_pattern_group
+        (eager output id = id_base + index), determinise, minimise."""
+        _, H = Ref.libs()
+        arr = (C.c_char_p * len(regexes))(*regexes)
+        return cls(H.rh_union_repeated(DIALECTS[dialect], arr, len(regexes), id_base, int(force_endids)))
+
+    def exec_eager_strings(self, strings, cap: int = 64):
+        """Literal fsm_exec with the eager-output callback: (ret, end, [sorted emitted ids])."""
+        _, H = Ref.libs()
+        off = np.zeros(len(strings) + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in strings])
+        base = np.frombuffer(b"".join(strings) + b"\0", np.uint8)
+        n = len(strings)
+        ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
+        ids, cnt = np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
+        H.rh_exec_eager_batch(self.ptr, _p(base), _p(off), n, _p(ret), _p(end), _p(ids), _p(cnt), cap)
+        return ret, end, [np.sort(ids[i, :cnt[i]]) for i in range(n)]
 
     # -- queries ----------------------------------------------------------------
     @property

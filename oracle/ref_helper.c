@@ -278,3 +278,95 @@ rh_vm_match_batch(const struct fsm_dfavm *vm, const unsigned char *base, const u
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- eager outputs (src/libfsm/eager_output.c, exec.c:126-144) ------------------ */
+
+/* The construction of tests/eager_output/utils.c:57-131: every pattern compiled with
+ * RE_SAVE_LINKAGE_INFO, combined with fsm_union_repeated_pattern_group (eager output id =
+ * id_base + index) or, with force_endids, fsm_setendid + fsm_union_array; then determinised
+ * and minimised. */
+struct fsm *
+rh_union_repeated(int dialect, const char *const *res, size_t n, unsigned id_base, int force_endids)
+{
+	struct fsm **a;
+	struct fsm *u;
+	size_t i;
+
+	a = calloc(n ? n : 1, sizeof *a);
+	if (a == NULL) {
+		return NULL;
+	}
+	for (i = 0; i < n; i++) {
+		const char *s = res[i];
+		a[i] = re_comp((enum re_dialect) dialect, fsm_sgetc, &s, NULL, RE_SAVE_LINKAGE_INFO, NULL);
+		if (a[i] == NULL) {
+			free(a);
+			return NULL;
+		}
+		if (force_endids && !fsm_setendid(a[i], (fsm_end_id_t) (i + id_base))) {
+			free(a);
+			return NULL;
+		}
+	}
+	u = force_endids ? fsm_union_array(n, a, NULL)
+	                 : fsm_union_repeated_pattern_group(n, a, NULL, id_base);
+	free(a);
+	if (u == NULL) {
+		return NULL;
+	}
+	if (!fsm_determinise(u) || !fsm_minimise(u)) {
+		fsm_free(u);
+		return NULL;
+	}
+	return u;
+}
+
+struct eager_acc {
+	uint32_t *ids;
+	uint32_t used, cap;
+};
+
+static void
+eager_cb(fsm_output_id_t id, void *opaque)
+{
+	struct eager_acc *acc = opaque;
+	uint32_t i;
+	for (i = 0; i < acc->used; i++) {
+		if (acc->ids[i] == id) {
+			return;
+		}
+	}
+	if (acc->used < acc->cap) {
+		acc->ids[acc->used++] = id;
+	}
+}
+
+/* literal fsm_exec with the eager-output callback installed: ids[i*cap .. i*cap+counts[i]) are the
+ * distinct ids emitted while walking input i, in order of first emission -- emitted whether or not
+ * the input finally matches (exec.c:126-144; the reference's tests drop them on reject). */
+void
+rh_exec_eager_batch(struct fsm *fsm, const unsigned char *base, const uint64_t *off, size_t n,
+	int8_t *ret, uint32_t *end, uint32_t *ids, uint32_t *counts, uint32_t cap)
+{
+	size_t i;
+	for (i = 0; i < n; i++) {
+		struct eager_acc acc;
+		unsigned e = 0xFFFFFFFFu;
+		int r;
+		acc.ids = ids + i * cap;
+		acc.used = 0;
+		acc.cap = cap;
+		fsm_eager_output_set_cb(fsm, eager_cb, &acc);
+		r = rh_exec(fsm, base + off[i], (size_t) (off[i + 1] - off[i]), &e);
+		ret[i] = (int8_t) r;
+		end[i] = r == 1 ? e : 0xFFFFFFFFu;
+		counts[i] = acc.used;
+	}
+	fsm_eager_output_set_cb(fsm, NULL, NULL);
+}
+
+size_t
+rh_eager_output_count(const struct fsm *fsm, unsigned state)
+{
+	return fsm_eager_output_count(fsm, state);
+}

@@ -22,6 +22,8 @@ class Golden:
         self.expect = z["expect"] if "expect" in z else None
         self.ids_off = z["ids_off"] if "ids_off" in z else None
         self.ids = z["ids"] if "ids" in z else None
+        self.eager_out_off = z["eager_out_off"] if "eager_out_off" in z else None
+        self.eager_out = z["eager_out"] if "eager_out" in z else None
         if "in_off" in z:                      # packed variable-length inputs
             self.base, self.off = z["in_bytes"], z["in_off"]
             self.rows = None
@@ -45,12 +47,30 @@ class Golden:
         n, L = self.rows.shape
         return self.rows.reshape(-1), (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
 
+    def eager_of(self, i):
+        return self.eager_out[int(self.eager_out_off[i]):int(self.eager_out_off[i + 1])]
+
+    def padded_rows(self):
+        """Packed inputs as fixed-stride rows + lengths (for the fixed-stride fronts)."""
+        strs = self.strings()
+        stride = max(16, (max([len(s) for s in strs] + [1]) + 15) // 16 * 16)
+        rows = np.zeros((len(strs), stride), np.uint8)
+        lens = np.array([len(s) for s in strs], np.uint32)
+        for i, s in enumerate(strs):
+            rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+        return rows, lens
+
     def ids_of(self, i):
         return self.ids[int(self.ids_off[i]):int(self.ids_off[i + 1])]
 
 
 def all_golden_paths():
-    return sorted(glob.glob(os.path.join(GOLDEN, "retest", "*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return (sorted(glob.glob(os.path.join(GOLDEN, "retest", "*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "eager", "*.npz")))
+            + sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+
+
+def eager_golden_paths():
+    return sorted(glob.glob(os.path.join(GOLDEN, "eager", "*.npz")))
 
 
 def golden_id(p):

@@ -289,6 +289,105 @@ def gen_c3():
     print("c3: accepts", int((ret == 1).sum()), "of", len(ret), "multi-id ends", int(sum(1 for k in range(len(ret)) if io[k + 1] - io[k] > 1)))
 
 
+def c_unescape(lit: str) -> bytes:
+    """A C string literal body -> bytes (the escapes the reference's test sources use)."""
+    out, i = bytearray(), 0
+    simple = {"n": 10, "t": 9, "r": 13, "0": 0, "\\": 92, '"': 34, "'": 39, "a": 7, "b": 8, "f": 12, "v": 11}
+    while i < len(lit):
+        ch = lit[i]
+        if ch != "\\":
+            out += ch.encode("latin1")
+            i += 1
+            continue
+        nx = lit[i + 1]
+        if nx == "x":
+            j = i + 2
+            while j < len(lit) and lit[j] in "0123456789abcdefABCDEF":
+                j += 1
+            out.append(int(lit[i + 2:j], 16) & 0xFF)
+            i = j
+        elif nx in simple:
+            out.append(simple[nx])
+            i += 2
+        else:
+            out += nx.encode("latin1")
+            i += 2
+    return bytes(out)
+
+
+def parse_eager_test(path):
+    """Pull .patterns / .inputs out of a tests/eager_output/*.c program (struct eager_output_test,
+    tests/eager_output/utils.h:28-39)."""
+    import re
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    m = re.search(r"\.patterns\s*=\s*\{(.*?)\}\s*,\s*\.inputs", src, flags=re.S)
+    if not m:
+        return None
+    STR = r'"((?:[^"\\]|\\.)*)"'
+    pats = [c_unescape(x) for x in re.findall(STR, m.group(1))]
+    body = src[m.end():]
+    inputs = []
+    MULTI = r'((?:"(?:[^"\\]|\\.)*"\s*)+)'          # adjacent literals concatenate
+    for im in re.finditer(r"\{\s*\.input\s*=\s*" + MULTI, body):
+        depth, pos = 1, im.end()
+        while depth and pos < len(body):          # scan to the brace closing this entry
+            ch = body[pos]
+            if ch == '"':                          # skip string literals
+                pos += 1
+                while body[pos] != '"':
+                    pos += 2 if body[pos] == "\\" else 1
+            elif ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+            pos += 1
+        rest = body[im.end():pos]
+        ids = re.search(r"\.expected_ids\s*=\s*\{([^}]*)\}", rest)
+        want = [int(x) for x in re.findall(r"\d+", ids.group(1))] if ids else []
+        text = b"".join(c_unescape(x) for x in re.findall(STR, im.group(1)))
+        inputs.append((text, "expect_fail" in rest, want))
+    return pats, inputs
+
+
+def gen_eager():
+    """tests/eager_output/*.c: 22 programs; the combined DFA carries eager outputs (and sometimes
+    end-ids).  Frozen: fsm_exec's return/end state, the end state's end-ids, and the ids the
+    eager-output callback received; checked against each program's own expected_ids the way
+    run_test() does (utils.c:170-251)."""
+    d = os.path.join(OUT, "eager")
+    os.makedirs(d, exist_ok=True)
+    k = total = 0
+    for fn in sorted(os.listdir(os.path.join(REF, "tests/eager_output"))):
+        if not fn.startswith("eager_output") or not fn.endswith(".c"):
+            continue
+        parsed = parse_eager_test(os.path.join(REF, "tests/eager_output", fn))
+        assert parsed, fn
+        pats, inputs = parsed
+        fsm = RefFsm.union_repeated("pcre", pats, 1, False)
+        strings = [x[0] for x in inputs]
+        ret, end, eager = fsm.exec_eager_strings(strings)
+        flat = fsm.flatten()
+        for i, (s_, fail, want) in enumerate(inputs):
+            got = sorted(set(eager[i].tolist()) | set(fsm.endids(int(end[i])).tolist())) if ret[i] == 1 else []
+            if fail or not want:
+                assert ret[i] == 0 or not got, (fn, s_)
+            else:
+                assert ret[i] == 1 and got == want, (fn, s_, got, want)
+        base, off = pack(strings)
+        io, ii = endid_csr(fsm, end)
+        eo = np.zeros(len(strings) + 1, np.uint32)
+        eo[1:] = np.cumsum([len(e) for e in eager])
+        flat.save(os.path.join(d, f"{k:03d}.npz"), in_bytes=base, in_off=off, ret=ret, end=end, ids_off=io, ids=ii,
+                  eager_out_off=eo, eager_out=np.concatenate(eager).astype(np.uint32) if eo[-1] else np.zeros(0, np.uint32),
+                  meta=np.frombuffer(json.dumps(dict(source=f"tests/eager_output/{fn}", patterns=[p.decode("latin1") for p in pats],
+                                                     expected=[x[2] for x in inputs], expect_fail=[x[1] for x in inputs])).encode(), np.uint8))
+        k += 1
+        total += len(inputs)
+    print(f"eager: {k} programs, {total} inputs")
+
+
 if __name__ == "__main__":
     assert build_ref(), "needs /root/reference to build oracle/_ref"
     gen_retest()
@@ -296,3 +395,4 @@ if __name__ == "__main__":
     gen_re_strings()
     gen_c1()
     gen_c3()
+    gen_eager()

@@ -469,3 +469,69 @@ def test_streaming_resume_in_pieces(hip):
             st2, _ = dfa.exec_batch_resume(np.ascontiguousarray(rows[:, :64]), np.full(n, hip.STATE_START, np.uint32), lens)
             assert np.array_equal(st2, o.state_walk(np.ascontiguousarray(rows[:, :64]), np.full(n, hip.STATE_START, np.uint32), lens))
             dfa.close()
+
+
+def test_eager_outputs_golden_and_random(hip):
+    """eager outputs.  Every tests/eager_output program: the set of ids the kernel
+    ORs together equals what the reference's callback received (also on rejected inputs), in every
+    layout that can carry them and through both eager kernels; then seeded random inputs against
+    the oracle."""
+    from common import eager_golden_paths
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(12)
+    n_checked = 0
+    for path in eager_golden_paths():
+        g = Golden(path)
+        rows, lens = g.padded_rows()
+        alpha = np.frombuffer((" ".join(g.meta["patterns"]) + " xyz$^").encode("latin1"), np.uint8)
+        rnd = alpha[rng.randint(0, len(alpha), (500, 64))]
+        for i in range(0, 500, 5):                 # plant whole patterns so outputs fire
+            p = g.meta["patterns"][rng.randint(len(g.meta["patterns"]))].encode("latin1").strip(b"^$")
+            if 0 < len(p) <= 40 and not any(c in p for c in b"[]()*+?|\\."):
+                at = rng.randint(0, 64 - len(p))
+                rnd[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
+        o = Oracle(g.flat)
+        rret, rend, rsets = o.exec_eager(rnd)
+        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_GLOBAL):
+            try:
+                dfa = hip.HipDfa(g.flat, L)
+            except OSError:
+                continue
+            for mode in (hip.IN_GENERIC, hip.IN_DIRECT):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                end, sets = dfa.exec_batch_eager(rows, lens)
+                assert np.array_equal(end, g.end), (g.meta["source"], L, mode)
+                for i in range(len(rows)):
+                    assert np.array_equal(sets[i], np.sort(g.eager_of(i))), (g.meta["source"], L, mode, i)
+                end2, sets2 = dfa.exec_batch_eager(rnd)
+                assert np.array_equal(end2, rend)
+                for i in range(len(rnd)):
+                    assert np.array_equal(sets2[i], rsets[i]), (g.meta["source"], L, mode, i)
+                n_checked += len(rows) + len(rnd)
+            dfa.close()
+    assert n_checked > 20000
+
+
+def test_eager_outputs_live_reference_through_shim(hip):
+    """fsm_hip_compile() now accepts fsms with eager outputs: build one with the reference's
+    fsm_union_repeated_pattern_group and compare with fsm_exec + callback on random text."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    pats = [b"apple", b"banana", b"^carrot", b"durian$", b"fig", b"ab+c", b"[0-9]{3}"]
+    f = RefFsm.union_repeated("pcre", pats, 1, False)
+    dfa = hip.HipDfa.compile_fsm(f.ptr)
+    rng = np.random.RandomState(2)
+    words = [b"apple", b"banana", b"carrot", b"durian", b"fig", b"abbbc", b"123", b"zz", b" "]
+    strings = [b" ".join(words[k] for k in rng.randint(0, len(words), rng.randint(0, 9))) for _ in range(800)]
+    ret, end, sets = f.exec_eager_strings(strings)
+    stride = (max(len(s) for s in strings) + 15) // 16 * 16
+    rows = np.zeros((len(strings), stride), np.uint8)
+    lens = np.array([len(s) for s in strings], np.uint32)
+    for i, s in enumerate(strings):
+        rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+    gend, gsets = dfa.exec_batch_eager(rows, lens)
+    assert np.array_equal(gend, end)
+    assert sum(len(s) for s in sets) > 500
+    for i in range(len(strings)):
+        assert np.array_equal(gsets[i], sets[i]), strings[i]
+    dfa.close()

@@ -99,3 +99,29 @@ def test_reference_vm_agrees_with_fsm_exec():
     ret, _ = f.exec_stride(data)
     for v in (1, 2):
         assert np.array_equal(f.vm_match_stride(data, v), ret)
+
+
+def test_oracle_eager_outputs_match_golden():
+    """tests/eager_output/*.c (22 programs, 89 inputs): the oracle's restatement of exec.c:126-144
+    emits exactly the ids the reference's callback received, and the union with the end state's
+    end-ids equals each program's own expected_ids (the check run_test() makes, utils.c:170-251)."""
+    from common import eager_golden_paths
+    paths = eager_golden_paths()
+    assert len(paths) == 22
+    total = 0
+    for path in paths:
+        g = Golden(path)
+        rows, lens = g.padded_rows()
+        o = Oracle(g.flat)
+        ret, end, sets = o.exec_eager(rows, lens)
+        assert np.array_equal(ret, g.ret) and np.array_equal(end, g.end)
+        for i in range(len(rows)):
+            assert np.array_equal(sets[i], np.sort(g.eager_of(i))), (g.meta["source"], i)
+            want, fail = g.meta["expected"][i], g.meta["expect_fail"][i]
+            got = sorted(set(sets[i].tolist()) | set(o.endids(int(end[i])).tolist())) if ret[i] == 1 else []
+            if fail or not want:
+                assert ret[i] == 0 or not got
+            else:
+                assert got == want
+        total += len(rows)
+    assert total == 89

@@ -36,6 +36,19 @@ def check_plan(flat, layout):
     want_fin = np.where(np.append(flat.is_end, 0).astype(bool)[new2old], new2old, NO).astype(np.uint32)
     assert np.array_equal(fin, want_fin)
     assert old2new[flat.start] == p.start
+    # eager outputs: masks follow the renumbering, states with outputs sit in the two test ranges
+    em = p.get("emask")
+    if flat.eager_off is not None:
+        eids = p.get("eager_ids")
+        assert len(em) == S1 and list(eids) == sorted(set(flat.eager_ids.tolist()))
+        for nidx in range(S1 - 1):
+            want_ids = flat.eager_of(int(new2old[nidx]))
+            got_ids = eids[[b for b in range(len(eids)) if (int(em[nidx]) >> b) & 1]]
+            assert np.array_equal(got_ids, want_ids)
+            assert (len(want_ids) > 0) == (nidx < p.eager_lo_end or nidx >= p.eager_hi_begin)
+        assert em[S1 - 1] == 0
+    else:
+        assert len(em) == 0
     # expected next state in NEW numbering for all (new state, byte)
     want = old2new[ref[new2old]]            # [S1][256]
     # absorbing threshold
