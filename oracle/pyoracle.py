@@ -208,6 +208,10 @@ class Ref:
             H.rh_vm_match_batch_stride.argtypes = [vp, vp, sz, sz, vp]
             H.rh_vm_match_batch.restype = C.c_double
             H.rh_vm_match_batch.argtypes = [vp, vp, vp, sz, vp]
+            H.rh_parse_fsm_file.restype = vp
+            H.rh_parse_fsm_file.argtypes = [C.c_char_p]
+            H.rh_generate_matches.restype = sz
+            H.rh_generate_matches.argtypes = [vp, sz, C.c_uint, vp, vp, sz]
             H.rh_union_repeated.restype = vp
             H.rh_union_repeated.argtypes = [C.c_int, vp, sz, C.c_uint, C.c_int]
             H.rh_exec_eager_batch.restype = None
@@ -265,6 +269,21 @@ class RefFsm:
         _, H = Ref.libs()
         arr = (C.c_char_p * len(regexes))(*regexes)
         return cls(H.rh_union_repeated(DIALECTS[dialect], arr, len(regexes), id_base, int(force_endids)))
+
+    @classmethod
+    def parse_file(cls, path: str):
+        """fsm_parse + determinise + minimise of a .fsm file; None if the reference rejects it."""
+        _, H = Ref.libs()
+        p = H.rh_parse_fsm_file(path.encode())
+        return cls(p) if p else None
+
+    def generate_matches(self, maxlen: int = 24, cap: int = 8, seed: int = 1):
+        """Accepted inputs found by the reference's fsm_generate_matches (randomised labels)."""
+        _, H = Ref.libs()
+        buf = np.zeros((cap, maxlen), np.uint8)
+        lens = np.zeros(cap, np.uint32)
+        n = H.rh_generate_matches(self.ptr, maxlen, seed, _p(buf), _p(lens), cap)
+        return [bytes(buf[i, :lens[i]]) for i in range(n)]
 
     def exec_eager_strings(self, strings, cap: int = 64):
         """Literal fsm_exec with the eager-output callback: (ret, end, [sorted emitted ids])."""

@@ -370,3 +370,72 @@ rh_eager_output_count(const struct fsm *fsm, unsigned state)
 {
 	return fsm_eager_output_count(fsm, state);
 }
+
+/* ---- golden .fsm corpus (tests/{pcre,native,glob,...}/out*.fsm) ------------------ */
+
+#include <fsm/parser.h>
+#include <fsm/walk.h>
+
+/* fsm_parse + determinise + minimise: the checked-in expected automata of the reference's
+ * golden-DFA tests (tests/pcre/Makefile:40-63) as executable DFAs. */
+struct fsm *
+rh_parse_fsm_file(const char *path)
+{
+	FILE *f = fopen(path, "r");
+	struct fsm *fsm;
+	if (f == NULL) {
+		return NULL;
+	}
+	fsm = fsm_parse(f, NULL);
+	fclose(f);
+	if (fsm == NULL) {
+		return NULL;
+	}
+	if (!fsm_determinise(fsm) || !fsm_minimise(fsm)) {
+		fsm_free(fsm);
+		return NULL;
+	}
+	return fsm;
+}
+
+struct gen_env {
+	unsigned char *buf;   /* [cap][maxlen] */
+	uint32_t *lens;
+	size_t cap, used, maxlen;
+};
+
+static enum fsm_generate_matches_cb_res
+gen_cb(const struct fsm *fsm, size_t depth, size_t match_count, size_t steps,
+	const char *input, size_t input_length, fsm_state_t end_state, void *opaque)
+{
+	struct gen_env *env = opaque;
+	(void) fsm; (void) depth; (void) match_count; (void) end_state;
+	if (steps > 200000) {
+		return FSM_GENERATE_MATCHES_CB_RES_HALT;
+	}
+	if (input_length <= env->maxlen) {
+		memcpy(env->buf + env->used * env->maxlen, input, input_length);
+		env->lens[env->used++] = (uint32_t) input_length;
+	}
+	return env->used >= env->cap ? FSM_GENERATE_MATCHES_CB_RES_HALT : FSM_GENERATE_MATCHES_CB_RES_CONTINUE;
+}
+
+/* up to cap accepted inputs from fsm_generate_matches (src/libfsm/gen.c:143) on a CLONE (it trims) */
+size_t
+rh_generate_matches(const struct fsm *fsm, size_t maxlen, unsigned seed, unsigned char *buf, uint32_t *lens, size_t cap)
+{
+	struct gen_env env;
+	struct fsm *c = fsm_clone(fsm);
+	if (c == NULL) {
+		return 0;
+	}
+	env.buf = buf;
+	env.lens = lens;
+	env.cap = cap;
+	env.used = 0;
+	env.maxlen = maxlen;
+	srand(seed);
+	(void) fsm_generate_matches(c, maxlen, 1, gen_cb, &env);
+	fsm_free(c);
+	return env.used;
+}

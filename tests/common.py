@@ -66,7 +66,7 @@ class Golden:
 
 def all_golden_paths():
     return (sorted(glob.glob(os.path.join(GOLDEN, "retest", "*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "eager", "*.npz")))
-            + sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+            + [p for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))) if not p.endswith("fsm_corpus.npz")])
 
 
 def eager_golden_paths():
@@ -75,3 +75,23 @@ def eager_golden_paths():
 
 def golden_id(p):
     return os.path.relpath(p, GOLDEN).replace(".npz", "")
+
+
+class Corpus:
+    """tests/golden/fsm_corpus.npz: the reference's checked-in out*.fsm automata with fsm_exec answers."""
+
+    def __init__(self):
+        self.z = np.load(os.path.join(GOLDEN, "fsm_corpus.npz"))
+        self.names = bytes(self.z["names"]).decode().split("\n")
+
+    def __len__(self):
+        return len(self.names)
+
+    def get(self, k):
+        z = self.z
+        from libfsm_amd.capi import RANGE_DTYPE
+        r = np.zeros(len(z[f"d{k}_r_lo"]), dtype=RANGE_DTYPE)
+        r["lo"], r["hi"], r["to"] = z[f"d{k}_r_lo"], z[f"d{k}_r_hi"], z[f"d{k}_r_to"]
+        flat = FlatDfa(int(z[f"d{k}_nstates"]), int(z[f"d{k}_start"]), z[f"d{k}_edge_off"], r, z[f"d{k}_is_end"],
+                       z[f"d{k}_endid_off"], z[f"d{k}_endids"])
+        return flat, z[f"d{k}_in_bytes"], z[f"d{k}_in_off"], z[f"d{k}_ret"], z[f"d{k}_end"]

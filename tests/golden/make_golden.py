@@ -388,6 +388,58 @@ def gen_eager():
     print(f"eager: {k} programs, {total} inputs")
 
 
+def gen_fsm_corpus():
+    """The reference's golden-DFA directories (tests/{pcre,pcre-anchor,pcre-classes,pcre-flags,
+    pcre-repeat,native,glob,like,literal,sql,...}/out*.fsm): every checked-in expected automaton,
+    parsed, determinised and minimised by the reference, with inputs from the reference's own
+    fsm_generate_matches plus mutations and random strings, and fsm_exec's answers.  One container
+    file: keys d<k>_<field>."""
+    import glob as _glob
+    rng = np.random.RandomState(77)
+    store, k, ncase, skipped = {}, 0, 0, 0
+    names = []
+    for path in sorted(_glob.glob(os.path.join(REF, "tests", "*", "out*.fsm"))):
+        if "/eclosure/" in path:  # not .fsm syntax (the reference's parser exits on it)
+            continue
+        f = RefFsm.parse_file(path)
+        if f is None or f.nstates == 0 or f.nstates > 3000:
+            skipped += 1
+            continue
+        try:
+            flat = f.flatten()
+        except OSError:
+            skipped += 1          # no start state etc.: fsm_exec would return -1 as well
+            continue
+        pos = f.generate_matches(24, 8, seed=k + 1)
+        strings = list(pos)
+        for s_ in pos:            # mutations: truncate, extend, flip one byte
+            if s_:
+                strings.append(s_[:-1])
+                t = bytearray(s_)
+                t[rng.randint(len(t))] ^= 1 << rng.randint(8)
+                strings.append(bytes(t))
+            strings.append(s_ + bytes([rng.randint(256)]))
+        used = sorted(set(int(r["lo"]) for r in flat.ranges) | {0x61, 0x0a, 0x00})
+        for _ in range(8):
+            strings.append(bytes(rng.choice(used, rng.randint(0, 12)).astype(np.uint8)))
+        strings.append(b"")
+        ret, end = f.exec_strings(strings)
+        base, off = pack(strings)
+        io, ii = endid_csr(f, end)
+        rel = os.path.relpath(path, REF)
+        for key, val in dict(nstates=np.uint32(flat.nstates), start=np.uint32(flat.start), edge_off=flat.edge_off,
+                             r_lo=flat.ranges["lo"], r_hi=flat.ranges["hi"], r_to=flat.ranges["to"], is_end=flat.is_end,
+                             endid_off=flat.endid_off, endids=flat.endids, in_bytes=base, in_off=off, ret=ret, end=end,
+                             ids_off=io, ids=ii).items():
+            store[f"d{k}_{key}"] = val
+        names.append(rel)
+        ncase += len(strings)
+        k += 1
+    store["names"] = np.frombuffer("\n".join(names).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "fsm_corpus.npz"), **store)
+    print(f"fsm corpus: {k} automata, {ncase} inputs, {skipped} skipped")
+
+
 if __name__ == "__main__":
     assert build_ref(), "needs /root/reference to build oracle/_ref"
     gen_retest()
@@ -396,3 +448,4 @@ if __name__ == "__main__":
     gen_c1()
     gen_c3()
     gen_eager()
+    gen_fsm_corpus()

@@ -535,3 +535,24 @@ def test_eager_outputs_live_reference_through_shim(hip):
     for i in range(len(strings)):
         assert np.array_equal(gsets[i], sets[i]), strings[i]
     dfa.close()
+
+
+def test_reference_fsm_corpus(hip):
+    """The 319 out*.fsm automata of the reference's golden-DFA tests, 8 843 inputs: HIP == fsm_exec
+    (auto layout, the HBM-resident layout, and the LDS-dense layout where it fits)."""
+    from common import Corpus
+    c = Corpus()
+    n_inputs = 0
+    for k in range(len(c)):
+        flat, base, off, ret, end = c.get(k)
+        for L in (hip.LAYOUT_AUTO, hip.LAYOUT_GLOBAL, hip.LAYOUT_LDS):
+            try:
+                dfa = hip.HipDfa(flat, L)
+            except OSError:
+                continue
+            got, bm = dfa.exec_batch_offsets(base, off)
+            assert np.array_equal(got, end), (c.names[k], L)
+            assert np.array_equal(bits(bm, len(ret)), ret == 1)
+            dfa.close()
+        n_inputs += len(ret)
+    assert n_inputs > 8000

@@ -125,3 +125,20 @@ def test_oracle_eager_outputs_match_golden():
                 assert got == want
         total += len(rows)
     assert total == 89
+
+
+def test_oracle_on_reference_fsm_corpus():
+    """319 automata checked into the reference as out*.fsm (pcre, pcre-anchor, pcre-repeat, native, glob,
+    like, literal, sql, determinise, minimise, reverse, ...), 8 843 inputs incl. the reference's own
+    fsm_generate_matches output: the oracle reproduces fsm_exec on all of them."""
+    from common import Corpus
+    c = Corpus()
+    assert len(c) >= 300
+    total = acc = 0
+    for k in range(len(c)):
+        flat, base, off, ret, end = c.get(k)
+        r, e = Oracle(flat).exec_offsets(base, off)
+        assert np.array_equal(r, ret) and np.array_equal(e, end), c.names[k]
+        total += len(ret)
+        acc += int((ret == 1).sum())
+    assert total > 8000 and acc > 2500

@@ -151,3 +151,15 @@ def test_random_dfas_all_layouts(built):
         flat = FlatDfa.from_dense(nt, int(rng.randint(S)), rng.randint(0, 2, S))
         for L in (0,) + tuple(ALL_LAYOUTS):
             check_plan(flat, L)
+
+
+def test_layouts_on_reference_fsm_corpus(built):
+    """Every layout that can hold each of the 319 corpus automata encodes its transition function exactly."""
+    from common import Corpus
+    c = Corpus()
+    held = 0
+    for k in range(0, len(c)):
+        flat = c.get(k)[0]
+        for L in (0,) + tuple(ALL_LAYOUTS):
+            held += bool(check_plan(flat, L))
+    assert held > 4 * len(c)
