@@ -406,7 +406,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
-	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early;
+	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	hipError_t e = hipEventRecord(md->ev0, s);
 	if (e == hipSuccess) {

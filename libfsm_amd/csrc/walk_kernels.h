@@ -63,7 +63,8 @@ struct WalkArgs {
 	uint32_t        start;    /* encoded start state                                  */
 	uint32_t        abs_min;  /* encoded states >= abs_min are absorbing              */
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
-	uint32_t        early;    /* retire a wavefront once every lane is absorbing      */
+	uint32_t        early;    /* bit 0: retire a wavefront once every lane is absorbing;
+	                           * bit 1: absorbing lanes stop loading their input        */
 	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
 	const uint32_t *fin2;     /* optional second per-state table (end-id / ret index) */
 	uint32_t       *out2;     /* n entries, written from fin2, or NULL                */
@@ -442,7 +443,7 @@ walk_direct(const WalkArgs a)
 			}
 #pragma unroll
 			for (int j = 0; j < NB; j++) step16<Pol, ROWS>(pol, st, cur[j]);
-			if (a.early) {
+			if (a.early & 1u) {
 				bool done = true;
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) done = done && Pol::code(st[r]) >= a.abs_min;
@@ -483,11 +484,18 @@ walk_direct_np(const WalkArgs a)
 		typename Pol::S st[1] = { pol.init(start_code(a, i, i < a.n)) };
 		for (uint32_t g = 0; g < ngroups; g++) {
 			u32x4 cur[NB][1];
+			/* (a.early & 2): a lane whose input can no longer change state stops reading it, as
+			 * fsm_exec stops pulling bytes at a missing edge (exec.c:133-138) */
+			if (!(a.early & 2u) || Pol::code(st[0]) < a.abs_min) {
 #pragma unroll
-			for (int j = 0; j < NB; j++) cur[j][0] = q[g * NB + j];
+				for (int j = 0; j < NB; j++) cur[j][0] = q[g * NB + j];
+			} else {
+#pragma unroll
+				for (int j = 0; j < NB; j++) cur[j][0] = u32x4{0u, 0u, 0u, 0u};
+			}
 #pragma unroll
 			for (int j = 0; j < NB; j++) step16<Pol, 1>(pol, st, cur[j]);
-			if (a.early && __all(Pol::code(st[0]) >= a.abs_min)) break;
+			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min)) break;
 		}
 		write_result(a, tile, i, i < a.n, Pol::code(st[0]));
 		Pol::finish(a, i, i < a.n, st[0]);
@@ -576,7 +584,7 @@ walk_ldsdma(const WalkArgs a)
 			}
 #pragma unroll
 			for (uint32_t p = 0; p < PIECES; p++) step16<Pol, 1>(pol, st, w[p]);
-			if (a.early && __all(Pol::code(st[0]) >= a.abs_min)) {
+			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min)) {
 				__builtin_amdgcn_s_waitcnt(0x0F70); /* drain the prefetch before the tile is reused */
 				break;
 			}
@@ -642,7 +650,7 @@ walk_generic(const WalkArgs a)
 				}
 				w[0] = wn;
 			}
-			if (a.early && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
+			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
 		write_result(a, tile, i, valid, Pol::code(st[0]));
 		Pol::finish(a, i, valid, st[0]);
