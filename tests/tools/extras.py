@@ -29,7 +29,8 @@ def main():
         dfa = hip.HipDfa(flat, hip.LAYOUT_COMBSELF if wl == "c3" else hip.LAYOUT_LDS)
         dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_DIRECT)
         dfa.tune(hip.KNOB_PREFETCH, 0)
-        for early in (1, 3, 0, 2):
+        first = True
+        for early in (0, 1, 0, 1, 3, 2):
             dfa.tune(hip.KNOB_EARLY_RETIRE, early)
             ms = []
             for r in range(4):
@@ -38,8 +39,9 @@ def main():
                 if r:
                     ms.append(t)
             torch.cuda.synchronize()
-            if early == 1:
+            if first:
                 ref.copy_(end)
+                first = False
             print(f"{wl} {dfa.info()['layout_name']} direct_np early={early} (bit0 wave retire, bit1 lane load skip) "
                   f"ms={min(ms):.3f} GB/s={n * L / min(ms) / 1e6:.1f} {'ok' if torch.equal(end, ref) else 'DIFF'}", flush=True)
         dfa.close()
