@@ -556,3 +556,50 @@ def test_reference_fsm_corpus(hip):
             dfa.close()
         n_inputs += len(ret)
     assert n_inputs > 8000
+
+
+def test_error_contracts(hip):
+    """Return conventions of the reference carried over: -1 + errno (cf. fsm_exec, exec.c:106-114),
+    NULL + errno from constructors, nothing silently accepted."""
+    import errno as _errno
+    lib = hip.load_library()
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    dfa = hip.HipDfa(g.flat)
+    rows = g.rows[:64]
+    # a length larger than the stride is rejected before anything is launched
+    with pytest.raises(OSError) as ei:
+        dfa.exec_batch(rows, np.full(64, rows.shape[1] + 1, np.uint32))
+    assert ei.value.errno == _errno.EINVAL
+    # decreasing offsets
+    with pytest.raises(OSError) as ei:
+        dfa.exec_batch_offsets(rows.reshape(-1), np.array([0, 10, 5], np.uint64))
+    assert ei.value.errno == _errno.EINVAL
+    # unknown knob, NULL handles
+    with pytest.raises(OSError):
+        dfa.tune(999, 1)
+    ctypes.set_errno(0)
+    assert lib.fsm_hip_exec_batch(None, None, 16, None, 1, None, None) == -1 and ctypes.get_errno() == _errno.EINVAL
+    assert lib.fsm_hip_dfa_create(None, 0) is None and ctypes.get_errno() == _errno.EINVAL
+    assert lib.fsm_hip_match_buffer(None, b"x", 1) == -1
+    # n == 0 is a no-op success
+    e, bm = dfa.exec_batch(np.zeros((0, 64), np.uint8))
+    assert len(e) == 0
+    # id modes other than the two defined ones
+    with pytest.raises(OSError) as ei:
+        dfa.exec_batch_ids(rows, 7)
+    assert ei.value.errno == _errno.EINVAL
+    # a DFA without eager outputs answers the eager front with empty sets
+    end, sets = dfa.exec_batch_eager(rows)
+    assert np.array_equal(end, g.end[:64]) and all(len(s) == 0 for s in sets)
+    # more than 64 distinct eager ids: ENOTSUP at creation
+    from libfsm_amd import FlatDfa
+    nt = np.full((70, 256), -1, np.int64)
+    for s in range(69):
+        nt[s, ord("a")] = s + 1
+    flat = FlatDfa.from_dense(nt, 0, [0] * 69 + [1])
+    flat.eager_off = np.arange(71, dtype=np.uint32)
+    flat.eager_ids = np.arange(70, dtype=np.uint32)
+    with pytest.raises(OSError) as ei:
+        hip.HipDfa(flat)
+    assert ei.value.errno == _errno.ENOTSUP
+    dfa.close()
