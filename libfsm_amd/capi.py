@@ -24,7 +24,7 @@ LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "c
 ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
 
-KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT, KNOB_QUEUE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 IN_DIRECT, IN_LDSDMA, IN_GENERIC = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -40,6 +40,8 @@ struct fsm_hip_dfa {
 	std::vector<uint32_t> enc_host;                  /* [S1] encoded state per renumbered state */
 	bool resume_ready = false;
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
+	unsigned long long *d_counter = nullptr;         /* work counter of walk_queue */
+	int knob_queue = -1;                             /* -1 auto: ragged fronts claim work per lane */
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -249,6 +251,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 	}
 	HIP_TRY(hipEventCreate(&d->ev0));
 	HIP_TRY(hipEventCreate(&d->ev1));
+	HIP_TRY(hipMalloc((void **)&d->d_counter, 16));
 	return d;
 fail:
 	{
@@ -270,6 +273,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
 	if (d->d_orig_of) (void)hipFree(d->d_orig_of);
 	if (d->d_emask) (void)hipFree(d->d_emask);
+	if (d->d_counter) (void)hipFree(d->d_counter);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -280,8 +284,9 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 struct LaunchCfg {
-	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch, nt;
+	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch, nt, queue;
 	uint32_t lds;
+	unsigned long long *counter;
 };
 
 static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
@@ -292,6 +297,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
+	c.queue = d->knob_queue != 0;
+	c.counter = d->d_counter;
 	/* every input line is consumed by exactly one DMA instruction (SEG = 128): nontemporal loads
 	 * measured +7.5 % on the HBM-bound tiny layout (profiles/r01_sweep8*), neutral elsewhere */
 	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : (layout == FSM_HIP_LAYOUT_TINY ? 1 : 0);
@@ -339,10 +346,25 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	return c;
 }
 
+/* ragged fronts: lanes claim inputs from a device counter (walk_queue); the counter and, if
+ * wanted, the bitmap (filled with atomicOr) are cleared on the launch stream first */
+template <class Pol>
+static hipError_t launch_queue(const LaunchCfg &c, const WalkArgs &a, unsigned long long *counter, dim3 grid, dim3 block, hipStream_t s)
+{
+	void (*k)(const WalkArgs, unsigned long long *) = walk_queue<Pol>;
+	hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+	if (e == hipSuccess && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ((a.n + 63) / 64) * sizeof(uint64_t), s);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, grid, block, c.lds, s, a, counter);
+	return hipGetLastError();
+}
+
 template <class Pol>
 static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	void (*k)(const WalkArgs) = nullptr;
+	if (c.mode == IN_GENERIC && c.queue) return launch_queue<Pol>(c, a, c.counter, grid, block, s);
 	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
 	else if (c.mode == IN_LDSDMA) {
 		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2> : walk_ldsdma<Pol, 128, 0>;
@@ -376,6 +398,7 @@ template <class Pol>
 static hipError_t launch_eager(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	void (*k)(const WalkArgs) = nullptr;
+	if (c.mode == IN_GENERIC && c.queue) return launch_queue<EagerPol<Pol>>(c, a, c.counter, grid, block, s);
 	if (c.mode == IN_GENERIC) k = walk_generic<EagerPol<Pol>>;
 	else k = walk_direct<EagerPol<Pol>, 4, 1>;
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
@@ -602,6 +625,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;
 	case FSM_HIP_KNOB_NT: d->knob_nt = value; break;
+	case FSM_HIP_KNOB_QUEUE: d->knob_queue = value; break;
 	case FSM_HIP_KNOB_HOT_BYTES:
 		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
 		set_hot_bytes(d, (uint32_t)value);

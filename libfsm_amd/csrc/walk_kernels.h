@@ -658,6 +658,101 @@ walk_generic(const WalkArgs a)
 }
 
 /* ------------------------------------------------------------------ */
+/* walk_queue: ragged inputs with per-lane work claiming               */
+/* ------------------------------------------------------------------ */
+
+/* per-lane result write (no wavefront-wide ballot: lanes finish at different times) */
+__device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i, uint32_t st)
+{
+	const uint32_t idx = st / a.fin_div;
+	const uint32_t end = a.fin[idx];
+	if (a.end_out != nullptr) a.end_out[i] = end;
+	if (a.out2 != nullptr) a.out2[i] = a.fin2[idx];
+	if (a.state_io != nullptr) a.state_io[i] = a.orig_of[idx];
+	if (a.bitmap != nullptr && end != FSMHIP_NO_MATCH)
+		atomicOr(reinterpret_cast<unsigned long long *>(a.bitmap + (i >> 6)), 1ull << (i & 63u)); /* bitmap pre-zeroed */
+}
+
+/*
+ * Ragged / packed inputs.  In walk_generic a wavefront owns 64 consecutive inputs and runs until
+ * the longest one ends, so with lengths uniform in [0, L] half the lane-steps are idle.  Here every
+ * lane claims its next input from a global counter as soon as its current one ends (one
+ * wave-aggregated atomicAdd per refill: ballot, popcount, prefix rank), and an input that reaches
+ * an absorbing state ends right there -- fsm_exec's own per-input early exit (exec.c:133-138).
+ * Inputs are claimed in index order, so neighbouring lanes start on neighbouring (packed) inputs.
+ */
+template <class Pol>
+__global__ void __launch_bounds__(1024)
+walk_queue(const WalkArgs a, unsigned long long *counter)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	Pol pol;
+	pol.setup(lds, a);
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u;
+	bool have = false;
+	uint64_t i = 0, q0 = 0, span = 0, c = 0, nchunks = 0;
+	uint32_t head = 0;
+	typename Pol::S st[1] = { pol.init(a.start) };
+	u32x4 w[1] = { {0u, 0u, 0u, 0u} };
+
+	for (;;) {
+		/* refill the lanes without work */
+		const uint64_t need = __ballot(!have);
+		if (need != 0) {
+			unsigned long long base = 0;
+			if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(need));
+			base = __shfl(base, __builtin_ctzll(need));
+			if (!have) {
+				i = base + (uint64_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+				if (i < a.n) {
+					uint64_t beg, len;
+					if (a.off != nullptr) { beg = a.off[i]; len = a.off[i + 1] - beg; }
+					else { beg = i * a.stride; len = a.len != nullptr ? a.len[i] : a.stride; }
+					const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
+					q0 = p0 & ~(uint64_t)15;
+					head = (uint32_t)(p0 - q0);
+					span = len ? head + len : 0;
+					nchunks = (span + 15u) / 16u;
+					c = 0;
+					st[0] = pol.init(start_code(a, i, true));
+					have = true;
+					if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
+				}
+			}
+		}
+		if (!__any(have)) break;
+		if (have) {
+			if (c < nchunks) {
+				u32x4 wn = {0u, 0u, 0u, 0u};
+				if (c + 1 < nchunks) wn = *reinterpret_cast<const u32x4 *>(q0 + (c + 1) * 16u);
+				const uint32_t lo = c == 0 ? head : 0u;
+				const uint64_t left = span - c * 16u;
+				const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
+				if (__all(lo == 0u && hi == 16u)) {
+					step16<Pol, 1>(pol, st, w);
+				} else {
+					const uint32_t cnt = hi - lo;
+#pragma unroll
+					for (int k = 0; k < 16; k++) {
+						const typename Pol::S nx = pol.next(st[0], pol.pre(byte_of(w[0], k)));
+						st[0] = ((uint32_t)k - lo) < cnt ? nx : st[0];
+					}
+				}
+				w[0] = wn;
+				c++;
+			}
+			if (c >= nchunks || ((a.early & 1u) && Pol::code(st[0]) >= a.abs_min)) {
+				write_result_lane(a, i, Pol::code(st[0]));
+				Pol::finish(a, i, true, st[0]);
+				have = false;
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
 /* synthetic input generator                                          */
 /* ------------------------------------------------------------------ */
 

@@ -121,9 +121,13 @@ def test_ragged_lengths_and_empty_inputs(hip):
         lens[:5] = [0, 1, 15, 16, 17]
         ret, want = Oracle(g.flat).exec_stride(rows, lens)
         for L, dfa in layouts_for(hip, g.flat):
-            end, bm = dfa.exec_batch(rows, lens)
-            assert np.array_equal(end, want), (name, L)
-            assert np.array_equal(bits(bm, len(rows)), ret == 1)
+            for queue in (1, 0):          # per-lane work claiming (default) and fixed 64 inputs per wave
+                dfa.tune(hip.KNOB_QUEUE, queue)
+                for early in (1, 0):
+                    dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                    end, bm = dfa.exec_batch(rows, lens)
+                    assert np.array_equal(end, want), (name, L, queue, early)
+                    assert np.array_equal(bits(bm, len(rows)), ret == 1)
             dfa.close()
 
 
@@ -145,8 +149,11 @@ def test_packed_unaligned_offsets(hip):
     ret, want = Oracle(g.flat).exec_strings(strings)
     assert (ret == 1).sum() > 1000
     for L, dfa in layouts_for(hip, g.flat):
-        end, bm = dfa.exec_strings(strings)
-        assert np.array_equal(end, want), L
+        for queue in (1, 0):
+            dfa.tune(hip.KNOB_QUEUE, queue)
+            end, bm = dfa.exec_strings(strings)
+            assert np.array_equal(end, want), (L, queue)
+            assert np.array_equal(bits(bm, len(strings)), ret == 1)
         dfa.close()
 
 

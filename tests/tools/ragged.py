@@ -40,7 +40,8 @@ def main():
             idx = np.random.RandomState(0).randint(0, n, 1024)
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
-            for front in ("stride+len", "packed"):
+            for front, queue in (("stride+len", 1), ("stride+len", 0), ("packed", 1), ("packed", 0)):
+                dfa.tune(hip.KNOB_QUEUE, queue)
                 ms = []
                 for r in range(4):
                     if front == "packed":
@@ -52,7 +53,7 @@ def main():
                         ms.append(t)
                 torch.cuda.synchronize()
                 ok = np.array_equal(end.cpu().numpy().view(np.uint32)[idx], want)
-                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} ms={min(ms):8.3f} "
+                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} queue={queue} ms={min(ms):8.3f} "
                       f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
             dfa.close()
 
