@@ -28,7 +28,7 @@ enum {
 	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */
 	FSM_HIP_KNOB_PREFETCH      = 10, /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
 	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
-	FSM_HIP_KNOB_QUEUE         = 12  /* ragged fronts: 1 = lanes claim inputs from a counter (default), 0 = 64 fixed inputs per wave */
+	FSM_HIP_KNOB_QUEUE         = 12  /* ragged fronts: 1 = lanes claim inputs from a device counter (walk_queue); default 0 = 64 fixed inputs per wave */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);

@@ -41,7 +41,7 @@ struct fsm_hip_dfa {
 	bool resume_ready = false;
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	unsigned long long *d_counter = nullptr;         /* work counter of walk_queue */
-	int knob_queue = -1;                             /* -1 auto: ragged fronts claim work per lane */
+	int knob_queue = -1;                             /* > 0: ragged fronts claim work per lane (walk_queue) */
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -297,7 +297,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nb = 1;
 	c.rows = 1;
 	c.seg = 64;
-	c.queue = d->knob_queue != 0;
+	c.queue = d->knob_queue > 0; /* opt-in: measured 2-4x slower than fixed assignment (profiles/r01_ragged.txt) */
 	c.counter = d->d_counter;
 	/* every input line is consumed by exactly one DMA instruction (SEG = 128): nontemporal loads
 	 * measured +7.5 % on the HBM-bound tiny layout (profiles/r01_sweep8*), neutral elsewhere */
