@@ -239,8 +239,8 @@ try {
 	};
 	auto emit_combself = [&]() -> int {
 		if (C > 32 || has_eager) return ENOTSUP;
-		/* image = comb + masks: half the room each */
-		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 8u, 65535u);
+		/* LDS image = 8 bytes per comb entry (entry + mask of its target) + 128 */
+		uint32_t max_entries = lds_room > 128u ? (uint32_t)std::min<uint64_t>((lds_room - 128u) / 8u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
 		p.comb_smask.assign(p.comb.size(), 0u);

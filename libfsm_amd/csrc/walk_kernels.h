@@ -254,18 +254,22 @@ struct CombSelfPol {
 	typedef uint32_t P;
 	typedef CombSelfState S;
 	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
-	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
-	const uint32_t *smask;  /* LDS, indexed by row offset: self-loop mask of that state */
+	const uint2 *comb;      /* LDS comb array of {owner_off << 16 | next_off, smask(next)}:
+	                         * one ds_read_b64 brings the next state AND its self-loop mask */
+	const uint32_t *dsm;    /* LDS [32]: self-loop mask of each class's default state   */
+	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
+		/* device image = comb64[n] (8 B each), dsm[32], smask[n]; LDS gets the first two parts */
 		bp = setup_btab(lds, a);
-		copy_table(lds + FSMHIP_BTAB_BYTES, a); /* image = comb[n] followed by smask[n] */
-		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
-		smask = comb + a.tab_bytes / 8u;
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		comb = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES);
+		dsm = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES + a.tab_bytes - 128u);
+		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
 	}
-	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask[code] }; return s; }
+	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask0[code] }; return s; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
@@ -273,9 +277,15 @@ struct CombSelfPol {
 	{
 		const uint32_t c = be & 0xffffu;
 		if (!((s.sm >> c) & 1u)) {
-			const uint32_t x = comb[s.st + c] ^ (s.st << 16);
-			s.st = x < 0x10000u ? x : (be >> 16);
-			s.sm = smask[s.st];
+			const uint2 e = comb[s.st + c];
+			const uint32_t x = e.x ^ (s.st << 16);
+			if (x < 0x10000u) {
+				s.st = x;
+				s.sm = e.y;
+			} else { /* no exception here: the class's default state (rare: mostly dying lanes) */
+				s.st = be >> 16;
+				s.sm = dsm[c];
+			}
 		}
 		return s;
 	}
