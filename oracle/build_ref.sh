@@ -61,7 +61,7 @@ ar rcs "$OUT/libfsmre.a" "$OUT"/obj/*.o
 # -Bsymbolic: libfsm's re_comp() would otherwise be interposed by glibc's BSD
 # re_comp() once loaded into a process such as python.
 gcc -std=c99 -O2 -fPIC -D_POSIX_C_SOURCE=200809L -I$R/include -c "$HERE/ref_helper.c" -o "$OUT/ref_helper.o"
-gcc -shared -Wl,-Bsymbolic -o "$OUT/libfsm_ref.so" -Wl,--whole-archive "$OUT/libfsmre.a" -Wl,--no-whole-archive "$OUT/ref_helper.o"
+gcc -shared -Wl,-Bsymbolic -o "$OUT/libfsm_ref.so" -Wl,--whole-archive "$OUT/libfsmre.a" -Wl,--no-whole-archive "$OUT/ref_helper.o" -lpthread
 gcc $CF -D_XOPEN_SOURCE=700 $R/src/re/main.c "$OUT/libfsmre.a" -o "$OUT/re"
 gcc -std=gnu99 -O2 -DNDEBUG -I$R/include -I$R/src $R/src/retest/main.c $R/src/retest/runner.c "$OUT/libfsmre.a" -ldl -o "$OUT/retest"
 echo "built: $(ls "$OUT"/obj/*.o | wc -l) objects -> $OUT/libfsmre.a, libfsm_ref.so, re, retest"

@@ -208,6 +208,8 @@ class Ref:
             H.rh_vm_match_batch_stride.argtypes = [vp, vp, sz, sz, vp]
             H.rh_vm_match_batch.restype = C.c_double
             H.rh_vm_match_batch.argtypes = [vp, vp, vp, sz, vp]
+            H.rh_match_threads.restype = C.c_double
+            H.rh_match_threads.argtypes = [vp, vp, vp, sz, sz, C.c_int, C.c_int, C.POINTER(C.c_ulong)]
             H.rh_parse_fsm_file.restype = vp
             H.rh_parse_fsm_file.argtypes = [C.c_char_p]
             H.rh_generate_matches.restype = sz
@@ -363,6 +365,20 @@ class RefFsm:
         self.last_seconds = H.rh_vm_match_batch_stride(vm, _p(data), stride, n, _p(ret))
         H.rh_vm_free(vm)
         return ret
+
+    def match_threads(self, data: np.ndarray, nthreads: int, reps: int = 1, use_vm: int = 2):
+        """The reference matcher on `nthreads` host threads over contiguous slices of the rows
+        (use_vm 1/2: DFAVM bytecode version; 0: literal fsm_exec).  Returns (GB/s, accepts)."""
+        _, H = Ref.libs()
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        vm = H.rh_vm_compile(self.ptr, use_vm) if use_vm else None
+        m = C.c_ulong(0)
+        t = H.rh_match_threads(vm, self.ptr, _p(data), stride, n, nthreads, reps, C.byref(m))
+        if vm:
+            H.rh_vm_free(vm)
+        self.last_seconds = t
+        return data.size * reps / t / 1e9, int(m.value)
 
     def flatten(self):
         """struct fsm * -> FlatDfa through the PRODUCT's shim (fsm_hip_flatten)."""

@@ -439,3 +439,91 @@ rh_generate_matches(const struct fsm *fsm, size_t maxlen, unsigned seed, unsigne
 	fsm_free(c);
 	return env.used;
 }
+
+/* ---- all-cores CPU baseline ------------------------------------------------------ */
+
+#include <pthread.h>
+
+struct mt_job {
+	const struct fsm_dfavm *vm;
+	const struct fsm *fsm;
+	const unsigned char *base;
+	size_t stride, first, count;
+	int reps;
+	unsigned long matched;
+};
+
+static void *
+mt_worker(void *p)
+{
+	struct mt_job *j = p;
+	unsigned long m = 0;
+	int r;
+	size_t i;
+	for (r = 0; r < j->reps; r++) {
+		for (i = 0; i < j->count; i++) {
+			const unsigned char *row = j->base + (j->first + i) * j->stride;
+			if (j->vm != NULL) {
+				m += (unsigned long) fsm_vm_match_buffer(j->vm, (const char *) row, j->stride);
+			} else {
+				unsigned e;
+				m += rh_exec(j->fsm, row, j->stride, &e) == 1;
+			}
+		}
+	}
+	j->matched = m;
+	return NULL;
+}
+
+/* The reference's matcher on nthreads host threads: the n rows are split into contiguous slices,
+ * one per thread, each walked `reps` times (the compiled VM / the fsm are shared read-only; the
+ * reference has no threading of its own, src/libfsm is single-threaded).  vm != NULL: DFAVM
+ * fsm_vm_match_buffer; else literal fsm_exec.  Returns wall seconds; *matched = accepts of one pass. */
+double
+rh_match_threads(const struct fsm_dfavm *vm, const struct fsm *fsm, const unsigned char *base, size_t stride, size_t n,
+	int nthreads, int reps, unsigned long *matched)
+{
+	pthread_t *th;
+	struct mt_job *jobs;
+	struct timespec t0, t1;
+	int t;
+	unsigned long total = 0;
+
+	if (nthreads < 1) {
+		nthreads = 1;
+	}
+	th = calloc((size_t) nthreads, sizeof *th);
+	jobs = calloc((size_t) nthreads, sizeof *jobs);
+	if (th == NULL || jobs == NULL) {
+		free(th);
+		free(jobs);
+		return -1.0;
+	}
+	for (t = 0; t < nthreads; t++) {
+		jobs[t].vm = vm;
+		jobs[t].fsm = fsm;
+		jobs[t].base = base;
+		jobs[t].stride = stride;
+		jobs[t].first = n * (size_t) t / (size_t) nthreads;
+		jobs[t].count = n * (size_t) (t + 1) / (size_t) nthreads - jobs[t].first;
+		jobs[t].reps = reps;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (t = 0; t < nthreads; t++) {
+		if (pthread_create(&th[t], NULL, mt_worker, &jobs[t]) != 0) {
+			nthreads = t;
+			break;
+		}
+	}
+	for (t = 0; t < nthreads; t++) {
+		pthread_join(th[t], NULL);
+		total += jobs[t].matched;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if (matched != NULL) {
+		*matched = reps > 0 ? total / (unsigned long) reps : 0;
+	}
+	free(th);
+	free(jobs);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
