@@ -99,14 +99,21 @@ def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample):
         assert np.array_equal(vm == 1, want != 0xFFFFFFFF), "reference VM != fsm_exec"
         # all host cores: the reference itself is single-threaded, so its fastest matcher (VM v2) is run
         # on one thread per core over slices of the sample, repeated to ~1-2 s of wall time
-        ncores = os.cpu_count() or 1
-        reps = max(1, int(1.5 * ncores * (gb / t_vm) / gb))
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:  # a container may be CPU-throttled far below the visible core count
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q == "max" else round(int(q) / int(per), 2)
+        except Exception:
+            pass
+        probe, _ = f.match_threads(rows, ncores, 1, 2)          # one pass to size the timed run (~2 s)
+        reps = max(1, min(2000, int(2.0 * probe / gb)))
         allc, acc = f.match_threads(rows, ncores, reps, 2)
         assert acc == int((want != 0xFFFFFFFF).sum()), "threaded VM run disagrees"
         out.update(kind="reference", value=round(nfe * L / 1e9 / t_exec, 5),
                    sample=f"reference fsm_exec (src/libfsm/exec.c) with a (ptr,len) getc, 1 thread, first {nfe} inputs x {L} B of the same generator stream",
                    vm_v2_value=round(gb / t_vm, 5), vm_v2_sample=f"reference fsm_vm_match_buffer v2, 1 thread, {sample} inputs",
-                   vm_v2_allcores_value=round(allc, 3), vm_v2_allcores_cores=ncores,
+                   vm_v2_allcores_value=round(allc, 3), vm_v2_allcores_cores=ncores, vm_v2_allcores_cgroup_cpu_quota=quota,
                    vm_v2_allcores_sample=f"same VM shared read-only by {ncores} threads, each walking its slice of the {sample}-input sample {reps}x")
     else:
         o = pyoracle.Oracle(flat)
