@@ -106,7 +106,10 @@ def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample):
             quota = None if q == "max" else round(int(q) / int(per), 2)
         except Exception:
             pass
-        probe, _ = f.match_threads(rows, ncores, 1, 2)          # one pass to size the timed run (~2 s)
+        if quota:
+            ncores = max(1, min(ncores, int(quota + 0.5)))          # threads = cores the cgroup really grants
+        f.match_threads(rows, ncores, 1, 2)                         # untimed pass (burst credit, page faults)
+        probe, _ = f.match_threads(rows, ncores, 2, 2)              # sizes the timed run (~2 s)
         reps = max(1, min(2000, int(2.0 * probe / gb)))
         allc, acc = f.match_threads(rows, ncores, reps, 2)
         assert acc == int((want != 0xFFFFFFFF).sum()), "threaded VM run disagrees"
