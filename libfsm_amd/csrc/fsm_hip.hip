@@ -154,19 +154,22 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			 * -- these two parts go to LDS (tab_bytes) -- then smask[n] by row offset (global only) */
 			uint32_t *t = nullptr;
 			const size_t n = p.comb.size();
-			std::vector<uint32_t> img(2 * n + 32 + n, 0);
+			std::vector<uint32_t> img(2 * n + 64 + n, 0);
 			for (size_t k = 0; k < n; k++) {
 				img[2 * k] = p.comb[k];
 				const uint32_t nxt = p.comb[k] & 0xffffu;
 				img[2 * k + 1] = (p.comb[k] >> 16) != 0xFFFFu && nxt < n ? p.comb_smask[nxt] : 0u;
 			}
-			for (uint32_t c = 0; c < p.C; c++) img[2 * n + c] = p.comb_smask[p.comb_dflt[c]];
-			for (size_t k = 0; k < n; k++) img[2 * n + 32 + k] = p.comb_smask[k];
+			for (uint32_t c = 0; c < p.C; c++) {
+				img[2 * n + 2 * c] = p.comb_dflt[c];
+				img[2 * n + 2 * c + 1] = p.comb_smask[p.comb_dflt[c]];
+			}
+			for (size_t k = 0; k < n; k++) img[2 * n + 64 + k] = p.comb_smask[k];
 			HIP_TRY(upload(&t, img));
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.comb_fin));
-			for (int b = 0; b < 256; b++) btab[b] = (p.comb_dflt[p.cls[b]] << 16) | p.cls[b];
-			a.tab_bytes = (uint32_t)((2 * n + 32) * 4);
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
+			a.tab_bytes = (uint32_t)((2 * n + 64) * 4);
 			a.start = p.comb_off[p.start];
 			a.abs_min = p.comb_abs_min_off;
 			a.fin_div = 1;
@@ -191,7 +194,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			HIP_TRY(upload(&t, p.lds_tab));
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.fin));
-			for (int b = 0; b < 256; b++) btab[b] = p.cls[b] * 2u;
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
 			a.tab_bytes = (uint32_t)(p.lds_tab.size() * 2);
 			a.start = p.start * p.row_bytes;
 			a.abs_min = p.abs_min * p.row_bytes;
@@ -201,11 +204,14 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		}
 		case FSM_HIP_LAYOUT_COMB: {
 			uint32_t *t = nullptr;
-			HIP_TRY(upload(&t, p.comb));
+			std::vector<uint32_t> img(p.comb);               /* image = comb[n], dflt[256] */
+			img.resize(p.comb.size() + 256, 0);
+			for (uint32_t c = 0; c < p.C; c++) img[p.comb.size() + c] = p.comb_dflt[c];
+			HIP_TRY(upload(&t, img));
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.comb_fin));
-			for (int b = 0; b < 256; b++) btab[b] = (p.comb_dflt[p.cls[b]] << 16) | p.cls[b];
-			a.tab_bytes = (uint32_t)(p.comb.size() * 4);
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
+			a.tab_bytes = (uint32_t)(img.size() * 4);
 			a.start = p.comb_off[p.start];
 			a.abs_min = p.comb_abs_min_off;
 			a.fin_div = 1;
@@ -217,7 +223,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			HIP_TRY(upload(&t, p.glob_tab));
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.fin));
-			for (int b = 0; b < 256; b++) btab[b] = p.cls[b] * 4u;
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
 			a.start = p.start * p.C * 4u;
 			a.abs_min = p.abs_min * p.C * 4u;
 			a.fin_div = p.C * 4u;
@@ -611,9 +617,9 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	switch (p.layout) {
 	case FSM_HIP_LAYOUT_TINY: out->table_bytes = 256 * 8; break;
 	case FSM_HIP_LAYOUT_LDS: out->table_bytes = p.lds_tab.size() * 2; break;
-	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4; break;
+	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
-	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8 + 128; break;
+	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8 + 256; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
 	LaunchCfg c = pick_cfg(d, true, 1024);

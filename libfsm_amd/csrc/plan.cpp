@@ -25,7 +25,7 @@ namespace fsmhip {
 static const uint32_t NOEDGE = 0xFFFFFFFFu;
 
 uint32_t lds_bytes_tiny() { return 256u * 32u * 8u; }
-uint32_t lds_bytes_btab() { return 256u * 32u * 4u; }
+uint32_t lds_bytes_btab() { return 256u; }
 
 static int build_comb(Plan &p, uint32_t max_entries, bool bytewise);
 
@@ -231,7 +231,7 @@ try {
 	};
 	auto emit_comb = [&]() -> int {
 		if (has_eager) return ENOTSUP; /* comb offsets do not keep the eager ordering */
-		uint32_t max_entries = (uint32_t)std::min<uint64_t>(lds_room / 4u, 65535u);
+		uint32_t max_entries = lds_room > 1024u ? (uint32_t)std::min<uint64_t>((lds_room - 1024u) / 4u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
 		p.layout = FSM_HIP_LAYOUT_COMB;
@@ -239,8 +239,8 @@ try {
 	};
 	auto emit_combself = [&]() -> int {
 		if (C > 32 || has_eager) return ENOTSUP;
-		/* LDS image = 8 bytes per comb entry (entry + mask of its target) + 128 */
-		uint32_t max_entries = lds_room > 128u ? (uint32_t)std::min<uint64_t>((lds_room - 128u) / 8u, 65535u) : 0u;
+		/* LDS image = 8 bytes per comb entry (entry + mask of its target) + 256 */
+		uint32_t max_entries = lds_room > 256u ? (uint32_t)std::min<uint64_t>((lds_room - 256u) / 8u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
 		p.comb_smask.assign(p.comb.size(), 0u);

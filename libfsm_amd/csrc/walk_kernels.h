@@ -16,7 +16,7 @@
  *              bank l%32: conflict-free by construction.  pre = the column,
  *              next = shift+mask: the state chain never touches memory.
  *   LdsPol     class-compressed dense table T[state][class] (u16) in LDS plus a
- *              bank-private byte->class table B[256][32] (conflict-free).
+ *              256-byte byte->class map (conflict-free for 7-bit text, <= 2-way otherwise).
  *   CombPol    column-default + comb exceptions over byte CLASSES (B table
  *              carries class and per-class default), see plan.cpp.
  *   Comb256Pol comb exceptions over raw BYTES with one default state for every
@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t start_code(const WalkArgs &a, uint64_t i, bo
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2 };
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
-#define FSMHIP_BTAB_BYTES (256u * 32u * 4u)
+#define FSMHIP_BTAB_BYTES 256u
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -140,11 +140,20 @@ struct TinyPol {
 	}
 };
 
-__device__ __forceinline__ const uint32_t *setup_btab(unsigned char *lds, const WalkArgs &a)
+/*
+ * byte -> class map: 256 u8 entries = 64 LDS dwords over 32 banks.  Lanes reading different bytes of
+ * one dword are served by a broadcast, and only dwords d and d+32 (bytes b and b+128) share a bank,
+ * so a lookup is conflict-free for 7-bit text and at most 2-way for arbitrary bytes -- a 256-byte
+ * table does what a bank-private [256][32] copy (32 KiB) was first used for.
+ */
+__device__ __forceinline__ const uint8_t *setup_btab(unsigned char *lds, const WalkArgs &a)
 {
-	uint32_t *B = reinterpret_cast<uint32_t *>(lds);
-	for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) B[i] = a.btab[i >> 5];
-	return B + (threadIdx.x & 31u);
+	for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) {
+		const uint32_t k = 4u * i;
+		reinterpret_cast<uint32_t *>(lds)[i] = (a.btab[k] & 0xffu) | ((a.btab[k + 1] & 0xffu) << 8) |
+			((a.btab[k + 2] & 0xffu) << 16) | ((a.btab[k + 3] & 0xffu) << 24);
+	}
+	return lds;
 }
 
 __device__ __forceinline__ void copy_table(unsigned char *dst, const WalkArgs &a)
@@ -161,7 +170,7 @@ struct LdsPol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 2      */
+	const uint8_t *bp;         /* LDS byte -> class map                           */
 	const unsigned char *tab;  /* LDS table; state is a byte offset into it      */
 	uint32_t abs_min;
 
@@ -173,14 +182,14 @@ struct LdsPol {
 		tab = lds + FSMHIP_BTAB_BYTES;
 		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P ca) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
 		if (MASK) {
-			if (st < abs_min) st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + ca)) << 2;
+			if (st < abs_min) st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + c * 2u)) << 2;
 			return st;
 		}
-		return (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + ca)) << 2;
+		return (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + c * 2u)) << 2;
 	}
 };
 
@@ -191,8 +200,9 @@ struct CombPol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
+	const uint8_t *bp;      /* LDS byte -> class map                                    */
 	const uint32_t *comb;   /* LDS comb array; state = row offset in entries            */
+	const uint32_t *dfl;    /* LDS [C]: row offset of each class's default state        */
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -201,14 +211,15 @@ struct CombPol {
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
+		dfl = comb + a.tab_bytes / 4u - 256u; /* image = comb[n], dflt[256] */
 		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P be) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
 		if (MASK && st >= abs_min) return st;
-		const uint32_t x = comb[st + (be & 0xffffu)] ^ (st << 16);
-		return x < 0x10000u ? x : (be >> 16);
+		const uint32_t x = comb[st + c] ^ (st << 16);
+		return x < 0x10000u ? x : dfl[c];
 	}
 };
 
@@ -253,29 +264,28 @@ struct CombSelfState { uint32_t st, sm; };
 struct CombSelfPol {
 	typedef uint32_t P;
 	typedef CombSelfState S;
-	const uint32_t *bp;     /* LDS B table + lane%32 ; entry = (dflt_off << 16) | class */
+	const uint8_t *bp;      /* LDS byte -> class map                                    */
 	const uint2 *comb;      /* LDS comb array of {owner_off << 16 | next_off, smask(next)}:
 	                         * one ds_read_b64 brings the next state AND its self-loop mask */
-	const uint32_t *dsm;    /* LDS [32]: self-loop mask of each class's default state   */
+	const uint2 *dsm;       /* LDS [32]: {row offset, self-loop mask} of each class's default state */
 	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		/* device image = comb64[n] (8 B each), dsm[32], smask[n]; LDS gets the first two parts */
+		/* device image = comb64[n] (8 B each), dsm[32] (8 B each), smask[n]; LDS gets the first two parts */
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		comb = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES);
-		dsm = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES + a.tab_bytes - 128u);
+		dsm = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES + a.tab_bytes - 256u);
 		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
 	}
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask0[code] }; return s; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
-	__device__ __forceinline__ S next(S s, P be) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ S next(S s, P c) const
 	{
-		const uint32_t c = be & 0xffffu;
 		if (!((s.sm >> c) & 1u)) {
 			const uint2 e = comb[s.st + c];
 			const uint32_t x = e.x ^ (s.st << 16);
@@ -283,8 +293,9 @@ struct CombSelfPol {
 				s.st = x;
 				s.sm = e.y;
 			} else { /* no exception here: the class's default state (rare: mostly dying lanes) */
-				s.st = be >> 16;
-				s.sm = dsm[c];
+				const uint2 d = dsm[c];
+				s.st = d.x;
+				s.sm = d.y;
 			}
 		}
 		return s;
@@ -298,7 +309,7 @@ struct GlobPol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	const uint32_t *bp;        /* LDS B table + lane%32 ; entry = class * 4                */
+	const uint8_t *bp;         /* LDS byte -> class map                                    */
 	const unsigned char *tab;  /* device table; state is a byte offset into it             */
 	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
 	uint32_t hot_bytes;        /* nearest the start state (breadth-first numbering)        */
@@ -314,12 +325,12 @@ struct GlobPol {
 		tab = static_cast<const unsigned char *>(a.tab);
 		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b * 32u]; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P ca) const
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
 		if (MASK && st >= abs_min) return st;
-		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + ca);
-		return *reinterpret_cast<const uint32_t *>(tab + st + ca);
+		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
+		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
 	}
 };
 

@@ -91,6 +91,9 @@ def main():
                 variants += [(hip.IN_LDSDMA, 128, 1, 8, 0, 0, 0), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 0)]
                 variants += [(hip.IN_DIRECT, nb, 1, w, b, 2, 1) for nb in (4, 8) for w in (16, 8) for b in (0, 4)]  # mask=2: no-prefetch kernel
                 variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
+            if a.set == "dma":  # LDS-DMA staging next to an LDS table: how many waves fit / pay
+                variants = [(hip.IN_LDSDMA, 128, 1, w, b, m, 1) for w in (16, 14, 12, 10, 8) for b in (0, 1) for m in (0, 4)]
+                variants += [(hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 2, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]
             if a.set == "nt":  # nontemporal LDS-DMA input loads (mask bit 2)
                 variants = [(hip.IN_LDSDMA, 128, 1, w, 0, m, 1) for w in (4, 8, 16) for m in (0, 4)]
                 variants += [(hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]
