@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0)
+    ap.add_argument("--knob", action="append", default=[], help="K=V: raw fsm_hip_dfa_tune knob (see include/fsm_hip_plan.h)")
     ap.add_argument("--no-early-retire", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="inputs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,6 +158,9 @@ def main():
                     (hip.KNOB_WAVES, a.waves), (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu), (hip.KNOB_MASK, a.mask)):
         if v > 0 or (knob in (hip.KNOB_INPUT_MODE, hip.KNOB_MASK) and v >= 0):
             dfa.tune(knob, v)
+    for kv in a.knob:
+        k, v = kv.split("=")
+        dfa.tune(int(k), int(v))
     info = dfa.info()
 
     L = a.len
