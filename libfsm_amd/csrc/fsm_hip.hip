@@ -316,7 +316,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.counter = d->d_counter;
 	/* every input line is consumed by exactly one DMA instruction (SEG = 128): nontemporal loads
 	 * measured +7.5 % on the HBM-bound tiny layout (profiles/r01_sweep8*), neutral elsewhere */
-	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : (layout == FSM_HIP_LAYOUT_TINY ? 1 : 0);
+	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : 1;
 	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
 	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
 	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF ? 0 : 1);
@@ -327,7 +327,11 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	if (fast_ok) {
 		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging wins while the table leaves room for
 		 * per-wave tiles; per-lane loads with 8 chunks in flight win next to a big LDS table */
-		int mode = layout == FSM_HIP_LAYOUT_TINY ? IN_LDSDMA : IN_DIRECT;
+		/* LDS-DMA tiles (8 KiB per wave) are the better input path whenever at least 12 waves of
+		 * them fit next to the table (profiles/r01_sweep10*: lds layout 5.1 vs 4.8 TB/s); the
+		 * latency-bound CombSelfPol prefers 2 x 16 waves of the register-light direct kernel */
+		const bool dma_fits = d->table_lds + 12u * 8192u <= d->lds_limit;
+		int mode = (layout == FSM_HIP_LAYOUT_TINY || (dma_fits && layout != FSM_HIP_LAYOUT_COMBSELF)) ? IN_LDSDMA : IN_DIRECT;
 		if (d->knob_input_mode >= 0) mode = d->knob_input_mode;
 		if (mode == IN_LDSDMA && stride % 64u != 0) mode = IN_DIRECT;
 		c.mode = mode;
@@ -348,7 +352,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	 * table + 16 x 8 KiB tiles = all 160 KiB of LDS) measured best for tiny (profiles/r01_sweep8*) */
 	int waves = d->knob_waves > 0 ? d->knob_waves : 16;
 	if (waves > 16) waves = 16;
-	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves >>= 1;
+	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
 	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
