@@ -216,6 +216,10 @@ void fsm_hip_desc_free(struct fsm_hip_dfa_desc *desc);
 int fsm_hip_desc_write(const struct fsm_hip_dfa_desc *desc, FILE *f);
 struct fsm_hip_dfa_desc *fsm_hip_desc_read(FILE *f);
 
+/* One more "language" in the shape of fsm_print()'s printers (src/libfsm/print.c:242-416):
+ * flatten `fsm` and write its table in the on-disk form.  0, or -1 + errno. */
+int fsm_hip_print(FILE *f, const struct fsm *fsm);
+
 /* ------------------------------------------------------------------ */
 /* streaming: inputs that arrive in pieces                            */
 /* ------------------------------------------------------------------ */

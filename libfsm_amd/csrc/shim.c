@@ -572,3 +572,30 @@ bad:
 	errno = EINVAL;
 	return NULL;
 }
+
+/* ---- printer: struct fsm * -> on-disk table -------------------------- */
+
+/* The shape of one more fsm_print() language (src/libfsm/print.c:242-416 dispatches
+ * FSM_PRINT_C, _VMC, ... to printers taking (FILE *, fsm)): writes the executable table of `fsm`
+ * in the FSMHIP on-disk form, ready for fsm_hip_desc_read() + fsm_hip_dfa_create() in a process
+ * that has no libfsm at all.  0 on success, -1 + errno (EINVAL: not a DFA / no start). */
+int
+fsm_hip_print(FILE *f, const struct fsm *fsm)
+{
+	struct fsm_hip_dfa_desc *desc;
+	int r, e;
+
+	if (f == NULL) {
+		errno = EINVAL;
+		return -1;
+	}
+	desc = fsm_hip_flatten(fsm);
+	if (desc == NULL) {
+		return -1;
+	}
+	r = fsm_hip_desc_write(desc, f);
+	e = errno;
+	fsm_hip_desc_free(desc);
+	errno = e;
+	return r;
+}

@@ -610,3 +610,37 @@ def test_error_contracts(hip):
         hip.HipDfa(flat)
     assert ei.value.errno == _errno.ENOTSUP
     dfa.close()
+
+
+def test_printer_and_standalone_c_caller(hip, tmp_path):
+    """fsm_hip_print() (a printer in fsm_print's shape) writes the table of a reference-built rx-style
+    union; examples/hipgrep.c -- plain C, no libfsm in the process -- loads it, matches a file of
+    records in one launch and prints line:end-ids; compared with fsm_exec + fsm_endid_get."""
+    _need_ref()
+    import subprocess
+    from oracle.pyoracle import RefFsm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pats = [b"^GET /[a-z]+$", b"^POST /api/v[0-9]+/[a-z_]+$", b"error: .*timeout", b"^[0-9]{1,3}(\\.[0-9]{1,3}){3}$", b"^GET /index$"]
+    f = RefFsm.union_res("pcre", pats, 0)
+    lib = hip.load_library()
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    table = str(tmp_path / "t.fsmhip")
+    fp = libc.fopen(table.encode(), b"wb")
+    assert lib.fsm_hip_print(ctypes.c_void_p(fp), ctypes.c_void_p(f.ptr)) == 0
+    libc.fclose(ctypes.c_void_p(fp))
+    rng = np.random.RandomState(6)
+    lines = [b"GET /index", b"GET /about", b"POST /api/v2/create_user", b"10.0.0.1", b"256.1.2.3", b"disk error: io timeout now",
+             b"", b"GET /Index", b"POST /api/vx/y", b"error: timeout"]
+    lines += [bytes(rng.choice(list(b"GET/POSTapiv0123456789.error: timeout_"), rng.randint(0, 30)).astype(np.uint8)) for _ in range(500)]
+    exe = str(tmp_path / "hipgrep")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "hipgrep.c"), "-o", exe,
+                           "-L" + os.path.join(root, "libfsm_amd"), "-lfsm_hip", "-Wl,-rpath," + os.path.join(root, "libfsm_amd")])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, table], input=b"\n".join(lines) + b"\n", capture_output=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ret, end = f.exec_strings(lines)
+    want = [f"{i + 1}:" + ",".join(str(int(x)) for x in f.endids(int(end[i]))) for i in range(len(lines)) if ret[i] == 1]
+    assert out.stdout.decode().split() == want
+    assert len(want) >= 6
