@@ -644,3 +644,76 @@ def test_printer_and_standalone_c_caller(hip, tmp_path):
     want = [f"{i + 1}:" + ",".join(str(int(x)) for x in f.endids(int(end[i]))) for i in range(len(lines)) if ret[i] == 1]
     assert out.stdout.decode().split() == want
     assert len(want) >= 6
+
+
+def _random_regex(rng, depth=0):
+    """A small PCRE generator in the spirit of the reference's fuzz/theft harnesses (fuzz/target.c,
+    theft/fuzz_literals.c): literals, classes, alternation, groups, repetition, anchors."""
+    atoms = ["a", "b", "c", "ab", "[abc]", "[a-d]", "[^a]", ".", "x", "\\d", "[0-9]", "b?", "(?:ab)"]
+    n = rng.randint(1, 5)
+    parts = []
+    for _ in range(n):
+        r = rng.rand()
+        if depth < 2 and r < 0.25:
+            inner = "|".join(_random_regex(rng, depth + 1) for _ in range(rng.randint(1, 4)))
+            a = "(" + inner + ")"
+        else:
+            a = atoms[rng.randint(len(atoms))]
+        q = rng.rand()
+        if q < 0.15:
+            a += "*"
+        elif q < 0.3:
+            a += "+"
+        elif q < 0.4:
+            a += "?"
+        elif q < 0.45:
+            a += "{%d,%d}" % (rng.randint(0, 3), rng.randint(3, 6))
+        parts.append(a)
+    s = "".join(parts)
+    if depth == 0:
+        if rng.rand() < 0.4:
+            s = "^" + s
+        if rng.rand() < 0.4:
+            s = s + "$"
+    return s
+
+
+def test_differential_fuzz_against_reference(hip):
+    """Property test in the reference's fuzz/theft tradition: random regexes -> reference DFA ->
+    fsm_hip_compile, random inputs, GPU result == fsm_exec result (accept, end state, end-ids)."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    rng = np.random.RandomState(20260923)
+    alpha = np.frombuffer(b"abcdx019 \n", np.uint8)
+    n_re = n_in = n_acc = 0
+    layouts = set()
+    for k in range(220):
+        rx = _random_regex(rng).encode()
+        try:
+            f = RefFsm.re_comp("pcre", rx, 0, True, bool(k & 1), endid=k)
+        except ValueError:
+            continue                      # the reference rejected the pattern
+        if f.nstates == 0 or f.nstates > 5000:
+            continue
+        if k % 3 == 0:
+            f.shuffle(k + 1)
+        try:
+            dfa = hip.HipDfa.compile_fsm(f.ptr)
+        except OSError:
+            assert f.exec_one(b"a")[0] == -1   # only what fsm_exec itself refuses (no start state)
+            continue
+        layouts.add(dfa.info()["layout_name"])
+        strings = [bytes(alpha[rng.randint(0, len(alpha), rng.randint(0, 20))]) for _ in range(200)]
+        strings += f.generate_matches(16, 6, seed=k + 1)
+        ret, want = f.exec_strings(strings)
+        end, bm = dfa.exec_strings(strings)
+        assert np.array_equal(end, want), rx
+        assert np.array_equal(bits(bm, len(strings)), ret == 1), rx
+        for e in set(int(x) for x in end if x != NO):
+            assert np.array_equal(dfa.endids(e), f.endids(e)), rx
+        n_re += 1
+        n_in += len(strings)
+        n_acc += int((ret == 1).sum())
+        dfa.close()
+    assert n_re >= 100 and n_in >= 20000 and n_acc >= 1500, (n_re, n_in, n_acc)
+    assert len(layouts) >= 2, layouts
