@@ -19,6 +19,10 @@ own sources) and freezes its answers as small .npz fixtures:
                    (rx-style, not minimised), end-id = pattern index, with
                    fsm_exec + end-id answers on 512 x 1 KiB inputs.
 
+  recorded/*.npz   every fsm_exec call made by the reference's own tests/endids, tests/re_strings and
+                   tests/capture programs (compiled in place with fsm_exec routed through
+                   record_exec.c), grouped per distinct automaton.
+
 Each fixture stores the flat DFA (libfsm_amd.FlatDfa.save) produced by the
 product's own fsm_hip_flatten() from the reference `struct fsm *`.
 """
@@ -440,6 +444,90 @@ def gen_fsm_corpus():
     print(f"fsm corpus: {k} automata, {ncase} inputs, {skipped} skipped")
 
 
+def gen_recorded():
+    """Compile the reference's own C test programs (tests/endids, tests/re_strings, tests/capture)
+    where they lie, with fsm_exec routed through record_exec.c, run them, and freeze every
+    (automaton, input, fsm_exec answer, end-ids) they produce: recorded/<dir>_<program>_<k>.npz.
+    Automata with capture paths flatten to ENOTSUP; those calls are frozen as `unsupported` counts."""
+    import struct
+    import subprocess
+    import tempfile
+    d = os.path.join(OUT, "recorded")
+    os.makedirs(d, exist_ok=True)
+    for old in os.listdir(d):
+        os.unlink(os.path.join(d, old))
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    libdir = os.path.join(ROOT, "libfsm_amd")
+    groups = {
+        "endids": (["utils.c"], lambda fn: fn.startswith("endids") and fn.endswith(".c")),
+        "re_strings": (["testutil.c"], lambda fn: fn.startswith("re_strings") and fn.endswith(".c")),
+        "capture": (["captest.c"], lambda fn: fn.startswith("capture") and fn.endswith(".c")),
+    }
+    nprog = ncalls = nfsm = nunsup = 0
+    summary = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for g, (common, pick) in groups.items():
+            src = os.path.join(REF, "tests", g)
+            for fn in sorted(os.listdir(src)):
+                if not pick(fn):
+                    continue
+                exe, log = os.path.join(tmp, "prog"), os.path.join(tmp, "log")
+                cmd = ["gcc", "-std=gnu99", "-O1", "-UNDEBUG", "-w", "-Dfsm_exec=rec_fsm_exec", f"-I{REF}/include", f"-I{REF}/src",
+                       f"-I{REF}/src/adt", f"-I{ROOT}/include", os.path.join(src, fn)] + [os.path.join(src, c) for c in common] + [
+                       os.path.join(OUT, "record_exec.c"), "-o", exe, f"-L{refdir}", "-lfsm_ref", f"-L{libdir}", "-lfsm_hip",
+                       f"-Wl,-rpath,{refdir}", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+                subprocess.check_call(cmd)
+                if os.path.exists(log):
+                    os.unlink(log)
+                r = subprocess.run([exe], env=dict(os.environ, REC_OUT=log), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                assert r.returncode == 0, (fn, r.returncode)      # the reference's own assertions hold
+                nprog += 1
+                raw = open(log, "rb").read() if os.path.exists(log) else b""
+                pos, by_fsm, unsup = 0, {}, 0
+                while pos < len(raw):
+                    magic, blen, ferr = struct.unpack_from("<III", raw, pos)
+                    assert magic == 0x43455852
+                    pos += 12
+                    blob = raw[pos:pos + blen]
+                    pos += blen
+                    (n,) = struct.unpack_from("<I", raw, pos)
+                    data = raw[pos + 4:pos + 4 + n]
+                    pos += 4 + n
+                    ret, end, cnt = struct.unpack_from("<iII", raw, pos)
+                    ids = struct.unpack_from(f"<{cnt}I", raw, pos + 12)
+                    pos += 12 + 4 * cnt
+                    ncalls += 1
+                    if ferr:
+                        assert ferr == 95, (fn, ferr)           # ENOTSUP: capture paths
+                        unsup += 1
+                        continue
+                    by_fsm.setdefault(blob, []).append((data, ret, end, ids))
+                nunsup += unsup
+                summary[f"{g}/{fn}"] = dict(calls=sum(len(v) for v in by_fsm.values()) + unsup, automata=len(by_fsm), unsupported=unsup)
+                for k, (blob, calls) in enumerate(by_fsm.items()):
+                    tf = os.path.join(tmp, "t.fsmhip")
+                    open(tf, "wb").write(blob)
+                    flat = FlatDfa.read_c(tf)
+                    seen, uniq = set(), []
+                    for c in calls:                              # the same input twice must give the same answer
+                        if c[0] in seen:
+                            assert [u for u in uniq if u[0] == c[0]][0] == c
+                            continue
+                        seen.add(c[0])
+                        uniq.append(c)
+                    base, off = pack([c[0] for c in uniq])
+                    io = np.zeros(len(uniq) + 1, np.uint32)
+                    io[1:] = np.cumsum([len(c[3]) for c in uniq])
+                    ii = np.array([x for c in uniq for x in c[3]], np.uint32)
+                    meta = dict(source=f"tests/{g}/{fn}", recorded_by="tests/golden/record_exec.c", automaton=k)
+                    flat.save(os.path.join(d, f"{g}_{fn[:-2]}_{k}.npz"), in_bytes=base, in_off=off,
+                              ret=np.array([c[1] for c in uniq], np.int32), end=np.array([c[2] for c in uniq], np.uint32),
+                              ids_off=io, ids=ii, meta=np.frombuffer(json.dumps(meta).encode(), np.uint8))
+                    nfsm += 1
+    json.dump(summary, open(os.path.join(d, "SUMMARY.json"), "w"), indent=1, sort_keys=True)
+    print(f"recorded: {nprog} reference test programs, {ncalls} fsm_exec calls, {nfsm} automata, {nunsup} calls on capture automata (ENOTSUP)")
+
+
 if __name__ == "__main__":
     assert build_ref(), "needs /root/reference to build oracle/_ref"
     gen_retest()
@@ -449,3 +537,4 @@ if __name__ == "__main__":
     gen_c3()
     gen_eager()
     gen_fsm_corpus()
+    gen_recorded()
