@@ -343,6 +343,36 @@ void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
 	unsigned every);
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
+/* ------------------------------------------------------------------ */
+/* literal sets: the Aho-Corasick caller of the path                   */
+/* ------------------------------------------------------------------ */
+
+/* Word list -> DFA, in the shape of libre's re_strings interface
+ * (include/re/strings.h:15-55, src/libre/re_strings.c:21-137, src/libre/ac.c): the same trie,
+ * failure edges, output propagation and state numbering (depth-first from the root in byte
+ * order, ac.c:277-346; state 0 is the shared absorbing end state when neither ANCHOR_RIGHT nor
+ * AC_AUTOMATON is given, re_strings.c:105-117), so the description equals
+ * fsm_hip_flatten(re_strings_build(...)) state for state -- but built iteratively, straight into
+ * the flat form, without a struct fsm (the reference recurses once per trie level and keeps 2 KiB
+ * per trie node).  add_* return 1 / 0 like re_strings_add_*; build returns a malloc'd description
+ * (fsm_hip_desc_free) or NULL + errno.  The builder may be reused after build. */
+enum {
+	FSM_HIP_STRINGS_ANCHOR_LEFT  = 1 << 0,   /* RE_STRINGS_ANCHOR_LEFT  */
+	FSM_HIP_STRINGS_ANCHOR_RIGHT = 1 << 1,   /* RE_STRINGS_ANCHOR_RIGHT */
+	FSM_HIP_STRINGS_AC_AUTOMATON = 1 << 2    /* RE_STRINGS_AC_AUTOMATON */
+};
+
+struct fsm_hip_strings;   /* plays struct re_strings */
+
+struct fsm_hip_strings *fsm_hip_strings_new(void);
+void fsm_hip_strings_free(struct fsm_hip_strings *g);
+int fsm_hip_strings_add_raw(struct fsm_hip_strings *g, const void *p, size_t n, const fsm_end_id_t *endid);
+int fsm_hip_strings_add_str(struct fsm_hip_strings *g, const char *s, const fsm_end_id_t *endid);
+struct fsm_hip_dfa_desc *fsm_hip_strings_build(struct fsm_hip_strings *g, unsigned flags);
+
+/* re_strings() in one call (re_strings.c:21-52): NUL-terminated words, no end-ids. */
+struct fsm_hip_dfa_desc *fsm_hip_strings(const char *const a[], size_t n, unsigned flags);
+
 int fsm_hip_version(void);
 
 #ifdef __cplusplus

@@ -96,6 +96,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.fsm_hip_flatten.argtypes = [vp]
     lib.fsm_hip_desc_free.argtypes = [C.POINTER(_Desc)]
     lib.fsm_hip_desc_read.restype = C.POINTER(_Desc)
+    lib.fsm_hip_strings_new.restype = vp
+    lib.fsm_hip_strings_free.argtypes = [vp]
+    lib.fsm_hip_strings_add_raw.argtypes = [vp, C.c_char_p, sz, u32p]
+    lib.fsm_hip_strings_build.restype = C.POINTER(_Desc)
+    lib.fsm_hip_strings_build.argtypes = [vp, C.c_uint]
     lib.fsm_hip_gen_inputs_device.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint, vp]
     lib.fsm_hip_gen_inputs_host.restype = None
     lib.fsm_hip_gen_inputs_host.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, vp, C.c_uint, vp, C.c_uint, C.c_uint]
@@ -243,6 +248,38 @@ class FlatDfa:
             return cls.from_desc(d.contents)
         finally:
             lib.fsm_hip_desc_free(d)
+
+    @classmethod
+    def from_strings(cls, words: Sequence[bytes], flags: int = 0, endids: Optional[Sequence[int]] = None) -> "FlatDfa":
+        """fsm_hip_strings_*(): literal set -> DFA, the automaton libre's re_strings builds
+        (flags: 1 anchor left, 2 anchor right, 4 AC automaton; endids: one per word or None)."""
+        lib = load_library()
+        g = lib.fsm_hip_strings_new()
+        if not g:
+            raise _oserr("fsm_hip_strings_new")
+        try:
+            for i, w in enumerate(words):
+                eid = C.byref(C.c_uint32(int(endids[i]))) if endids is not None else None
+                if not lib.fsm_hip_strings_add_raw(g, w, len(w), C.cast(eid, C.POINTER(C.c_uint32)) if eid is not None else None):
+                    raise _oserr("fsm_hip_strings_add_raw")
+            C.set_errno(0)
+            d = lib.fsm_hip_strings_build(g, flags)
+            if not d:
+                raise _oserr("fsm_hip_strings_build")
+            try:
+                return cls.from_desc(d.contents)
+            finally:
+                lib.fsm_hip_desc_free(d)
+        finally:
+            lib.fsm_hip_strings_free(g)
+
+    def canonical(self):
+        """(nstates, start, dense [S][256] next table with 0xFFFFFFFF = no edge, is_end, end-id lists): order-free form."""
+        nt = np.full((self.nstates, 256), NO_MATCH, np.uint32)
+        for s_ in range(self.nstates):
+            for r in self.ranges[int(self.edge_off[s_]):int(self.edge_off[s_ + 1])]:
+                nt[s_, int(r["lo"]):int(r["hi"]) + 1] = r["to"]
+        return self.nstates, self.start, nt, self.is_end.copy(), self.endid_off.copy(), self.endids.copy()
 
     def save(self, path: str, **extra):
         np.savez_compressed(path, nstates=np.uint32(self.nstates), start=np.uint32(self.start), edge_off=self.edge_off,

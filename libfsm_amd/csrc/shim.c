@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "../../include/fsm_hip.h"
+#include "flat.h"
 
 struct api {
 	int resolved;
@@ -71,17 +72,6 @@ resolve(void)
 }
 
 /* ---- flatten ------------------------------------------------------- */
-
-struct flat {
-	struct fsm_hip_dfa_desc d;
-	uint32_t *edge_off;
-	struct fsm_hip_range *ranges;
-	uint8_t *is_end;
-	uint32_t *endid_off;
-	uint32_t *endids;
-	uint32_t *eager_off;
-	uint32_t *eager_ids;
-};
 
 struct walk_env {
 	uint32_t *next;   /* [nstates][256], 0xFFFFFFFF = no edge */
