@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path (batched DFA walk) on N GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3] [--n INPUTS_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c5] [--n INPUTS_PER_GPU]
 
 A "step" is one pass of the walk kernel over one batch of synthetic inputs that
 is already resident in HBM (generated on the device, so nothing crosses PCIe),
@@ -14,7 +14,12 @@ Workloads (BASELINE.json configs):
       inputs per GPU, "Libfsm" planted in every 8th input.        (default)
   c3  configs[2]: 1 024 anchored PCRE unioned into a ~4 096-state DFA, half the
       inputs derived from a pattern (prefix + digits + suffix), half random.
-The DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real
+  c5  configs[4]: Aho-Corasick DFA of 1e5 literals (8-16 characters over 64
+      symbols, ~1e6 states, right-anchored, end-id = literal), built by the
+      library's own fsm_hip_strings_* builder; 1e7 x 1 KiB inputs over the same
+      alphabet, every 8th ending with a literal.  The table does not fit LDS: this
+      walk is bound by L2 gather requests, not by HBM.
+The c2/c3 DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real
 reference by tests/golden/make_golden.py); /root/reference is not needed.
 """
 import argparse
@@ -38,8 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
-    ap.add_argument("--n", type=int, default=100_000_000, help="inputs per GPU")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--n", type=int, default=0, help="inputs per GPU (default 1e8; c5: 1e7)")
+    ap.add_argument("--c5-words", type=int, default=100_000, help="c5: number of literals")
     ap.add_argument("--len", type=int, default=1024, help="bytes per input")
     ap.add_argument("--input-mode", type=int, default=-1)
     ap.add_argument("--nb", type=int, default=0)
@@ -60,7 +66,52 @@ def c3_affixes():
     return [p[1:p.index(b"[")] for p in pats], [b"x", b"yz"]
 
 
-def generate(hip, workload, d_ptr, n, L, first):
+ALPHA64 = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-"
+_C5 = {}
+
+
+def c5_words(nwords):
+    """configs[4]: seeded literals of 8-16 characters over a 64-symbol alphabet."""
+    if nwords not in _C5:
+        rng = np.random.RandomState(SEED & 0x7FFFFFFF)
+        alpha = np.frombuffer(ALPHA64, np.uint8)
+        _C5[nwords] = [bytes(alpha[rng.randint(0, 64, rng.randint(8, 17))]) for _ in range(nwords)]
+    return _C5[nwords]
+
+
+def c5_tail_table(words):
+    lens = np.array([len(w) for w in words], np.int64)
+    W = np.zeros((len(words), 16), np.uint8)
+    for i, w in enumerate(words):
+        W[i, :len(w)] = np.frombuffer(w, np.uint8)
+    return W, lens
+
+
+def c5_plant_tails(rows, first, words, xp):
+    """Every 8th input (by global index) ends with the literal (index * 2654435761) % nwords, so that it is
+    accepted by the right-anchored automaton; `rows` is a torch (device) or numpy [n][L] array."""
+    W, lens = c5_tail_table(words)
+    n, L = rows.shape
+    if xp is np:
+        idx = np.arange((-first) % 8, n, 8)
+        Wd, ld = W, lens
+    else:
+        idx = xp.arange((-first) % 8, n, 8, device=rows.device)
+        Wd, ld = xp.from_numpy(W).to(rows.device), xp.from_numpy(lens).to(rows.device)
+    widx = ((idx + first) * 2654435761) % len(words)
+    for l in sorted(set(lens.tolist())):
+        m = ld[widx] == l
+        if bool(m.any()):
+            rows[idx[m], L - l:] = Wd[widx[m], :l]
+
+
+def generate(hip, workload, d_ptr, n, L, first, words=None, buf=None):
+    if workload == "c5":
+        import torch
+        hip.gen_inputs_device(d_ptr, n, L, first, SEED, ALPHA64)
+        torch.cuda.synchronize()
+        c5_plant_tails(buf, first, words, torch)
+        return
     if workload == "c2":
         hip.gen_inputs_device(d_ptr, n, L, first, SEED, None, b"Libfsm", 8)
     else:
@@ -68,20 +119,33 @@ def generate(hip, workload, d_ptr, n, L, first):
         hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
 
 
-def generate_host(hip, workload, n, L, first):
+def generate_host(hip, workload, n, L, first, words=None):
+    if workload == "c5":
+        rows = hip.gen_inputs_host(n, L, first, SEED, ALPHA64)
+        c5_plant_tails(rows, first, words, np)
+        return rows
     if workload == "c2":
         return hip.gen_inputs_host(n, L, first, SEED, None, b"Libfsm", 8)
     pf, sf = c3_affixes()
     return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
 
 
-def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample):
+def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample, words=None):
     """Time the reference's CPU path on a bounded sample of the same inputs (rank 0, N=1 only)
     and check the GPU's answers on that sample against it, bit for bit."""
     from oracle import pyoracle
-    rows = generate_host(hip, workload, sample, L, 0)
+    rows = generate_host(hip, workload, sample, L, 0, words)
     out = {"cores": 1, "unit": "GB/s"}
     gb = rows.size / 1e9
+    if workload == "c5":
+        # the reference needs ~1 min and 7.5 GB for re_strings on 1e5 literals, 3.7 s per fsm_exec call
+        # (fsm_all(isdfa) over 1e6 states, exec.c:106) and 7 min to compile its VM (measured in the build
+        # container, DESIGN.md): the CPU leg of this workload is the oracle's table walker
+        o = pyoracle.Oracle(flat)
+        want = o.table_walk(rows)
+        out.update(kind="port", value=round(gb / o.last_seconds, 5),
+                   sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, first {sample} inputs x {L} B")
+        return out, bool(np.array_equal(gpu_end_sample, want))
     if pyoracle.have_ref():
         # the real reference, rebuilt as a struct fsm from its own regex sources
         if workload == "c2":
@@ -151,7 +215,13 @@ def main():
     import libfsm_amd as hip
     hip.load_library()
 
-    flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if a.workload == "c2" else "c3.npz"))
+    words = None
+    if a.workload == "c5":
+        words = c5_words(a.c5_words)
+        # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
+        flat = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
+    else:
+        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if a.workload == "c2" else "c3.npz"))
     flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
     dfa = hip.HipDfa(flat, flags)
     for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_ROWS, a.rows),
@@ -164,7 +234,8 @@ def main():
     info = dfa.info()
 
     L = a.len
-    n = a.n
+    n = a.n if a.n > 0 else (10_000_000 if a.workload == "c5" else 100_000_000)
+    requested = n
     free, total = torch.cuda.mem_get_info()
     need = n * (L + 4) + n // 8 + (1 << 30)
     if need > free * 0.92:  # shrink rather than risk an OOM strike; reported in config
@@ -178,7 +249,7 @@ def main():
     nwords = (n + 63) // 64
     bm = torch.zeros(nwords, dtype=torch.int64, device="cuda")
     gathered = torch.empty(nwords * world, dtype=torch.int64, device="cuda") if world > 1 else None
-    generate(hip, a.workload, buf.data_ptr(), n, L, first)
+    generate(hip, a.workload, buf.data_ptr(), n, L, first, words, buf)
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -247,12 +318,14 @@ def main():
         "config": {
             "workload": ("c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), "
                          if a.workload == "c2" else
-                         "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, " % flat.nstates)
+                         "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, " % flat.nstates
+                         if a.workload == "c3" else
+                         "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), " % (len(words), flat.nstates))
                         + f"{n} x {L} B synthetic inputs per GPU resident in HBM, 64 inputs/wavefront",
             "inputs_per_gpu": n, "input_len": L, "dfa_states": flat.nstates, "byte_classes": info["nclasses"],
-            "table_layout": info["layout_name"], "lds_bytes_per_block": info["lds_bytes"],
+            "table_layout": info["layout_name"], "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"],
             "waves_per_block": info["waves_per_block"], "sharding": f"{world} contiguous index ranges, all-gather of the accept bitmap" if world > 1 else "single GPU",
-            "accepted_inputs": int(acc_t.item()), "requested_inputs_per_gpu": a.n,
+            "accepted_inputs": int(acc_t.item()), "requested_inputs_per_gpu": requested,
         },
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -264,7 +337,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline and a.cpu_sample != 0:
         sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if a.workload == "c2" else 100_000)
         sample = min(sample, n)
-        cb, parity = cpu_baseline(hip, a.workload, flat, L, sample, end[:sample].cpu().numpy().view(np.uint32))
+        cb, parity = cpu_baseline(hip, a.workload, flat, L, sample, end[:sample].cpu().numpy().view(np.uint32), words)
         res["cpu_baseline"] = cb
         res["parity_vs_cpu_sample"] = "bit-exact" if parity else "MISMATCH"
         if not parity:

@@ -19,9 +19,9 @@ NO_ID = 0xFFFFFFFE
 STATE_START = 0xFFFFFFFD
 STATE_DEAD = 0xFFFFFFFC
 
-LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF = 0, 1, 2, 3, 4, 5, 6
-LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself"}
-ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL)
+LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_SPARSE = 0, 1, 2, 3, 4, 5, 6, 7
+LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself", 7: "sparse"}
+ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
 
 KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT, KNOB_QUEUE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
@@ -308,7 +308,7 @@ class Plan:
                  dense=(4, np.uint32), tiny_col=(5, np.uint64), lds_tab=(6, np.uint16), comb=(7, np.uint32),
                  comb_dflt=(8, np.uint32), comb_off=(9, np.uint32), comb_fin=(10, np.uint32), glob_tab=(11, np.uint32),
                  comb256=(12, np.uint32), comb256_off=(13, np.uint32), comb256_fin=(14, np.uint32), comb_smask=(15, np.uint32),
-                 emask=(16, np.uint64), eager_ids=(17, np.uint32))
+                 emask=(16, np.uint64), eager_ids=(17, np.uint32), sparse=(18, np.uint32))
 
     def __init__(self, flat: FlatDfa, flags: int = 0, lds_limit: int = 0):
         lib = load_library()

@@ -232,6 +232,18 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			set_hot_bytes(d, 40u * 1024u);
 			break;
 		}
+		case FSM_HIP_LAYOUT_SPARSE: {
+			uint32_t *t = nullptr;
+			HIP_TRY(upload(&t, p.sparse_img));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			a.tab_bytes = p.sparse_lds_bytes;
+			a.start = p.start;
+			a.abs_min = p.abs_min;
+			a.fin_div = 1;
+			d->table_lds = SparsePol::lds_bytes(a.tab_bytes);
+			break;
+		}
 		default:
 			errno = EINVAL;
 			goto fail;
@@ -240,7 +252,8 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		d->enc_host.resize(p.S1);
 		for (uint32_t n2 = 0; n2 < p.S1; n2++) {
 			switch (p.layout) {
-			case FSM_HIP_LAYOUT_TINY: d->enc_host[n2] = n2; break;
+			case FSM_HIP_LAYOUT_TINY:
+			case FSM_HIP_LAYOUT_SPARSE: d->enc_host[n2] = n2; break;
 			case FSM_HIP_LAYOUT_LDS: d->enc_host[n2] = n2 * p.row_bytes; break;
 			case FSM_HIP_LAYOUT_COMB:
 			case FSM_HIP_LAYOUT_COMBSELF: d->enc_host[n2] = p.comb_off[n2]; break;
@@ -319,7 +332,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : 1;
 	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
 	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
-	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF ? 0 : 1);
+	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF || layout == FSM_HIP_LAYOUT_SPARSE ? 0 : 1);
 	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
 	/* measured: the exec-mask bookkeeping costs more than the bank conflicts it removes
 	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
@@ -340,7 +353,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 			if (stride % 128u != 0) c.seg = 64;
 		}
 		if (c.mode == IN_DIRECT) {
-			c.nb = d->knob_nb > 0 ? d->knob_nb : 8;
+			/* the sparse layout waits on gathers, not on its input: 4 chunks keep it under 64 VGPRs */
+			c.nb = d->knob_nb > 0 ? d->knob_nb : (layout == FSM_HIP_LAYOUT_SPARSE ? 4 : 8);
 			while (c.nb > 1 && (stride / 16u) % (unsigned)c.nb != 0) c.nb >>= 1;
 			c.rows = d->knob_rows == 2 ? 2 : 1;
 			if (c.rows == 2 && c.nb > 4) c.nb = 4;
@@ -472,6 +486,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		case FSM_HIP_LAYOUT_COMB:    e = launch_masked<CombPol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_COMB256: e = launch_masked<Comb256Pol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_COMBSELF: e = launch_pol<CombSelfPol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_SPARSE:  e = launch_pol<SparsePol>(c, a, grid, block, s); break;
 		default:                     e = launch_masked<GlobPol>(c, a, grid, block, s); break;
 		}
 	}
@@ -624,6 +639,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
 	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8 + 256; break;
+	case FSM_HIP_LAYOUT_SPARSE: out->table_bytes = p.sparse_img.size() * 4; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
 	LaunchCfg c = pick_cfg(d, true, 1024);
@@ -713,6 +729,7 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB_OFF: *data = p.comb_off.data(); *count = p.comb_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB_FIN: *data = p.comb_fin.data(); *count = p.comb_fin.size(); return 0;
 	case FSM_HIP_PLAN_GLOB_TAB: *data = p.glob_tab.data(); *count = p.glob_tab.size(); return 0;
+	case FSM_HIP_PLAN_SPARSE: *data = p.sparse_img.data(); *count = p.sparse_img.size(); return 0;
 	case FSM_HIP_PLAN_COMB256: *data = p.comb256.data(); *count = p.comb256.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;

@@ -29,6 +29,8 @@ uint32_t lds_bytes_btab() { return 256u; }
 
 static int build_comb(Plan &p, uint32_t max_entries, bool bytewise);
 
+static int build_sparse(Plan &p, uint32_t lds_limit);
+
 int build_plan(const fsm_hip_dfa_desc *d, unsigned flags, uint32_t lds_limit, Plan &p)
 try {
 	if (d == nullptr || d->nstates == 0 || d->start >= d->nstates ||
@@ -280,7 +282,13 @@ try {
 		return 0;
 	};
 
+	auto emit_sparse = [&]() -> int {
+		if (has_eager) return ENOTSUP;
+		return build_sparse(p, lds_limit);
+	};
+
 	switch (want) {
+	case FSM_HIP_LAYOUT_SPARSE: return emit_sparse();
 	case FSM_HIP_LAYOUT_TINY:   return emit_tiny();
 	case FSM_HIP_LAYOUT_LDS:    return emit_lds();
 	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
@@ -295,12 +303,192 @@ try {
 		if (emit_comb256() == 0) return 0;
 		if (emit_lds() == 0) return 0;
 		if (emit_comb() == 0) return 0;
+		/* too big for LDS: base-row records when they shrink the table at least 4x (Aho-Corasick
+		 * and other DFAs whose rows repeat their predecessors'), else the plain table */
+		if (emit_sparse() == 0) {
+			if ((uint64_t)p.sparse_img.size() * 4u * 4u <= (uint64_t)S1 * C * 4u) return 0;
+			std::vector<uint32_t>().swap(p.sparse_img);
+		}
 		return emit_glob();
 	default:
 		return EINVAL;
 	}
 } catch (const std::bad_alloc &) {
 	return ENOMEM;
+}
+
+/*
+ * Base-row records ("sparse" layout) for tables that do not fit LDS.
+ *
+ * Every non-absorbing state n is either DENSE (a full row of C next states) or SPARSE: a base
+ * state b(n), numbered before n, plus the classes on which row(n) differs from row(b(n)) -- a
+ * bitmap over (up to 64) classes and the list of next states for the set bits:
+ *
+ *     delta(n, c) = exc[off(n) + popcount(bits(n) below bit(c))]   if bit(c) is set in bits(n)
+ *                 = delta(b(n), c)                                 otherwise (follow the chain)
+ *
+ * The base is found without knowing where the DFA came from: for a state first reached from its
+ * breadth-first parent p on class c, the candidate is delta(b(p), c) (the start state when p is
+ * dense).  On an Aho-Corasick DFA this reconstructs the failure links (fail(n) = delta(fail(p), c),
+ * src/libre/ac.c:229-241) and the exceptions are the trie children; on other automata it is just a
+ * row that is often similar.  A state whose row differs from the candidate's (and from the start
+ * state's) on more than half the classes stays dense, so the form is never much larger than the
+ * table and the result is the same for any choice.
+ *
+ * Records are 16 bytes {bits lo, bits hi, base | DENSE, offset}; those of the states nearest the
+ * start state, and the dense rows among them, are mirrored in LDS (breadth-first numbering puts
+ * the states a walk visits most first), the rest stays in HBM/L2.
+ *
+ * Image (u32 words): hdr[16] | pmap u16[256] (byte -> class | bit << 8, bit 0xff = unmapped)
+ *   | LDS dense rows | LDS records || all records | all dense rows | exceptions.
+ * Everything before the || is copied to LDS by the kernel (Plan::sparse_lds_bytes).
+ */
+static int build_sparse(Plan &p, uint32_t lds_limit)
+{
+	const uint32_t S1 = p.S1, C = p.C, N = p.abs_min;   /* records for the non-absorbing states only */
+	const uint32_t NONE = 0xFFFFFFFFu, DENSE = 0x80000000u;
+	if (N >= DENSE || p.start >= S1) return ENOTSUP;
+	auto row = [&](uint32_t n) { return &p.dense[(size_t)n * C]; };
+
+	/* breadth-first parents over the renumbered graph */
+	std::vector<uint32_t> parent(N, NONE), order;
+	std::vector<uint8_t> pcls(N, 0), seen(N, 0);
+	order.reserve(N);
+	if (p.start < N) { seen[p.start] = 1; order.push_back(p.start); }
+	for (size_t h = 0; h < order.size(); h++) {
+		const uint32_t n = order[h];
+		for (uint32_t c = 0; c < C; c++) {
+			const uint32_t t = row(n)[c];
+			if (t < N && !seen[t]) { seen[t] = 1; parent[t] = n; pcls[t] = (uint8_t)c; order.push_back(t); }
+		}
+	}
+	for (uint32_t n = 0; n < N; n++) if (!seen[n]) order.push_back(n);   /* unreachable: dense */
+
+	/* vb[n]: the candidate of n (its "failure state"), kept whether or not n ends up sparse, so
+	 * that the candidates of n's children derive from it even across dense states */
+	std::vector<uint32_t> base(N, NONE), vb(N, NONE), nexc(N, 0);
+	std::vector<uint8_t> done(N, 0), chain(N, 0);
+	auto diff = [&](uint32_t a, uint32_t b) {
+		uint32_t k = 0;
+		const uint32_t *ra = row(a), *rb = row(b);
+		for (uint32_t c = 0; c < C; c++) k += ra[c] != rb[c];
+		return k;
+	};
+	const uint32_t thr = C / 2u;
+	for (uint32_t n : order) {
+		done[n] = 1;
+		if (n == p.start || parent[n] == NONE || p.start >= N) continue;
+		const uint32_t pp = parent[n];
+		uint32_t cand = vb[pp] == NONE ? p.start : row(vb[pp])[pcls[n]];
+		if (cand >= N || cand == n || !done[cand]) cand = p.start;
+		vb[n] = cand;
+		if (chain[cand] >= 6) cand = p.start;
+		uint32_t k = diff(n, cand);
+		if (k > thr && cand != p.start) { cand = p.start; k = diff(n, cand); }
+		if (k > thr) continue;
+		base[n] = cand;
+		nexc[n] = k;
+		chain[n] = (uint8_t)(chain[cand] + 1);
+	}
+
+	/* classes that get a bit: the 64 most often excepted; a state excepted elsewhere goes dense */
+	uint8_t bit_of[256];
+	memset(bit_of, 0xff, sizeof bit_of);
+	{
+		std::vector<uint64_t> cnt(C, 0);
+		for (uint32_t n = 0; n < N; n++) {
+			if (base[n] == NONE) continue;
+			const uint32_t *ra = row(n), *rb = row(base[n]);
+			for (uint32_t c = 0; c < C; c++) cnt[c] += ra[c] != rb[c];
+		}
+		std::vector<uint32_t> byc(C);
+		for (uint32_t c = 0; c < C; c++) byc[c] = c;
+		std::stable_sort(byc.begin(), byc.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+		std::vector<uint32_t> pick(byc.begin(), byc.begin() + (C < 64u ? C : 64u));
+		std::sort(pick.begin(), pick.end());
+		for (size_t k = 0; k < pick.size(); k++) bit_of[pick[k]] = (uint8_t)k;
+		if (C > 64u) {
+			for (uint32_t n = 0; n < N; n++) {
+				if (base[n] == NONE) continue;
+				const uint32_t *ra = row(n), *rb = row(base[n]);
+				for (uint32_t c = 0; c < C; c++) {
+					if (ra[c] != rb[c] && bit_of[c] == 0xff) { base[n] = NONE; nexc[n] = 0; break; }
+				}
+			}
+		}
+	}
+
+	/* sizes; which states live in LDS */
+	uint64_t ndense = 0, ntot_exc = 0;
+	for (uint32_t n = 0; n < N; n++) { if (base[n] == NONE) ndense++; else ntot_exc += nexc[n]; }
+	const uint64_t words = 16u + 128u + (uint64_t)N * 4u + ndense * C + ntot_exc;
+	if (words * 4u + 160u * 1024u >= 0xFFFFFFFFull) return ENOTSUP;
+	/* half the LDS, so that two 16-wave workgroups share a CU: the walk waits on gathers, and 32
+	 * resident waves measured 283 vs 220 GB/s with all of LDS and 16 (profiles/r01_c5_sparse.txt) */
+	const uint32_t budget = lds_limit / 2u > 4096u ? lds_limit / 2u - 2048u : 0;
+	uint32_t H = 0, HD = 0;                                              /* records / dense rows in LDS */
+	{
+		uint64_t used = 64u + 512u;
+		for (uint32_t n = 0; n < N; n++) {
+			const uint64_t need = 16u + (base[n] == NONE ? (uint64_t)C * 4u : 0u);
+			if (used + need > budget) break;
+			used += need;
+			H++;
+			if (base[n] == NONE) HD++;
+		}
+	}
+
+	std::vector<uint32_t> &img = p.sparse_img;
+	const uint32_t lds_dense_w = 16u + 128u, lds_rec_w = (lds_dense_w + HD * C + 3u) & ~3u;
+	const uint32_t lds_words = lds_rec_w + H * 4u;
+	const uint32_t grec_w = lds_words, gdense_w = grec_w + N * 4u;
+	const uint64_t exc_w64 = (uint64_t)gdense_w + ndense * C;
+	const uint32_t exc_w = (uint32_t)exc_w64;
+	img.assign((size_t)(exc_w64 + ntot_exc), 0);
+	{
+		uint16_t *pm = reinterpret_cast<uint16_t *>(&img[16]);
+		for (unsigned b = 0; b < 256; b++) pm[b] = (uint16_t)(p.cls[b] | (bit_of[p.cls[b]] << 8));
+	}
+	uint32_t drow = 0, eoff = 0, maxchain = 0;
+	for (uint32_t n = 0; n < N; n++) {
+		uint32_t *r = &img[grec_w + (size_t)n * 4u];
+		if (base[n] == NONE) {
+			r[0] = r[1] = 0;
+			r[2] = DENSE;
+			r[3] = drow * C;
+			memcpy(&img[gdense_w + (size_t)drow * C], row(n), (size_t)C * 4u);
+			if (drow < HD) memcpy(&img[lds_dense_w + (size_t)drow * C], row(n), (size_t)C * 4u);
+			drow++;
+		} else {
+			uint64_t bits = 0;
+			const uint32_t *ra = row(n), *rb = row(base[n]);
+			r[3] = eoff;
+			for (uint32_t c = 0; c < C; c++) {          /* bit order = class order (bit_of is monotone) */
+				if (ra[c] != rb[c]) { bits |= (uint64_t)1 << bit_of[c]; img[exc_w + eoff++] = ra[c]; }
+			}
+			r[0] = (uint32_t)bits;
+			r[1] = (uint32_t)(bits >> 32);
+			r[2] = base[n];
+			if (chain[n] > maxchain) maxchain = chain[n];
+		}
+		if (n < H) memcpy(&img[lds_rec_w + (size_t)n * 4u], r, 16);
+	}
+	img[0] = 0x31525053u;   /* "SPR1" */
+	img[1] = H;
+	img[2] = HD * C;
+	img[3] = lds_dense_w * 4u;
+	img[4] = lds_rec_w * 4u;
+	img[5] = grec_w * 4u;
+	img[6] = gdense_w * 4u;
+	img[7] = exc_w * 4u;
+	img[8] = N;
+	img[9] = C;
+	img[10] = (uint32_t)ndense;
+	img[11] = (uint32_t)ntot_exc;
+	img[12] = maxchain;
+	p.sparse_lds_bytes = lds_words * 4u;
+	p.layout = FSM_HIP_LAYOUT_SPARSE;
+	return 0;
 }
 
 /*

@@ -69,6 +69,9 @@ struct Plan {
 	uint32_t comb256_dflt = 0, comb256_abs_min_off = 0;
 	/* GLOBAL: u32 entries [S1][C], entry = next_state * C * 4 (byte offset) */
 	std::vector<uint32_t> glob_tab;
+	/* SPARSE: base-row records (see build_sparse in plan.cpp); states are plain renumbered ids */
+	std::vector<uint32_t> sparse_img;
+	uint32_t sparse_lds_bytes = 0;    /* leading part of the image that the kernel mirrors in LDS */
 };
 
 /* Returns 0 or an errno value (EINVAL, ENOMEM, ENOTSUP for a forced layout

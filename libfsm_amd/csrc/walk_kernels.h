@@ -25,6 +25,8 @@
  *   CombSelfPol CombPol + a self-loop mask per state kept in a register: bytes on
  *              which the state does not change cost only the conflict-free B lookup.
  *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS (+ LDS mirror of its head).
+ *   SparsePol  per-state record {exception bitmap, base state} + exception lists in HBM/L2, the
+ *              records nearest the start state in LDS (failure-link form of big tables).
  * MASK: lanes already in an absorbing state skip the state-dependent lookup
  * (exec-masked), which takes their addresses out of the LDS bank arbitration.
  *
@@ -331,6 +333,71 @@ struct GlobPol {
 		if (MASK && st >= abs_min) return st;
 		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
 		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
+	}
+};
+
+/*
+ * SparsePol: base-row records (plan.cpp build_sparse).  A state is its renumbered id; its 16-byte
+ * record {bits lo, bits hi, base | DENSE, offset} comes from LDS for the H states nearest the start
+ * state and from HBM/L2 for the rest.  A lane follows base links until a record has the class's bit
+ * set (next state = one gather from the exception list) or is dense (next state from the dense
+ * row, LDS for the first rows).  The loop is lane-divergent; chains are bounded by the planner.
+ */
+struct SparsePol {
+	typedef uint32_t P;   /* class | bit << 8 */
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	const uint16_t *pm;        /* LDS: byte -> class | bit << 8 */
+	const uint32_t *ldense;    /* LDS: first dense rows         */
+	const u32x4 *lrec;         /* LDS: first H records          */
+	const u32x4 *grec;
+	const uint32_t *gdense, *exc;
+	uint32_t H, HDE, abs_min;
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		copy_table(lds, a);
+		const uint32_t *hdr = static_cast<const uint32_t *>(a.tab);
+		const unsigned char *g = static_cast<const unsigned char *>(a.tab);
+		H = hdr[1];
+		HDE = hdr[2];
+		pm = reinterpret_cast<const uint16_t *>(lds + 64);
+		ldense = reinterpret_cast<const uint32_t *>(lds + hdr[3]);
+		lrec = reinterpret_cast<const u32x4 *>(lds + hdr[4]);
+		grec = reinterpret_cast<const u32x4 *>(g + hdr[5]);
+		gdense = reinterpret_cast<const uint32_t *>(g + hdr[6]);
+		exc = reinterpret_cast<const uint32_t *>(g + hdr[7]);
+		abs_min = a.abs_min;
+	}
+	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
+	{
+		const uint32_t cls = p & 0xffu, bit = p >> 8;
+		const uint32_t lowmask_lo = bit < 32u ? (1u << bit) - 1u : 0xFFFFFFFFu;
+		const uint32_t lowmask_hi = bit < 32u ? 0u : bit < 64u ? (1u << (bit - 32u)) - 1u : 0u;
+		uint32_t res = st;
+		bool live = st < abs_min;
+		while (live) {
+			u32x4 r;
+			if (st < H) r = lrec[st]; else r = grec[st];
+			if (r.z & 0x80000000u) {
+				const uint32_t o = r.w + cls;
+				if (o < HDE) res = ldense[o]; else res = gdense[o];
+				live = false;
+			} else {
+				const uint32_t sel = bit < 32u ? (r.x >> bit) & 1u : bit < 64u ? (r.y >> (bit - 32u)) & 1u : 0u;
+				if (sel) {
+					res = exc[r.w + __popc(r.x & lowmask_lo) + __popc(r.y & lowmask_hi)];
+					live = false;
+				} else {
+					st = r.z;
+				}
+			}
+		}
+		return res;
 	}
 };
 

@@ -397,23 +397,53 @@ def test_config5_aho_corasick_100k_literals(hip):
     threading.stack_size(0)
     f, flat = out["f"], out["flat"]
     assert flat.nstates > 250_000
-    dfa = hip.HipDfa(flat)
-    assert dfa.info()["layout_name"] == "global"
     rows = alpha[rng.randint(0, 26, (20000, 1024))]
     for i in range(0, 20000, 2):      # end half of the rows on a word so they accept
         w = words[rng.randint(len(words))]
         rows[i, 1024 - len(w):] = np.frombuffer(w, np.uint8)
     want = Oracle(flat).table_walk(rows)
     assert (want != NO).sum() >= 10000
-    for mode in (hip.IN_DIRECT, hip.IN_LDSDMA, hip.IN_GENERIC):
-        dfa.tune(hip.KNOB_INPUT_MODE, mode)
-        end, _ = dfa.exec_batch(rows)
-        assert np.array_equal(end, want), mode
     ret, e5 = f.exec_stride(rows[:5])  # literal fsm_exec sweeps all 3e5 states per call
     assert np.array_equal(e5, want[:5])
-    for e in set(int(x) for x in want[:200] if x != NO):
-        assert np.array_equal(dfa.endids(e), f.endids(e))
-    dfa.close()
+    for layout in (hip.LAYOUT_GLOBAL, hip.LAYOUT_SPARSE, hip.LAYOUT_AUTO):
+        dfa = hip.HipDfa(flat, layout)
+        assert dfa.info()["layout_name"] == {hip.LAYOUT_GLOBAL: "global", hip.LAYOUT_SPARSE: "sparse", hip.LAYOUT_AUTO: "sparse"}[layout]
+        for mode in (hip.IN_DIRECT, hip.IN_LDSDMA, hip.IN_GENERIC):
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            end, _ = dfa.exec_batch(rows)
+            assert np.array_equal(end, want), (layout, mode)
+        for e in set(int(x) for x in want[:200] if x != NO):
+            assert np.array_equal(dfa.endids(e), f.endids(e))
+        dfa.close()
+
+
+def test_literal_set_builder_to_device(hip):
+    """fsm_hip_strings_* -> fsm_hip_dfa_create without a struct fsm: 3e4 literals over 64 symbols (the
+    configs[4] generator at reduced size), anchored and not, sparse vs global layout vs the oracle, with
+    device-side end-ids equal to the literal indices."""
+    import bench
+    from oracle.pyoracle import Oracle
+    words = bench.c5_words(30000)
+    rows = hip.gen_inputs_host(6000, 512, 0, bench.SEED, bench.ALPHA64)
+    bench.c5_plant_tails(rows, 0, words, np)
+    for flags in (2, 0):
+        flat = hip.FlatDfa.from_strings(words, flags, list(range(len(words))))
+        assert flat.nstates > 250_000
+        want = Oracle(flat).table_walk(rows)
+        assert (want != NO).sum() == 750
+        got = {}
+        for layout in (hip.LAYOUT_SPARSE, hip.LAYOUT_GLOBAL):
+            dfa = hip.HipDfa(flat, layout)
+            end, _ = dfa.exec_batch(rows)
+            assert np.array_equal(end, want), (flags, layout)
+            got[layout] = dfa.exec_batch_ids(rows, 1)      # lowest end-id per accepted input, from the kernel
+            dfa.close()
+        assert np.array_equal(got[hip.LAYOUT_SPARSE], got[hip.LAYOUT_GLOBAL])
+        planted = np.arange(0, 6000, 8)
+        idx = (planted * 2654435761) % len(words)
+        for i, k in zip(planted[:200], idx[:200]):      # the literal itself, or an equal / suffix literal with a lower index
+            e = int(got[hip.LAYOUT_SPARSE][i])
+            assert e <= k and words[int(k)].endswith(words[e])
 
 
 def test_device_side_endids(hip):

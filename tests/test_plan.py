@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from common import Golden, all_golden_paths, golden_id
-from libfsm_amd import ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_TINY, FlatDfa, Plan
+from libfsm_amd import (ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_SPARSE, LAYOUT_TINY,
+                        FlatDfa, Plan)
 
 NO = 0xFFFFFFFF
 
@@ -17,6 +18,67 @@ def reference_table(flat):
     S = flat.nstates
     d[d == NO] = S
     return np.vstack([d, np.full((1, 256), S, np.int64)])
+
+
+def decode_sparse(p, S1, lds_limit=160 * 1024):
+    """SparsePol::next for every (state, byte), vectorised over the 256 bytes; the LDS mirror (records and
+    dense rows of the first states) is read exactly where the kernel reads it."""
+    img = p.get("sparse").astype(np.int64)
+    assert img[0] == 0x31525053
+    H, HDE, ldo, lro, gro, gdo, exo, N, Cn = (int(x) for x in img[1:10])
+    ndense, nexc, maxchain = int(img[10]), int(img[11]), int(img[12])
+    assert N == p.abs_min and Cn == p.C
+    assert lro + 16 * H <= gro <= lds_limit and gro % 16 == 0          # the LDS part fits one workgroup
+    pm = img[16:16 + 128]
+    pm = np.stack([pm & 0xffff, pm >> 16], axis=1).reshape(-1)          # u16[256]
+    cls_b, bit_b = pm & 0xff, pm >> 8
+    assert np.array_equal(cls_b, p.get("cls").astype(np.int64))
+    lds = img[:gro // 4]
+    got = np.empty((S1, 256), np.int64)
+    for n in range(S1):
+        if n >= N:
+            got[n] = n
+            continue
+        res = np.full(256, -1, np.int64)
+        st = np.full(256, n, np.int64)
+        live = np.ones(256, bool)
+        hops = 0
+        while live.any():
+            idx = np.nonzero(live)[0]
+            s0 = st[idx]
+            rec = np.where((s0 < H)[:, None], lds[(lro // 4 + np.minimum(s0, H - 1) * 4)[:, None] + np.arange(4)] if H else 0,
+                           img[(gro // 4 + s0 * 4)[:, None] + np.arange(4)])
+            if H:
+                in_lds = s0 < H
+                assert np.array_equal(lds[(lro // 4 + s0[in_lds] * 4)[:, None] + np.arange(4)],
+                                      img[(gro // 4 + s0[in_lds] * 4)[:, None] + np.arange(4)])
+            dense = (rec[:, 2] & 0x80000000) != 0
+            o = rec[:, 3] + cls_b[idx]
+            dval = np.where(o < HDE, lds[np.minimum(ldo // 4 + o, len(lds) - 1)], img[np.minimum(gdo // 4 + o, len(img) - 1)])
+            bits = rec[:, 0] | (rec[:, 1] << 32)
+            b = bit_b[idx]
+            sel = (b < 64) & (((bits >> np.minimum(b, 63)) & 1) == 1)
+            low = bits & ((1 << np.minimum(b, 63)) - 1)
+            pop = np.array([bin(int(x)).count("1") for x in low], np.int64)
+            eval_ = img[np.minimum(exo // 4 + rec[:, 3] + pop, len(img) - 1)]
+            fin_now = dense | sel
+            res[idx[fin_now]] = np.where(dense, dval, eval_)[fin_now]
+            st[idx[~fin_now]] = rec[~fin_now, 2]
+            live[idx[fin_now]] = False
+            hops += 1
+            assert hops <= maxchain + 1
+        got[n] = res
+    return got
+
+
+def decode_want(flat, p):
+    """expected next state in the plan's numbering for all (state, byte)"""
+    ref = reference_table(flat)
+    new2old = p.get("new2old").astype(np.int64)
+    new2old[p.S1 - 1] = flat.nstates
+    old2new = np.empty(p.S1, np.int64)
+    old2new[new2old] = np.arange(p.S1)
+    return old2new[ref[new2old]]
 
 
 def check_plan(flat, layout):
@@ -102,6 +164,8 @@ def check_plan(flat, layout):
         got = back[nxt_off]
         assert np.array_equal(cfin[off], fin)
         assert ((off >= p.comb256_abs_min_off) == absorbing).all()
+    elif p.layout == LAYOUT_SPARSE:
+        got = decode_sparse(p, S1)
     else:
         tab = p.get("glob_tab").astype(np.int64)
         st = np.arange(S1)[:, None] * Cn * 4
@@ -125,6 +189,17 @@ def test_auto_layout_choices(built):
     assert Plan(Golden(os.path.join(GOLDEN, "c1.npz")).flat).layout == LAYOUT_TINY
     c3 = Plan(Golden(os.path.join(GOLDEN, "c3.npz")).flat)
     assert c3.layout in (LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_COMB)   # the ~4k-state union must stay LDS resident
+    # a literal set too big for LDS: base-row records (the failure-link form), an order of magnitude smaller
+    rng = np.random.RandomState(9)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", np.uint8)
+    words = [bytes(alpha[rng.randint(0, 36, rng.randint(6, 12))]) for _ in range(3000)]
+    ac = FlatDfa.from_strings(words, 2, list(range(len(words))))
+    pa = Plan(ac)
+    assert pa.layout == LAYOUT_SPARSE
+    img = pa.get("sparse")
+    assert img.size * 4 * 4 < pa.S1 * pa.C * 4 and int(img[12]) <= 7
+    want = decode_want(ac, pa)
+    assert np.array_equal(decode_sparse(pa, pa.S1), want)
 
 
 def test_rejects_non_dfa(built):
