@@ -334,6 +334,10 @@ def main():
                      "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    if a.workload == "c5":
+        res["roofline"]["note"] = ("this walk is bound by L2 gather requests, not by HBM: profiles/r01g_c5_rocprof_summary.json "
+                                   "(TCC_REQ 6.96e9 per 1e7 x 1 KiB launch = 205 G requests/s, 96.5 % hits; a 4-byte gather test peaks "
+                                   "at ~265 G/s, profiles/r01_c5_global_hot.txt); HBM traffic is 3.0x the input bytes")
     if world == 1 and not a.no_cpu_baseline and a.cpu_sample != 0:
         sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if a.workload == "c2" else 100_000)
         sample = min(sample, n)

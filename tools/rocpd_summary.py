@@ -48,6 +48,14 @@ def main():
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
                 "note": "read side = FETCH_SIZE KiB x 1024 x 2 (gfx950: 128-B requests tallied as 64 B for 16-B/lane streams); write side as reported"},
     }
+    l2db = glob.glob(os.path.join(prof, "l2", "*.db"))
+    if l2db:  # optional pass: L2 (TCC) request / hit / miss counts per walk launch
+        r = rows(l2db[0], "select counter_name, counter_value from pmc_events where name like '%walk_%'")
+        l2 = {}
+        for x in r:
+            l2.setdefault(x["counter_name"], []).append(x["counter_value"])
+        summary["l2_per_launch"] = {k: sum(v) / len(v) for k, v in l2.items()}
+        summary["l2_per_launch"]["input_bytes_per_launch"] = n * L
     json.dump(summary, open(out + "_rocprof_summary.json", "w"), indent=1)
     json.dump({"n": n, "len": L, "hbm_bytes_per_launch": hbm, "kernel": walk["name"], "source": os.path.basename(out) + "_rocprof_summary.json"},
               open(os.path.join(os.path.dirname(out), f"pmc_{wl}.json"), "w"))
