@@ -5,7 +5,8 @@
 
 A "step" is one pass of the walk kernel over one batch of synthetic inputs that
 is already resident in HBM (generated on the device, so nothing crosses PCIe),
-followed -- for N > 1 -- by the RCCL all-gather of the accept bitmap.  Inputs are
+followed -- for N > 1 -- by the RCCL all-gather of the accept bitmap (asynchronous: it
+overlaps the next step's kernel; all K gathers finish inside the timed region).  Inputs are
 sharded by contiguous global index range, one shard per rank (weak scaling:
 per-GPU work is fixed).  Rank 0 prints ONE JSON line.
 
@@ -255,17 +256,37 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms = []
 
+    # N > 1: the all-gather of step k's bitmap runs on RCCL's stream while step k+1's walk kernel runs
+    # (two bitmap / gather buffers); every gather is waited for before the timed region ends.
+    bms = [bm, torch.zeros_like(bm)] if world > 1 else [bm]
+    gats = [gathered, torch.empty_like(gathered)] if world > 1 else [None]
+    pending = [None, None]
+    tick = [0]
+
     def step(record):
-        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr(), stream=stream)
+        k = tick[0] % len(bms)
+        tick[0] += 1
+        if world > 1 and pending[k] is not None:
+            pending[k].wait()      # stream-level: the gather that last read this bitmap buffer is done
+            pending[k] = None
+        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bms[k].data_ptr(), stream=stream)
         if record:
             kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
         if world > 1:
-            dist.all_gather_into_tensor(gathered, bm)  # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
+            # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
+            pending[k] = dist.all_gather_into_tensor(gats[k], bms[k], async_op=True)
+
+    def drain():
+        for k in range(len(pending)):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(4):  # setup, untimed: the first launches after a long generator kernel run at ramping clocks
         dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr(), stream=stream)
     for _ in range(a.warmup):
         step(False)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -273,6 +294,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -324,7 +346,7 @@ def main():
                         + f"{n} x {L} B synthetic inputs per GPU resident in HBM, 64 inputs/wavefront",
             "inputs_per_gpu": n, "input_len": L, "dfa_states": flat.nstates, "byte_classes": info["nclasses"],
             "table_layout": info["layout_name"], "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"],
-            "waves_per_block": info["waves_per_block"], "sharding": f"{world} contiguous index ranges, all-gather of the accept bitmap" if world > 1 else "single GPU",
+            "waves_per_block": info["waves_per_block"], "sharding": f"{world} contiguous index ranges; RCCL all-gather of each step's accept bitmap, overlapped with the next step's walk" if world > 1 else "single GPU",
             "accepted_inputs": int(acc_t.item()), "requested_inputs_per_gpu": requested,
         },
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
