@@ -41,6 +41,9 @@ struct fsm_hip_dfa {
 	bool resume_ready = false;
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	unsigned long long *d_counter = nullptr;         /* work counter of walk_queue */
+	unsigned char *arena = nullptr;                  /* device scratch of the host-pointer front */
+	size_t arena_bytes = 0;
+	unsigned char *stage = nullptr;                  /* pinned host staging for small calls */
 	int knob_queue = -1;                             /* > 0: ragged fronts claim work per lane (walk_queue) */
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
@@ -302,6 +305,8 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_orig_of) (void)hipFree(d->d_orig_of);
 	if (d->d_emask) (void)hipFree(d->d_emask);
 	if (d->d_counter) (void)hipFree(d->d_counter);
+	if (d->arena) (void)hipFree(d->arena);
+	if (d->stage) (void)hipHostFree(d->stage);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -549,49 +554,88 @@ extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
 /* host-buffer front: stage through HBM                                */
 /* ------------------------------------------------------------------ */
 
-static int exec_host(const struct fsm_hip_dfa *d,
+/*
+ * Host-pointer front.  One device arena per dfa (grow-only up to ARENA_KEEP, so repeated calls --
+ * retest / re(1) issue one per input line -- do no hipMalloc/hipFree), laid out
+ *     [inputs (+32: the generic kernel reads whole aligned 16-byte chunks)] [len] [off] | [end] [bitmap]
+ * Small calls gather their host arrays in one pinned buffer: one H2D copy, the kernel, one D2H copy,
+ * one stream synchronise.  Large inputs are copied straight from the caller's pages.
+ */
+static const size_t ARENA_KEEP = (size_t)256 << 20, STAGE_BYTES = (size_t)1 << 20;
+
+static size_t up256(size_t x) { return (x + 255u) & ~(size_t)255u; }
+
+static int exec_host(const struct fsm_hip_dfa *cd,
 	const unsigned char *base, size_t in_bytes, size_t stride,
 	const uint32_t *len, const uint64_t *off, size_t n,
 	uint32_t *end_out, uint64_t *accept_bitmap)
 {
-	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (cd == nullptr) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
-	unsigned char *d_in = nullptr;
-	uint32_t *d_len = nullptr, *d_end = nullptr;
-	uint64_t *d_off = nullptr, *d_bm = nullptr;
+	if (hipSetDevice(cd->device) != hipSuccess) { errno = ENODEV; return -1; }
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(cd);
 	const size_t nwords = (n + 63) / 64;
+	const size_t o_in = 0, o_len = up256(in_bytes + 32);
+	const size_t o_off = o_len + (len ? up256(n * sizeof(uint32_t)) : 0);
+	const size_t o_end = o_off + (off ? up256((n + 1) * sizeof(uint64_t)) : 0);
+	const size_t o_bm = o_end + (end_out ? up256(n * sizeof(uint32_t)) : 0);
+	const size_t total = o_bm + (accept_bitmap ? up256(nwords * sizeof(uint64_t)) : 0);
+	unsigned char *arena = nullptr;
+	bool temp = false;
 	int rc = -1;
-	/* +32: the generic kernel reads whole aligned 16-byte chunks */
-	HIP_TRY(hipMalloc((void **)&d_in, in_bytes + 32));
-	if (in_bytes) HIP_TRY(hipMemcpy(d_in, base, in_bytes, hipMemcpyHostToDevice));
-	if (len) {
-		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
-		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	}
-	if (off) {
-		HIP_TRY(hipMalloc((void **)&d_off, (n + 1) * sizeof(uint64_t)));
-		HIP_TRY(hipMemcpy(d_off, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-	}
-	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
-	if (accept_bitmap) HIP_TRY(hipMalloc((void **)&d_bm, nwords * sizeof(uint64_t)));
-	if (off) {
-		if (fsm_hip_exec_batch_offsets_device(d, d_in, d_off, n, d_end, d_bm, nullptr) != 0) goto fail;
+	if (total <= d->arena_bytes) {
+		arena = d->arena;
+	} else if (total <= ARENA_KEEP) {
+		if (d->arena) { (void)hipFree(d->arena); d->arena = nullptr; d->arena_bytes = 0; }
+		size_t want = d->arena_bytes ? d->arena_bytes : ((size_t)2 << 20);
+		while (want < total) want *= 2;
+		HIP_TRY(hipMalloc((void **)&d->arena, want));
+		d->arena_bytes = want;
+		arena = d->arena;
 	} else {
-		if (fsm_hip_exec_batch_device(d, d_in, stride, d_len, n, d_end, d_bm, nullptr) != 0) goto fail;
+		HIP_TRY(hipMalloc((void **)&arena, total));
+		temp = true;
 	}
-	HIP_TRY(hipStreamSynchronize(nullptr));
-	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	if (accept_bitmap) HIP_TRY(hipMemcpy(accept_bitmap, d_bm, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	{
+		unsigned char *d_in = arena + o_in;
+		uint32_t *d_len = len ? reinterpret_cast<uint32_t *>(arena + o_len) : nullptr;
+		uint64_t *d_off = off ? reinterpret_cast<uint64_t *>(arena + o_off) : nullptr;
+		uint32_t *d_end = end_out ? reinterpret_cast<uint32_t *>(arena + o_end) : nullptr;
+		uint64_t *d_bm = accept_bitmap ? reinterpret_cast<uint64_t *>(arena + o_bm) : nullptr;
+		const bool small = total <= STAGE_BYTES;
+		if (small && d->stage == nullptr) HIP_TRY(hipHostMalloc((void **)&d->stage, STAGE_BYTES, hipHostMallocDefault));
+		if (small) {
+			/* inputs and side arrays are contiguous in the arena up to o_end: one copy */
+			if (in_bytes) memcpy(d->stage + o_in, base, in_bytes);
+			if (len) memcpy(d->stage + o_len, len, n * sizeof(uint32_t));
+			if (off) memcpy(d->stage + o_off, off, (n + 1) * sizeof(uint64_t));
+			HIP_TRY(hipMemcpyAsync(arena, d->stage, o_end, hipMemcpyHostToDevice, nullptr));
+		} else {
+			if (in_bytes) HIP_TRY(hipMemcpy(d_in, base, in_bytes, hipMemcpyHostToDevice));
+			if (len) HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+			if (off) HIP_TRY(hipMemcpy(d_off, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+		}
+		if (off) {
+			if (fsm_hip_exec_batch_offsets_device(d, d_in, d_off, n, d_end, d_bm, nullptr) != 0) goto fail;
+		} else {
+			if (fsm_hip_exec_batch_device(d, d_in, stride, d_len, n, d_end, d_bm, nullptr) != 0) goto fail;
+		}
+		if (small) {
+			if (total > o_end) HIP_TRY(hipMemcpyAsync(d->stage + o_end, arena + o_end, total - o_end, hipMemcpyDeviceToHost, nullptr));
+			HIP_TRY(hipStreamSynchronize(nullptr));
+			if (end_out) memcpy(end_out, d->stage + o_end, n * sizeof(uint32_t));
+			if (accept_bitmap) memcpy(accept_bitmap, d->stage + o_bm, nwords * sizeof(uint64_t));
+		} else {
+			HIP_TRY(hipStreamSynchronize(nullptr));
+			if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (accept_bitmap) HIP_TRY(hipMemcpy(accept_bitmap, d_bm, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		}
+	}
 	rc = 0;
 fail:
-	{
+	if (temp) {
 		int e = errno;
-		if (d_in) (void)hipFree(d_in);
-		if (d_len) (void)hipFree(d_len);
-		if (d_off) (void)hipFree(d_off);
-		if (d_end) (void)hipFree(d_end);
-		if (d_bm) (void)hipFree(d_bm);
+		(void)hipFree(arena);
 		errno = e;
 	}
 	return rc;
