@@ -76,7 +76,7 @@ struct fsm_hip_dfa_desc {
 	const uint32_t *endid_off;           /* nstates+1 CSR offsets into endids[], or NULL */
 	const uint32_t *endids;              /* sorted unique per state (fsm_endid_get order) */
 	/* eager outputs (src/libfsm/eager_output.c): ids emitted whenever the state is entered,
-	 * start state included (exec.c:126-144).  NULL = none.  At most 64 distinct ids. */
+	 * start state included (exec.c:126-144).  NULL = none. */
 	const uint32_t *eager_off;           /* nstates+1 CSR offsets into eager_ids[], or NULL */
 	const uint32_t *eager_ids;           /* sorted unique per state (fsm_eager_output_get order) */
 };
@@ -183,10 +183,10 @@ int fsm_hip_endid_get(const struct fsm_hip_dfa *dfa, uint32_t end_state,
 /* struct fsm * -> device table.  Checks ONCE what fsm_exec checks on every
  * call (fsm_all(fsm, fsm_isdfa) and fsm_getstart, src/libfsm/exec.c:106-114).
  * NULL + errno=EINVAL if not a DFA / no start; errno=ENOTSUP if the fsm uses
- * captures (fsm_countcaptures > 0: per-byte host callbacks) or more than 64
- * distinct eager-output ids; errno=ENOSYS if libfsm's symbols are not present
- * in the process.  Eager outputs (<= 64 ids) are carried into the table and
- * delivered by fsm_hip_exec_batch_eager*(); the plain exec calls ignore them. */
+ * captures (fsm_countcaptures > 0: per-byte host callbacks); errno=ENOSYS if
+ * libfsm's symbols are not present in the process.  Eager outputs are carried
+ * into the table and delivered by fsm_hip_exec_batch_eager*(); the plain exec
+ * calls ignore them. */
 struct fsm_hip_dfa *fsm_hip_compile(const struct fsm *fsm, unsigned flags);
 
 /* Same signature and result as fsm_exec() (include/fsm/fsm.h:560-562):
@@ -284,8 +284,10 @@ int fsm_hip_ret_get(const struct fsm_hip_dfa *dfa, uint32_t ret_index,
  * include/fsm/fsm.h:311-312; exec.c:126-144) calls it with every output id of
  * the start state and of every state entered, also on inputs that finally do
  * not match.  The batch form returns, per input, the SET of ids emitted as a
- * bit mask: bit k of eager_out[i] <=> id fsm_hip_eager_id(dfa, k) was emitted
- * (ids numbered in ascending order).  end_out is as in fsm_hip_exec_batch. */
+ * bit set of W = fsm_hip_eager_words(dfa) 64-bit words (W = 1 for up to 64
+ * distinct ids): bit k%64 of eager_out[i*W + k/64] <=> id fsm_hip_eager_id(dfa, k)
+ * was emitted (ids numbered in ascending order).  eager_out holds n*W words.
+ * end_out is as in fsm_hip_exec_batch. */
 int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *eager_out);
@@ -295,6 +297,7 @@ int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *dfa,
 	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream);
 
 size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *dfa);
+size_t fsm_hip_eager_words(const struct fsm_hip_dfa *dfa);   /* ceil(id_count / 64), at least 1 */
 uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *dfa, unsigned bit);
 
 /* ------------------------------------------------------------------ */

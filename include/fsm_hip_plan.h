@@ -55,7 +55,10 @@ enum {
 	FSM_HIP_PLAN_COMB_SMASK  = 15, /* u32[] by comb row offset */
 	FSM_HIP_PLAN_EMASK       = 16, /* u64[S1] eager-output masks by renumbered state (empty: none) */
 	FSM_HIP_PLAN_EAGER_IDS   = 17, /* u32[K] ids in ascending order: bit k of a mask */
-	FSM_HIP_PLAN_SPARSE      = 18  /* u32[] image of the sparse layout (header + tables, plan.cpp build_sparse) */
+	FSM_HIP_PLAN_SPARSE      = 18, /* u32[] image of the sparse layout (header + tables, plan.cpp build_sparse) */
+	FSM_HIP_PLAN_EW_OFF      = 19, /* u32[S1+1] wide eager sets (> 64 ids): per state a run of (word, mask) pairs */
+	FSM_HIP_PLAN_EW_WORD     = 20, /* u32[] */
+	FSM_HIP_PLAN_EW_MASK     = 21  /* u64[] */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

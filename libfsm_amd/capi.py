@@ -308,7 +308,8 @@ class Plan:
                  dense=(4, np.uint32), tiny_col=(5, np.uint64), lds_tab=(6, np.uint16), comb=(7, np.uint32),
                  comb_dflt=(8, np.uint32), comb_off=(9, np.uint32), comb_fin=(10, np.uint32), glob_tab=(11, np.uint32),
                  comb256=(12, np.uint32), comb256_off=(13, np.uint32), comb256_fin=(14, np.uint32), comb_smask=(15, np.uint32),
-                 emask=(16, np.uint64), eager_ids=(17, np.uint32), sparse=(18, np.uint32))
+                 emask=(16, np.uint64), eager_ids=(17, np.uint32), sparse=(18, np.uint32),
+                 ew_off=(19, np.uint32), ew_word=(20, np.uint32), ew_mask=(21, np.uint64))
 
     def __init__(self, flat: FlatDfa, flags: int = 0, lds_limit: int = 0):
         lib = load_library()
@@ -467,7 +468,9 @@ class HipDfa:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         n, stride = data.shape
         end = np.empty(n, dtype=np.uint32)
-        eo = np.zeros(n, dtype=np.uint64)
+        self._lib.fsm_hip_eager_words.restype = C.c_size_t
+        W = self._lib.fsm_hip_eager_words(C.c_void_p(self._h))
+        eo = np.zeros((n, W), dtype=np.uint64)
         if lens is not None:
             lens = np.ascontiguousarray(lens, dtype=np.uint32)
         C.set_errno(0)
@@ -478,8 +481,13 @@ class HipDfa:
         self._lib.fsm_hip_eager_id.restype = C.c_uint32
         k = self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h))
         ids = np.array([self._lib.fsm_hip_eager_id(C.c_void_p(self._h), C.c_uint(b)) for b in range(k)], np.uint32)
-        sets = [ids[[b for b in range(k) if (int(m) >> b) & 1]] for m in eo]
+        bits = np.unpackbits(eo.view(np.uint8).reshape(n, W * 8), axis=1, bitorder="little")[:, :k].astype(bool)
+        sets = [ids[row] for row in bits]
         return end, sets
+
+    def eager_id_count(self) -> int:
+        self._lib.fsm_hip_eager_id_count.restype = C.c_size_t
+        return int(self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h)))
 
     def ret_sets(self):
         """The de-duplicated end-id sets, in retlist order."""

@@ -40,6 +40,8 @@ struct fsm_hip_dfa {
 	std::vector<uint32_t> enc_host;                  /* [S1] encoded state per renumbered state */
 	bool resume_ready = false;
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
+	uint32_t *d_ew_off = nullptr, *d_ew_word = nullptr; /* wide eager sets (> 64 ids) */
+	uint64_t *d_ew_mask = nullptr;
 	unsigned long long *d_counter = nullptr;         /* work counter of walk_queue */
 	unsigned char *arena = nullptr;                  /* device scratch of the host-pointer front */
 	size_t arena_bytes = 0;
@@ -274,6 +276,19 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.emask = d->d_emask;
 			a.eager_lo_end = p.eager_lo_end < p.S1 ? d->enc_host[p.eager_lo_end] : 0xFFFFFFFFu;
 			a.eager_hi_begin = p.eager_hi_begin < p.S1 ? d->enc_host[p.eager_hi_begin] : 0xFFFFFFFFu;
+			a.eager_words = p.eager_words;
+			if (p.eager_words > 1) {
+				/* eager-capable layouts (tiny, lds, global) all have fin index == renumbered state */
+				std::vector<uint32_t> w(p.ew_word);
+				std::vector<uint64_t> m(p.ew_mask);
+				if (w.empty()) { w.push_back(0); m.push_back(0); }
+				HIP_TRY(upload(&d->d_ew_off, p.ew_off));
+				HIP_TRY(upload(&d->d_ew_word, w));
+				HIP_TRY(upload(&d->d_ew_mask, m));
+				a.ew_off = d->d_ew_off;
+				a.ew_word = d->d_ew_word;
+				a.ew_mask = d->d_ew_mask;
+			}
 		}
 		a.tab = d->d_tab;
 		a.fin = d->d_fin;
@@ -304,6 +319,9 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
 	if (d->d_orig_of) (void)hipFree(d->d_orig_of);
 	if (d->d_emask) (void)hipFree(d->d_emask);
+	if (d->d_ew_off) (void)hipFree(d->d_ew_off);
+	if (d->d_ew_word) (void)hipFree(d->d_ew_word);
+	if (d->d_ew_mask) (void)hipFree(d->d_ew_mask);
 	if (d->d_counter) (void)hipFree(d->d_counter);
 	if (d->arena) (void)hipFree(d->arena);
 	if (d->stage) (void)hipHostFree(d->stage);
@@ -432,17 +450,25 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 
 /* eager-output walks: the policy wrapped in EagerPol, two kernels only (per-lane loads with four
  * chunks in flight, or the generic one) */
-template <class Pol>
-static hipError_t launch_eager(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+template <class EP>
+static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	void (*k)(const WalkArgs) = nullptr;
-	if (c.mode == IN_GENERIC && c.queue) return launch_queue<EagerPol<Pol>>(c, a, c.counter, grid, block, s);
-	if (c.mode == IN_GENERIC) k = walk_generic<EagerPol<Pol>>;
-	else k = walk_direct<EagerPol<Pol>, 4, 1>;
+	if (c.mode == IN_GENERIC && c.queue) return launch_queue<EP>(c, a, c.counter, grid, block, s);
+	if (c.mode == IN_GENERIC) k = walk_generic<EP>;
+	else k = walk_direct<EP, 4, 1>;
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
 	return hipGetLastError();
+}
+
+template <class Pol>
+static hipError_t launch_eager(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	/* up to 64 ids: the set rides in a register pair; more: it lives in device memory */
+	return a.eager_words > 1 ? launch_eager_pol<EagerWidePol<Pol>>(c, a, grid, block, s)
+	                         : launch_eager_pol<EagerPol<Pol>>(c, a, grid, block, s);
 }
 
 template <template <bool> class PolT>
@@ -780,6 +806,9 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB_SMASK: *data = p.comb_smask.data(); *count = p.comb_smask.size(); return 0;
 	case FSM_HIP_PLAN_EMASK: *data = p.emask.data(); *count = p.emask.size(); return 0;
 	case FSM_HIP_PLAN_EAGER_IDS: *data = p.eager_ids.data(); *count = p.eager_ids.size(); return 0;
+	case FSM_HIP_PLAN_EW_OFF: *data = p.ew_off.data(); *count = p.ew_off.size(); return 0;
+	case FSM_HIP_PLAN_EW_WORD: *data = p.ew_word.data(); *count = p.ew_word.size(); return 0;
+	case FSM_HIP_PLAN_EW_MASK: *data = p.ew_mask.data(); *count = p.ew_mask.size(); return 0;
 	default: errno = EINVAL; return -1;
 	}
 }
@@ -1184,6 +1213,11 @@ extern "C" size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *d)
 	return d == nullptr ? 0 : d->plan.eager_ids.size();
 }
 
+extern "C" size_t fsm_hip_eager_words(const struct fsm_hip_dfa *d)
+{
+	return d == nullptr || d->plan.eager_words == 0 ? 1 : d->plan.eager_words;
+}
+
 extern "C" uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *d, unsigned bit)
 {
 	if (d == nullptr || bit >= d->plan.eager_ids.size()) return FSM_HIP_NO_MATCH;
@@ -1201,6 +1235,11 @@ extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
 		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
 		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 		return fsm_hip_exec_batch_device(d, d_base, stride, d_len, n, d_end_out, nullptr, hip_stream);
+	}
+	if (d->plan.eager_words > 1) {
+		/* wide sets are OR-ed in place by the kernel: start from zero */
+		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * d->plan.eager_words * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
+		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 	}
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
@@ -1227,6 +1266,7 @@ extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 	unsigned char *d_in = nullptr;
 	uint32_t *d_len = nullptr, *d_end = nullptr;
 	uint64_t *d_eo = nullptr;
+	const size_t words = fsm_hip_eager_words(d);
 	int rc = -1;
 	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
 	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
@@ -1235,11 +1275,11 @@ extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **)&d_eo, n * sizeof(uint64_t)));
+	HIP_TRY(hipMalloc((void **)&d_eo, n * words * sizeof(uint64_t)));
 	if (fsm_hip_exec_batch_eager_device(d, d_in, stride, d_len, n, d_end, d_eo, nullptr) != 0) goto fail;
 	HIP_TRY(hipStreamSynchronize(nullptr));
 	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(eager_out, d_eo, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(eager_out, d_eo, n * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	rc = 0;
 fail:
 	{

@@ -110,16 +110,19 @@ try {
 		p.eager_ids.assign(d->eager_ids, d->eager_ids + d->eager_off[S]);
 		std::sort(p.eager_ids.begin(), p.eager_ids.end());
 		p.eager_ids.erase(std::unique(p.eager_ids.begin(), p.eager_ids.end()), p.eager_ids.end());
-		if (p.eager_ids.size() > 64) return ENOTSUP;
+		/* up to 64 ids: one mask per state, carried in a register pair by the walk; more: the mask
+		 * only says "emits something" and the ids go into per-state (word, mask) lists (below) */
+		const bool wide = p.eager_ids.size() > 64;
 		for (uint32_t s = 0; s < S; s++) {
 			if (d->eager_off[s + 1] < d->eager_off[s]) return EINVAL;
 			for (uint32_t k = d->eager_off[s]; k < d->eager_off[s + 1]; k++) {
 				size_t bit = std::lower_bound(p.eager_ids.begin(), p.eager_ids.end(), d->eager_ids[k]) - p.eager_ids.begin();
-				emask_old[s] |= (uint64_t)1 << bit;
+				emask_old[s] |= wide ? (uint64_t)1 : (uint64_t)1 << bit;
 			}
 		}
 	}
 	const bool has_eager = !p.eager_ids.empty();
+	p.eager_words = (uint32_t)((p.eager_ids.size() + 63u) / 64u);
 
 	/* 4: renumber */
 	std::vector<uint8_t> absorbing(S1, 0);
@@ -168,9 +171,30 @@ try {
 		if (d->is_end[o]) p.fin[n] = o;
 	}
 	p.emask.clear();
+	p.ew_off.clear();
+	p.ew_word.clear();
+	p.ew_mask.clear();
 	if (has_eager) {
 		p.emask.assign(S1, 0);
 		for (uint32_t n = 0; n + 1 < S1; n++) p.emask[n] = emask_old[p.new2old[n]];
+		if (p.eager_words > 1) {
+			/* wide sets: per renumbered state the 64-bit words of the id set it touches */
+			p.ew_off.assign((size_t)S1 + 1, 0);
+			for (uint32_t n = 0; n + 1 < S1; n++) {
+				const uint32_t o = p.new2old[n];
+				p.ew_off[n] = (uint32_t)p.ew_word.size();
+				for (uint32_t k = d->eager_off[o]; k < d->eager_off[o + 1]; k++) {   /* ids of a state are sorted */
+					const size_t bit = std::lower_bound(p.eager_ids.begin(), p.eager_ids.end(), d->eager_ids[k]) - p.eager_ids.begin();
+					const uint32_t w = (uint32_t)(bit / 64u);
+					if (p.ew_word.size() == p.ew_off[n] || p.ew_word.back() != w) {
+						p.ew_word.push_back(w);
+						p.ew_mask.push_back(0);
+					}
+					p.ew_mask.back() |= (uint64_t)1 << (bit % 64u);
+				}
+			}
+			p.ew_off[S1 - 1] = p.ew_off[S1] = (uint32_t)p.ew_word.size();
+		}
 	} else {
 		p.eager_lo_end = 0;
 		p.eager_hi_begin = 0xFFFFFFFFu;

@@ -40,6 +40,11 @@ struct Plan {
 	std::vector<uint32_t> eager_ids;
 	std::vector<uint64_t> emask;      /* [S1], empty if the DFA has no eager outputs */
 	uint32_t eager_lo_end = 0, eager_hi_begin = 0xFFFFFFFFu;
+	/* more than 64 ids: emask[] only flags the emitting states; state n ORs ew_mask[k] into word
+	 * ew_word[k] of the input's id set for k in [ew_off[n], ew_off[n+1]) */
+	uint32_t eager_words = 0;         /* 64-bit words per id set: ceil(#ids / 64) */
+	std::vector<uint32_t> ew_off, ew_word;
+	std::vector<uint64_t> ew_mask;
 
 	uint32_t layout = 0;          /* FSM_HIP_LAYOUT_* chosen */
 

@@ -81,6 +81,12 @@ struct WalkArgs {
 	const uint64_t *emask;
 	uint64_t       *eager_out;
 	uint32_t        eager_lo_end, eager_hi_begin;
+	/* more than 64 eager ids: eager_out holds eager_words u64 per input; a state's ids are the
+	 * (word, mask) pairs ew_word/ew_mask[ew_off[idx] .. ew_off[idx+1]) with idx as for fin */
+	uint32_t        eager_words;
+	const uint32_t *ew_off;
+	const uint32_t *ew_word;
+	const uint64_t *ew_mask;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu
@@ -457,6 +463,99 @@ struct EagerPol : Pol {
 	}
 };
 
+/*
+ * EagerWidePol<Pol>: the same side channel for more than 64 ids.  The id set of input i is
+ * eager_words u64 in device memory, owned by the lane that walks i: entering a state with outputs
+ * ORs that state's (word, mask) pairs into it (plain read-modify-write, no atomics; rare).  The
+ * buffer is zeroed on the launch stream before the kernel.
+ */
+template <class Pol>
+struct EagerWideState {
+	typename Pol::S s;
+	uint64_t *row;     /* NULL for lanes without an input */
+	uint32_t pend;     /* encoded state whose outputs are not written yet, or NONE */
+};
+
+template <class Pol>
+struct EagerWidePol : Pol {
+	typedef EagerWideState<Pol> S;
+	typedef typename Pol::P P;
+	const uint32_t *ew_off, *ew_word;
+	const uint64_t *ew_mask;
+	uint32_t lo_end, hi_begin, fin_div;
+
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		Pol::setup(lds, a);
+		ew_off = a.ew_off;
+		ew_word = a.ew_word;
+		ew_mask = a.ew_mask;
+		lo_end = a.eager_lo_end;
+		hi_begin = a.eager_hi_begin;
+		fin_div = a.fin_div;
+	}
+	__device__ __forceinline__ bool emits(uint32_t c) const { return c < lo_end || c >= hi_begin; }
+	__device__ __forceinline__ void emit(uint32_t c, uint64_t *row) const
+	{
+		if (c != 0xFFFFFFFFu && row != nullptr) {
+			const uint32_t idx = c / fin_div;
+			for (uint32_t k = ew_off[idx]; k < ew_off[idx + 1]; k++) row[ew_word[k]] |= ew_mask[k];
+		}
+	}
+	__device__ __forceinline__ S init_at(uint32_t code, const WalkArgs &a, uint64_t i, bool valid) const
+	{
+		S st;
+		st.s = Pol::init(code);
+		st.row = valid ? a.eager_out + i * a.eager_words : nullptr;
+		st.pend = emits(code) ? code : 0xFFFFFFFFu;   /* the start state emits before any input (exec.c:126-130) */
+		return st;
+	}
+	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
+	/* The kernels may compute next() for a byte past the end of a ragged input and drop the result,
+	 * so a step must not write.  The state handed IN is committed: its pending outputs are written
+	 * here, the new state's are left pending (the last one is written by finish()). */
+	__device__ __forceinline__ S next(S st, P p) const
+	{
+		emit(st.pend, st.row);
+		const uint32_t before = Pol::code(st.s);
+		st.s = Pol::next(st.s, p);
+		const uint32_t c = Pol::code(st.s);
+		/* fsm_exec emits on every transition INTO a state, self-loops included (exec.c:139-144); OR is
+		 * idempotent, so re-entering the same state need not write again */
+		st.pend = (c != before && emits(c)) ? c : 0xFFFFFFFFu;
+		return st;
+	}
+	__device__ __forceinline__ void finish_at(const S &st) const { emit(st.pend, st.row); }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
+};
+
+/* the state an input starts from: policies that need the input index define init_at() */
+template <class Pol>
+__device__ __forceinline__ auto init_state(const Pol &pol, uint32_t code, const WalkArgs &a, uint64_t i, bool valid, int)
+	-> decltype(pol.init_at(code, a, i, valid))
+{
+	return pol.init_at(code, a, i, valid);
+}
+template <class Pol>
+__device__ __forceinline__ typename Pol::S init_state(const Pol &pol, uint32_t code, const WalkArgs &, uint64_t, bool, long)
+{
+	return pol.init(code);
+}
+
+/* end of an input: policies with deferred side effects define finish_at() */
+template <class Pol>
+__device__ __forceinline__ auto finish_state(const Pol &pol, const WalkArgs &a, uint64_t i, bool valid, const typename Pol::S &st, int)
+	-> decltype(pol.finish_at(st))
+{
+	pol.finish_at(st);
+	Pol::finish(a, i, valid, st);
+}
+template <class Pol>
+__device__ __forceinline__ void finish_state(const Pol &, const WalkArgs &a, uint64_t i, bool valid, const typename Pol::S &st, long)
+{
+	Pol::finish(a, i, valid, st);
+}
+
 /* 16 input bytes of ROWS independent rows: all state-independent lookups
  * first, then the ROWS state chains interleaved byte by byte. */
 template <class Pol, int ROWS>
@@ -516,7 +615,7 @@ walk_direct(const WalkArgs a)
 		for (int r = 0; r < ROWS; r++) {
 			i[r] = (tile * ROWS + r) * 64u + lane;
 			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
-			st[r] = pol.init(start_code(a, i[r], i[r] < a.n));
+			st[r] = init_state(pol, start_code(a, i[r], i[r] < a.n), a, i[r], i[r] < a.n, 0);
 		}
 #pragma unroll
 		for (int j = 0; j < NB; j++)
@@ -545,7 +644,7 @@ walk_direct(const WalkArgs a)
 #pragma unroll
 		for (int r = 0; r < ROWS; r++) {
 			write_result(a, tile * ROWS + r, i[r], i[r] < a.n, Pol::code(st[r]));
-			Pol::finish(a, i[r], i[r] < a.n, st[r]);
+			finish_state(pol, a, i[r], i[r] < a.n, st[r], 0);
 		}
 	}
 }
@@ -569,7 +668,7 @@ walk_direct_np(const WalkArgs a)
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
 		const uint64_t i = tile * 64u + lane;
 		const u32x4 *q = reinterpret_cast<const u32x4 *>(a.base + (i < a.n ? i : a.n - 1) * a.stride);
-		typename Pol::S st[1] = { pol.init(start_code(a, i, i < a.n)) };
+		typename Pol::S st[1] = { init_state(pol, start_code(a, i, i < a.n), a, i, i < a.n, 0) };
 		for (uint32_t g = 0; g < ngroups; g++) {
 			u32x4 cur[NB][1];
 			/* (a.early & 2): a lane whose input can no longer change state stops reading it, as
@@ -586,7 +685,7 @@ walk_direct_np(const WalkArgs a)
 			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min)) break;
 		}
 		write_result(a, tile, i, i < a.n, Pol::code(st[0]));
-		Pol::finish(a, i, i < a.n, st[0]);
+		finish_state(pol, a, i, i < a.n, st[0], 0);
 	}
 }
 
@@ -651,7 +750,7 @@ walk_ldsdma(const WalkArgs a)
 			const uint32_t piece = (lq - ((ri >> ROTSH) & (PIECES - 1u))) & (PIECES - 1u);
 			src[j] = a.base + row * a.stride + piece * 16u;
 		}
-		typename Pol::S st[1] = { pol.init(start_code(a, i, valid)) };
+		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
 #pragma unroll
 		for (uint32_t j = 0; j < NDMA; j++)
 			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
@@ -678,7 +777,7 @@ walk_ldsdma(const WalkArgs a)
 			}
 		}
 		write_result(a, tile, i, valid, Pol::code(st[0]));
-		Pol::finish(a, i, valid, st[0]);
+		finish_state(pol, a, i, valid, st[0], 0);
 	}
 }
 
@@ -714,7 +813,7 @@ walk_generic(const WalkArgs a)
 		const uint32_t head = (uint32_t)(p0 - q0);
 		const uint64_t span = len ? head + len : 0;
 		const uint64_t nchunks = (span + 15u) / 16u;
-		typename Pol::S st[1] = { pol.init(start_code(a, i, valid)) };
+		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
 		u32x4 w[1] = { {0u, 0u, 0u, 0u} };
 		if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
 		for (uint64_t c = 0; __any(c < nchunks); c++) {
@@ -741,7 +840,7 @@ walk_generic(const WalkArgs a)
 			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
 		write_result(a, tile, i, valid, Pol::code(st[0]));
-		Pol::finish(a, i, valid, st[0]);
+		finish_state(pol, a, i, valid, st[0], 0);
 	}
 }
 
@@ -782,7 +881,7 @@ walk_queue(const WalkArgs a, unsigned long long *counter)
 	bool have = false;
 	uint64_t i = 0, q0 = 0, span = 0, c = 0, nchunks = 0;
 	uint32_t head = 0;
-	typename Pol::S st[1] = { pol.init(a.start) };
+	typename Pol::S st[1] = { init_state(pol, a.start, a, 0, false, 0) };
 	u32x4 w[1] = { {0u, 0u, 0u, 0u} };
 
 	/* wave-local pool of claimed input indices [pool, pool_end): one atomicAdd per QCHUNK inputs
@@ -818,7 +917,7 @@ walk_queue(const WalkArgs a, unsigned long long *counter)
 					span = len ? head + len : 0;
 					nchunks = (span + 15u) / 16u;
 					c = 0;
-					st[0] = pol.init(start_code(a, i, true));
+					st[0] = init_state(pol, start_code(a, i, true), a, i, true, 0);
 					have = true;
 					if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
 				}
@@ -850,7 +949,7 @@ walk_queue(const WalkArgs a, unsigned long long *counter)
 			}
 			if (c >= nchunks || ((a.early & 1u) && Pol::code(st[0]) >= a.abs_min)) {
 				write_result_lane(a, i, Pol::code(st[0]));
-				Pol::finish(a, i, true, st[0]);
+				finish_state(pol, a, i, true, st[0], 0);
 				have = false;
 			}
 		}

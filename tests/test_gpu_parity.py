@@ -574,6 +574,90 @@ def test_eager_outputs_live_reference_through_shim(hip):
     dfa.close()
 
 
+def random_eager_dfa(rng, S, nids, alphabet=b"abcdefgh"):
+    """A random complete DFA over `alphabet` whose states carry random eager-output ids out of nids."""
+    from libfsm_amd import FlatDfa
+    nt = np.full((S, 256), -1, np.int64)
+    for c in alphabet:
+        nt[:, c] = rng.randint(0, S, S)
+    nt[S - 1, :] = -1
+    for c in alphabet:
+        nt[S - 1, c] = S - 1                      # one absorbing state, also with outputs
+    flat = FlatDfa.from_dense(nt, 0, (rng.rand(S) < 0.3).astype(int).tolist())
+    pool = np.sort(rng.choice(np.arange(1, 10 * nids), nids, replace=False)).astype(np.uint32)
+    off, ids = [0], []
+    for s_ in range(S):
+        k = rng.randint(0, 4) if rng.rand() < 0.4 or s_ in (0, S - 1) else 0
+        ids.extend(sorted(set(int(x) for x in rng.choice(pool, k))))
+        off.append(len(ids))
+    # make sure every id is used somewhere, so the table has exactly nids distinct ids
+    missing = sorted(set(pool.tolist()) - set(ids))
+    ids.extend(missing)
+    off[-1] = len(ids)
+    ids[off[S - 1]:] = sorted(set(ids[off[S - 1]:]))
+    off[-1] = len(ids)
+    flat.eager_off = np.array(off, np.uint32)
+    flat.eager_ids = np.array(ids, np.uint32)
+    return flat
+
+
+@pytest.mark.parametrize("nids", [64, 65, 200, 1000])
+def test_eager_outputs_wide_sets(hip, nids):
+    """More than 64 distinct eager ids: the id set of an input is W = ceil(ids/64) words in device memory,
+    OR-ed by the owning lane.  Random DFAs against the oracle, every eager-capable layout, both kernels,
+    ragged lengths; W = 1 (64 ids) stays on the register path."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(nids)
+    for S in (7, 300, 40000):
+        flat = random_eager_dfa(rng, S, nids)
+        rows = np.frombuffer(b"abcdefgh", np.uint8)[rng.randint(0, 8, (700, 48))]
+        lens = rng.randint(0, 49, 700).astype(np.uint32)
+        o = Oracle(flat)
+        want = {None: o.exec_eager(rows, None, cap=nids + 8), "r": o.exec_eager(rows, lens, cap=nids + 8)}
+        assert max(len(x) for x in want[None][2]) >= 3
+        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_GLOBAL, hip.LAYOUT_AUTO):
+            try:
+                dfa = hip.HipDfa(flat, L)
+            except OSError:
+                continue
+            assert dfa.eager_id_count() == nids
+            for mode in (hip.IN_GENERIC, hip.IN_DIRECT):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                for key, ln in ((None, None), ("r", lens)):
+                    end, sets = dfa.exec_batch_eager(rows, ln)
+                    _, wend, wsets = want[key]
+                    assert np.array_equal(end, wend), (S, L, mode, key)
+                    for i in range(len(rows)):
+                        assert np.array_equal(sets[i], wsets[i]), (S, L, mode, key, i)
+            dfa.close()
+
+
+def test_eager_outputs_wide_live_reference(hip):
+    """fsm_union_repeated_pattern_group over 150 patterns (150 eager ids) through fsm_hip_compile vs the
+    reference's fsm_exec + callback."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    rng = np.random.RandomState(8)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 26, rng.randint(3, 6))]) for _ in range(150)))[:150]
+    f = RefFsm.union_repeated("pcre", words, 1, False)
+    dfa = hip.HipDfa.compile_fsm(f.ptr)
+    assert dfa.eager_id_count() == len(words) > 64
+    strings = [b" ".join(words[k] for k in rng.randint(0, len(words), rng.randint(0, 12))) for _ in range(600)]
+    ret, end, sets = f.exec_eager_strings(strings, cap=256)
+    stride = (max(len(s) for s in strings) + 15) // 16 * 16
+    rows = np.zeros((len(strings), stride), np.uint8)
+    lens = np.array([len(s) for s in strings], np.uint32)
+    for i, s_ in enumerate(strings):
+        rows[i, :len(s_)] = np.frombuffer(s_, np.uint8)
+    gend, gsets = dfa.exec_batch_eager(rows, lens)
+    assert np.array_equal(gend, end)
+    assert sum(len(x) for x in sets) > 2000
+    for i in range(len(strings)):
+        assert np.array_equal(gsets[i], sets[i]), strings[i]
+    dfa.close()
+
+
 def test_reference_fsm_corpus(hip):
     """The 319 out*.fsm automata of the reference's golden-DFA tests, 8 843 inputs: HIP == fsm_exec
     (auto layout, the HBM-resident layout, and the LDS-dense layout where it fits)."""
@@ -628,17 +712,6 @@ def test_error_contracts(hip):
     # a DFA without eager outputs answers the eager front with empty sets
     end, sets = dfa.exec_batch_eager(rows)
     assert np.array_equal(end, g.end[:64]) and all(len(s) == 0 for s in sets)
-    # more than 64 distinct eager ids: ENOTSUP at creation
-    from libfsm_amd import FlatDfa
-    nt = np.full((70, 256), -1, np.int64)
-    for s in range(69):
-        nt[s, ord("a")] = s + 1
-    flat = FlatDfa.from_dense(nt, 0, [0] * 69 + [1])
-    flat.eager_off = np.arange(71, dtype=np.uint32)
-    flat.eager_ids = np.arange(70, dtype=np.uint32)
-    with pytest.raises(OSError) as ei:
-        hip.HipDfa(flat)
-    assert ei.value.errno == _errno.ENOTSUP
     dfa.close()
 
 

@@ -202,6 +202,41 @@ def test_auto_layout_choices(built):
     assert np.array_equal(decode_sparse(pa, pa.S1), want)
 
 
+def test_wide_eager_sets(built):
+    """More than 64 eager ids: per state the (word, mask) pairs spell exactly the state's id list."""
+    from libfsm_amd.capi import RANGE_DTYPE
+    rng = np.random.RandomState(3)
+    S, nids = 500, 300
+    nt = np.full((S, 256), -1, np.int64)
+    for c in b"abc":
+        nt[:, c] = rng.randint(0, S, S)
+    flat = FlatDfa.from_dense(nt, 0, [1] * S)
+    pool = np.arange(5, 5 + 3 * nids, 3, dtype=np.uint32)
+    off, ids = [0], []
+    for s_ in range(S):
+        ids.extend(sorted(set(int(x) for x in rng.choice(pool, rng.randint(0, 5)))))
+        off.append(len(ids))
+    ids.extend(sorted(set(pool.tolist()) - set(ids)))
+    ids[off[S - 1]:] = sorted(set(ids[off[S - 1]:]))
+    off[-1] = len(ids)
+    flat.eager_off, flat.eager_ids = np.array(off, np.uint32), np.array(ids, np.uint32)
+    p = Plan(flat, LAYOUT_GLOBAL)
+    eids = p.get("eager_ids")
+    assert list(eids) == pool.tolist()
+    eo, ew, em = p.get("ew_off"), p.get("ew_word"), p.get("ew_mask")
+    new2old = p.get("new2old")
+    flags = p.get("emask")
+    assert len(eo) == p.S1 + 1
+    for n in range(p.S1 - 1):
+        got = []
+        for k in range(int(eo[n]), int(eo[n + 1])):
+            got.extend(int(eids[64 * int(ew[k]) + b]) for b in range(64) if (int(em[k]) >> b) & 1)
+        want = flat.eager_of(int(new2old[n])).tolist()
+        assert got == want
+        assert (flags[n] != 0) == (len(want) > 0) == (n < p.eager_lo_end or n >= p.eager_hi_begin)
+    assert eo[p.S1 - 1] == eo[p.S1]
+
+
 def test_rejects_non_dfa(built):
     from libfsm_amd.capi import RANGE_DTYPE
     r = np.zeros(2, RANGE_DTYPE)
