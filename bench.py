@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
-    ap.add_argument("--n", type=int, default=0, help="inputs per GPU (default 1e8; c5: 1e7)")
+    ap.add_argument("--n", "--inputs", dest="n", type=int, default=0, help="inputs per GPU (default 1e8; c5: 1e7)")
     ap.add_argument("--c5-words", type=int, default=100_000, help="c5: number of literals")
     ap.add_argument("--len", type=int, default=1024, help="bytes per input")
     ap.add_argument("--input-mode", type=int, default=-1)
@@ -203,10 +203,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
+    # FSM_BENCH_BACKEND=gloo lets the N > 1 plumbing be exercised on a box with fewer GPUs than ranks
+    # (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu); the real runs use RCCL.
+    backend = os.environ.get("FSM_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -820,3 +820,26 @@ def test_differential_fuzz_against_reference(hip):
         dfa.close()
     assert n_re >= 100 and n_in >= 20000 and n_acc >= 1500, (n_re, n_in, n_acc)
     assert len(layouts) >= 2, layouts
+
+
+def test_bench_two_ranks_share_one_gpu(hip):
+    """bench.py's N > 1 path (sharding by global index, asynchronous bitmap all-gather, barrier + max-over-ranks
+    timing, one JSON line from rank 0) with two ranks on this box's single GPU over gloo; RCCL itself only
+    runs on the multi-GPU node."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--inputs", "262144"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["inputs_per_gpu"] == 262144
+    # every 8th input of the 2 x 262144 carries the planted match (plus chance matches)
+    assert abs(r["config"]["accepted_inputs"] - 2 * 262144 // 8) < 64
+    assert "cpu_baseline" not in r
