@@ -361,13 +361,12 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
 	c.mask = d->knob_mask > 0 ? 1 : 0;
 	if (fast_ok) {
-		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging wins while the table leaves room for
-		 * per-wave tiles; per-lane loads with 8 chunks in flight win next to a big LDS table */
-		/* LDS-DMA tiles (8 KiB per wave) are the better input path whenever at least 12 waves of
-		 * them fit next to the table (profiles/r01_sweep10*: lds layout 5.1 vs 4.8 TB/s); the
-		 * latency-bound CombSelfPol prefers 2 x 16 waves of the register-light direct kernel */
+		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging (8 KiB tile per wave) is the better input
+		 * path whenever at least 12 waves of tiles fit next to the table (lds layout 5.1 vs 4.8 TB/s;
+		 * combself, once whole self-loop chunks are skipped, 6.1 vs 5.0 TB/s: profiles/r01_sweep11*);
+		 * per-lane loads with 8 chunks in flight next to a bigger LDS table */
 		const bool dma_fits = d->table_lds + 12u * 8192u <= d->lds_limit;
-		int mode = (layout == FSM_HIP_LAYOUT_TINY || (dma_fits && layout != FSM_HIP_LAYOUT_COMBSELF)) ? IN_LDSDMA : IN_DIRECT;
+		int mode = (layout == FSM_HIP_LAYOUT_TINY || dma_fits) ? IN_LDSDMA : IN_DIRECT;
 		if (d->knob_input_mode >= 0) mode = d->knob_input_mode;
 		if (mode == IN_LDSDMA && stride % 64u != 0) mode = IN_DIRECT;
 		c.mode = mode;
@@ -387,7 +386,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
 	/* waves per block: as many as LDS allows, 16 at most */
 	/* 16 waves behind one table copy; with nontemporal DMA loads the 16-wave workgroup (32 KiB
 	 * table + 16 x 8 KiB tiles = all 160 KiB of LDS) measured best for tiny (profiles/r01_sweep8*) */
-	int waves = d->knob_waves > 0 ? d->knob_waves : 16;
+	/* combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72) */
+	int waves = d->knob_waves > 0 ? d->knob_waves : (layout == FSM_HIP_LAYOUT_COMBSELF && c.mode == IN_LDSDMA ? 12 : 16);
 	if (waves > 16) waves = 16;
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
 	c.waves = waves;

@@ -292,6 +292,15 @@ struct CombSelfPol {
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	/* all 16 classes of the chunk are self-loops of every lane's state (digit runs, dead lanes):
+	 * 16 shift-ORs and one wave vote replace 16 test-and-branch steps */
+	__device__ __forceinline__ bool skip16(const S &s, const P (&c)[16]) const
+	{
+		uint32_t m = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) m |= 1u << c[k];
+		return __all((m & ~s.sm) == 0u);
+	}
 	__device__ __forceinline__ S next(S s, P c) const
 	{
 		if (!((s.sm >> c) & 1u)) {
@@ -558,6 +567,19 @@ __device__ __forceinline__ void finish_state(const Pol &, const WalkArgs &a, uin
 
 /* 16 input bytes of ROWS independent rows: all state-independent lookups
  * first, then the ROWS state chains interleaved byte by byte. */
+/* a policy may know cheaply that none of 16 bytes changes the state of ANY lane (skip16) */
+template <class Pol>
+__device__ __forceinline__ auto skip_chunk(const Pol &pol, const typename Pol::S &st, const typename Pol::P (&pre)[16], int)
+	-> decltype(pol.skip16(st, pre))
+{
+	return pol.skip16(st, pre);
+}
+template <class Pol>
+__device__ __forceinline__ bool skip_chunk(const Pol &, const typename Pol::S &, const typename Pol::P (&)[16], long)
+{
+	return false;
+}
+
 template <class Pol, int ROWS>
 __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
@@ -566,6 +588,7 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 	for (int r = 0; r < ROWS; r++)
 #pragma unroll
 		for (int k = 0; k < 16; k++) pre[r][k] = pol.pre(byte_of(w[r], k));
+	if (ROWS == 1 && skip_chunk(pol, st[0], pre[0], 0)) return;
 #pragma unroll
 	for (int k = 0; k < 16; k++)
 #pragma unroll
