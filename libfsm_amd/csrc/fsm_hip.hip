@@ -143,6 +143,18 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		std::vector<uint32_t> btab(256);
 		switch (p.layout) {
 		case FSM_HIP_LAYOUT_TINY: {
+			if (!p.tiny5_col.empty()) {   /* <= 6 states: Tiny5Pol, state code = 5 * state */
+				uint32_t *t = nullptr;
+				HIP_TRY(upload(&t, p.tiny5_col));
+				d->d_tab = t;
+				HIP_TRY(upload(&d->d_fin, p.fin));
+				a.tab_bytes = 256 * 4;
+				a.start = p.start * 5u;
+				a.abs_min = p.abs_min * 5u;
+				a.fin_div = 5;
+				d->table_lds = Tiny5Pol::lds_bytes(0);
+				break;
+			}
 			uint64_t *t = nullptr;
 			HIP_TRY(upload(&t, p.tiny_col));
 			d->d_tab = t;
@@ -257,7 +269,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		d->enc_host.resize(p.S1);
 		for (uint32_t n2 = 0; n2 < p.S1; n2++) {
 			switch (p.layout) {
-			case FSM_HIP_LAYOUT_TINY:
+			case FSM_HIP_LAYOUT_TINY: d->enc_host[n2] = p.tiny5_col.empty() ? n2 : n2 * 5u; break;
 			case FSM_HIP_LAYOUT_SPARSE: d->enc_host[n2] = n2; break;
 			case FSM_HIP_LAYOUT_LDS: d->enc_host[n2] = n2 * p.row_bytes; break;
 			case FSM_HIP_LAYOUT_COMB:
@@ -501,7 +513,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		if (eager) {
 			switch (d->plan.layout) {
 			case FSM_HIP_LAYOUT_TINY:
-				e = d->plan.S1 <= 8 ? launch_eager<TinyPol<uint32_t>>(c, a, grid, block, s)
+				e = !d->plan.tiny5_col.empty() ? launch_eager<Tiny5Pol>(c, a, grid, block, s)
+				  : d->plan.S1 <= 8 ? launch_eager<TinyPol<uint32_t>>(c, a, grid, block, s)
 				                    : launch_eager<TinyPol<uint64_t>>(c, a, grid, block, s);
 				break;
 			case FSM_HIP_LAYOUT_LDS: e = launch_eager<LdsPol<false>>(c, a, grid, block, s); break;
@@ -510,7 +523,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		} else
 		switch (d->plan.layout) {
 		case FSM_HIP_LAYOUT_TINY:
-			e = d->plan.S1 <= 8 ? launch_pol<TinyPol<uint32_t>>(c, a, grid, block, s)
+			e = !d->plan.tiny5_col.empty() ? launch_pol<Tiny5Pol>(c, a, grid, block, s)
+			  : d->plan.S1 <= 8 ? launch_pol<TinyPol<uint32_t>>(c, a, grid, block, s)
 			                    : launch_pol<TinyPol<uint64_t>>(c, a, grid, block, s);
 			break;
 		case FSM_HIP_LAYOUT_LDS:     e = launch_masked<LdsPol>(c, a, grid, block, s); break;
@@ -793,6 +807,7 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_FIN: *data = p.fin.data(); *count = p.fin.size(); return 0;
 	case FSM_HIP_PLAN_DENSE: *data = p.dense.data(); *count = p.dense.size(); return 0;
 	case FSM_HIP_PLAN_TINY_COL: *data = p.tiny_col.data(); *count = p.tiny_col.size(); return 0;
+	case FSM_HIP_PLAN_TINY5_COL: *data = p.tiny5_col.data(); *count = p.tiny5_col.size(); return 0;
 	case FSM_HIP_PLAN_LDS_TAB: *data = p.lds_tab.data(); *count = p.lds_tab.size(); return 0;
 	case FSM_HIP_PLAN_COMB: *data = p.comb.data(); *count = p.comb.size(); return 0;
 	case FSM_HIP_PLAN_COMB_DFLT: *data = p.comb_dflt.data(); *count = p.comb_dflt.size(); return 0;

@@ -240,6 +240,18 @@ try {
 			}
 			p.tiny_col[b] = v;
 		}
+		p.tiny5_col.clear();
+		if (S1 <= 6) {   /* 5-bit fields holding 5 * next(s): Tiny5Pol */
+			p.tiny5_col.assign(256, 0);
+			for (unsigned b = 0; b < 256; b++) {
+				uint32_t v = 0;
+				for (uint32_t s = 0; s < 6; s++) {
+					uint32_t t = s < S1 ? p.dense[(size_t)s * C + p.cls[b]] : s;
+					v |= (5u * t) << (5 * s);
+				}
+				p.tiny5_col[b] = v;
+			}
+		}
 		p.layout = FSM_HIP_LAYOUT_TINY;
 		return 0;
 	};

@@ -51,6 +51,8 @@ struct Plan {
 	/* ---- device images (host copies) ---- */
 	/* TINY: col[256] = 16 nibbles, nibble s = next state of s on that byte */
 	std::vector<uint64_t> tiny_col;
+	/* <= 6 states: col5[256], field s (5 bits at bit 5 s) = 5 * next state of s on that byte */
+	std::vector<uint32_t> tiny5_col;
 	/* LDS dense: u16 entries, row stride row_bytes (multiple of 4);
 	 * entry = next_state * (row_bytes/4)                                   */
 	std::vector<uint16_t> lds_tab;

@@ -171,6 +171,44 @@ __device__ __forceinline__ void copy_table(unsigned char *dst, const WalkArgs &a
 	for (uint32_t i = threadIdx.x; i < (a.tab_bytes + 3u) / 4u; i += blockDim.x) T[i] = src[i];
 }
 
+/*
+ * Tiny5Pol: <= 6 states (C1/C2: 5 + DEAD).  Two VALU operations per input byte instead of four:
+ *  - the column of byte b sits at LDS byte address (b << 8) | (lane << 2) (one private copy per
+ *    lane: conflict-free), so ONE v_perm_b32 builds the address from the raw input dword;
+ *  - a column packs, for every state s, 5 * next(s) in the 5-bit field at bit 5 * s, and the state
+ *    is carried as 5 * s: the dependent chain is ONE v_bfe_u32 per byte.
+ */
+struct Tiny5Pol {
+	typedef uint32_t P;
+	typedef uint32_t S;
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	typedef const uint32_t __attribute__((address_space(3))) *lds_u32p;
+	uint32_t lanebase;         /* LDS byte address of this lane's copy of column 0: table base + (lane << 2) */
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 64u * 4u; }
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		uint32_t *col = reinterpret_cast<uint32_t *>(lds);
+		const uint32_t *src = static_cast<const uint32_t *>(a.tab);
+		for (uint32_t i = threadIdx.x; i < 256u * 64u; i += blockDim.x) col[i] = src[i >> 6];
+		/* addresses are formed by byte permutation, not addition: the table must start at LDS
+		 * address 0 (these kernels have no static LDS, the dynamic segment is the whole of it) */
+		const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+		if (base != 0u) __builtin_trap();
+		lanebase = (threadIdx.x & 63u) << 2;
+	}
+	__device__ __forceinline__ P pre(uint32_t b) const { return *(lds_u32p)(uintptr_t)((b << 8) | lanebase); }
+	/* byte k of the input dword d -> address bytes [0, 0, d.byte[k], lanebase.byte[0]] */
+	__device__ __forceinline__ P pre_dw(uint32_t d, int k) const
+	{
+		const uint32_t sel = 0x0c0c0400u + ((uint32_t)k << 8);
+		return *(lds_u32p)(uintptr_t)__builtin_amdgcn_perm(d, lanebase, sel);
+	}
+	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const { return __builtin_amdgcn_ubfe(v, st, 5u); }
+};
+
 template <bool MASK>
 struct LdsPol {
 	typedef uint32_t P;
@@ -567,6 +605,19 @@ __device__ __forceinline__ void finish_state(const Pol &, const WalkArgs &a, uin
 
 /* 16 input bytes of ROWS independent rows: all state-independent lookups
  * first, then the ROWS state chains interleaved byte by byte. */
+/* the state-independent lookup of byte k of a 16-byte chunk; a policy may want the raw dword (pre_dw) */
+template <class Pol>
+__device__ __forceinline__ auto pre_of(const Pol &pol, const u32x4 &w, int k, int) -> decltype(pol.pre_dw(0u, 0))
+{
+	const uint32_t d = (k < 4) ? w.x : (k < 8) ? w.y : (k < 12) ? w.z : w.w;
+	return pol.pre_dw(d, k & 3);
+}
+template <class Pol>
+__device__ __forceinline__ typename Pol::P pre_of(const Pol &pol, const u32x4 &w, int k, long)
+{
+	return pol.pre(byte_of(w, k));
+}
+
 /* a policy may know cheaply that none of 16 bytes changes the state of ANY lane (skip16) */
 template <class Pol>
 __device__ __forceinline__ auto skip_chunk(const Pol &pol, const typename Pol::S &st, const typename Pol::P (&pre)[16], int)
@@ -587,7 +638,7 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 #pragma unroll
 	for (int r = 0; r < ROWS; r++)
 #pragma unroll
-		for (int k = 0; k < 16; k++) pre[r][k] = pol.pre(byte_of(w[r], k));
+		for (int k = 0; k < 16; k++) pre[r][k] = pre_of(pol, w[r], k, 0);
 	if (ROWS == 1 && skip_chunk(pol, st[0], pre[0], 0)) return;
 #pragma unroll
 	for (int k = 0; k < 16; k++)

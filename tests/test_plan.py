@@ -121,6 +121,11 @@ def check_plan(flat, layout):
     if p.layout == LAYOUT_TINY:
         col = p.get("tiny_col")
         got = np.stack([(col >> np.uint64(4 * s)) & np.uint64(15) for s in range(S1)]).astype(np.int64)
+        col5 = p.get("tiny5_col").astype(np.int64)
+        assert (len(col5) == 256) == (S1 <= 6)
+        if len(col5):   # Tiny5Pol: state code 5*s, field s of the byte's column = 5 * next(s)
+            got5 = np.stack([(col5 >> (5 * s)) & 31 for s in range(S1)])
+            assert np.array_equal(got5, 5 * got) and (col5 < (1 << 30)).all()
     elif p.layout == LAYOUT_LDS:
         tab = p.get("lds_tab").astype(np.int64)
         rb = p.row_bytes
