@@ -1131,7 +1131,10 @@ gen_affix_kernel(const GenArgs g, const AffixArgs x)
 }
 
 /* Read-only streaming probe: the HBM read rate a trivially coalesced kernel reaches on this
- * device (16 B per lane, grid-stride), reported by bench.py next to the spec peak. */
+ * device (16 B per lane, grid-stride, optionally nontemporal), reported by bench.py next to the
+ * spec peak.  A lower bound of the achievable stream rate, not a roof: the walk kernels' LDS-DMA
+ * path has measured above it. */
+template <bool NT>
 __global__ void __launch_bounds__(256)
 stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
 {
@@ -1139,7 +1142,15 @@ stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
 	const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	for (; i + 3 * step < nvec; i += 4 * step) {
-		const u32x4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+		u32x4 a, b, c, d;
+		if (NT) {
+			a = __builtin_nontemporal_load(src + i);
+			b = __builtin_nontemporal_load(src + i + step);
+			c = __builtin_nontemporal_load(src + i + 2 * step);
+			d = __builtin_nontemporal_load(src + i + 3 * step);
+		} else {
+			a = src[i]; b = src[i + step]; c = src[i + 2 * step]; d = src[i + 3 * step];
+		}
 		acc ^= a ^ b ^ c ^ d;
 	}
 	for (; i < nvec; i += step) acc ^= src[i];
