@@ -843,3 +843,55 @@ def test_bench_two_ranks_share_one_gpu(hip):
     # every 8th input of the 2 x 262144 carries the planted match (plus chance matches)
     assert abs(r["config"]["accepted_inputs"] - 2 * 262144 // 8) < 64
     assert "cpu_baseline" not in r
+
+
+def test_retest_style_c_driver(hip, tmp_path):
+    """examples/retest_hip.c: a plain-C retest(1) over .tst files -- libre compiles each regex, the HIP path
+    runs each block's +/- lines in ONE batch.  The .tst files are regenerated here from the retest goldens
+    (regex, dialect, flags and inputs frozen from the reference's tests/retest/*.tst): 37 regexps, 115 tests,
+    none may fail; flipping one expectation must be reported."""
+    _need_ref()
+    import subprocess
+    from common import all_golden_paths
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "retest_hip")
+    ref_dir, lib_dir = os.path.join(root, "oracle", "_ref"), os.path.join(root, "libfsm_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "retest_hip.c"),
+                           "-o", exe, "-L" + ref_dir, "-lfsm_ref", "-L" + lib_dir, "-lfsm_hip",
+                           "-Wl,-rpath," + ref_dir, "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
+
+    def esc(b):
+        return "".join("\\\\" if c == 0x5C else chr(c) if 32 <= c < 127 else "\\x%02x" % c for c in b)
+
+    letters = {1: "i", 2: "t", 4: "m", 8: "r", 16: "s", 32: "z", 64: "a", 128: "x"}
+    lines, ncases, nre = ["# regenerated from tests/golden/retest/*.npz", "O +e"], 0, 0
+    flip = None
+    for path in [q for q in all_golden_paths() if "/retest/" in q]:
+        g = Golden(path)
+        regex = g.meta["regex"].encode("latin1").split(b"\0")[0]
+        lines.append("R " + g.meta["dialect"])
+        fl = "".join(v for k, v in letters.items() if g.meta["flags"] & k)
+        if fl:
+            lines.append("M " + fl)
+        lines.append(("~" if regex[:1] in (b"#", b"~", b"R", b"O", b"M", b"+", b"-") or not regex else "") + esc(regex))
+        if not regex:
+            lines[-1] = "~"
+        for inp, r in zip(g.strings(), g.ret):
+            lines.append(("+" if r == 1 else "-") + esc(inp))
+            if flip is None and r == 1:
+                flip = len(lines) - 1
+            ncases += 1
+        lines.append("")
+        nre += 1
+    assert (nre, ncases) == (37, 115)
+    tst = tmp_path / "all.tst"
+    tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, str(tst)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "37 regexps, 115 tests, 0 failed, 0 errors"
+    lines[flip] = "-" + lines[flip][1:]
+    bad = tmp_path / "bad.tst"
+    bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    out = subprocess.run([exe, str(bad)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 1 and "FAIL" in out.stdout and out.stdout.strip().splitlines()[-1] == "37 regexps, 115 tests, 1 failed, 0 errors"
