@@ -431,6 +431,17 @@ class HipDfa:
         if self._lib.fsm_hip_exec_batch_device(self._h, d_base, stride, d_len or None, n, d_end or None, d_bitmap or None, stream or None) != 0:
             raise _oserr("fsm_hip_exec_batch_device")
 
+    def exec_batch_eager_device(self, d_base: int, stride: int, n: int, d_end: int, d_sets: int, d_len: int = 0, stream: int = 0):
+        """d_sets: n * eager_words() u64 on the device."""
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_eager_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_size_t(stride), C.c_void_p(d_len or None),
+                                                     C.c_size_t(n), C.c_void_p(d_end or None), C.c_void_p(d_sets), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_eager_device")
+
+    def eager_words(self) -> int:
+        self._lib.fsm_hip_eager_words.restype = C.c_size_t
+        return int(self._lib.fsm_hip_eager_words(C.c_void_p(self._h)))
+
     def exec_batch_offsets_device(self, d_base: int, d_off: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
         C.set_errno(0)
         if self._lib.fsm_hip_exec_batch_offsets_device(self._h, d_base, d_off, n, d_end or None, d_bitmap or None, stream or None) != 0:

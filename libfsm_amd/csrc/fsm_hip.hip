@@ -468,6 +468,7 @@ static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 g
 	void (*k)(const WalkArgs) = nullptr;
 	if (c.mode == IN_GENERIC && c.queue) return launch_queue<EP>(c, a, c.counter, grid, block, s);
 	if (c.mode == IN_GENERIC) k = walk_generic<EP>;
+	else if (c.mode == IN_LDSDMA) k = c.nt ? walk_ldsdma<EP, 128, 2> : walk_ldsdma<EP, 128, 0>;
 	else k = walk_direct<EP, 4, 1>;
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
 	if (e != hipSuccess) return e;
@@ -495,8 +496,13 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const bool eager = a.eager_out != nullptr;
 	if (eager && (a.stride / 16u) % 4u != 0) fast_ok = false;
 	LaunchCfg c = pick_cfg(d, fast_ok, a.stride);
-	if (eager && c.mode != IN_GENERIC) {
-		/* the one fast eager kernel: per-lane loads, NB = 4, no LDS staging */
+	if (eager && c.mode == IN_DIRECT) {
+		/* the per-lane-load eager kernel is instantiated for NB = 4 only */
+		c.nb = 4; c.rows = 1;
+	}
+	if (eager && c.mode == IN_LDSDMA && (c.seg != 128 || a.eager_words > 1)) {
+		/* LDS-DMA eager kernels: 128-byte segments, register-held sets only (2.3 vs 1.1 TB/s for those;
+		 * wide sets measured 1.8 behind LDS-DMA vs 2.1 with per-lane loads: tests/tools/eager_probe.py) */
 		c.mode = IN_DIRECT; c.nb = 4; c.rows = 1;
 		c.waves = d->knob_waves > 0 && d->knob_waves <= 16 ? d->knob_waves : 16;
 		c.lds = d->table_lds;

@@ -500,8 +500,8 @@ struct EagerPol : Pol {
 		const uint32_t before = Pol::code(st.s);
 		st.s = Pol::next(st.s, p);
 		const uint32_t c = Pol::code(st.s);
-		(void)before;
-		st.acc |= outputs_of(c);
+		/* OR is idempotent: staying in the same state emits nothing new */
+		if (c != before && (c < lo_end || c >= hi_begin)) st.acc |= emask[c / fin_div];
 		return st;
 	}
 	__device__ __forceinline__ static void finish(const WalkArgs &a, uint64_t i, bool valid, const S &st)
