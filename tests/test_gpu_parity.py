@@ -895,3 +895,34 @@ def test_retest_style_c_driver(hip, tmp_path):
     bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
     out = subprocess.run([exe, str(bad)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 1 and "FAIL" in out.stdout and out.stdout.strip().splitlines()[-1] == "37 regexps, 115 tests, 1 failed, 0 errors"
+
+
+def test_chunk_skip_never_skips_a_state_change(hip):
+    """CombSelfPol::skip16 drops a 16-byte chunk only if no lane's state changes in it.  Rows that sit in a
+    digit self-loop with ONE odd byte at every possible position (and in only one lane of a wavefront), through
+    the LDS-DMA, per-lane-load and ragged kernels, against the oracle."""
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    pre = pats[0][1:pats[0].index(b"[")]
+    L = 256
+    rows = np.full((2 * L + 64, L), ord("7"), np.uint8)
+    rows[:, :len(pre)] = np.frombuffer(pre, np.uint8)
+    for i in range(L):                       # row i: a letter at position i (dies there unless it is the final x)
+        if i >= len(pre):
+            rows[i, i] = ord("x")
+            rows[L + i, i] = ord("q")
+    rows[2 * L:, L - 1] = ord("x")           # plain matches: prefix digits... x
+    want = Oracle(g.flat).table_walk(rows)
+    assert (want != NO).sum() >= 64 and (want == NO).sum() >= L
+    dfa = hip.HipDfa(g.flat, hip.LAYOUT_COMBSELF)
+    lens = np.full(len(rows), L, np.uint32)
+    for mode in (hip.IN_LDSDMA, hip.IN_DIRECT, hip.IN_GENERIC):
+        dfa.tune(hip.KNOB_INPUT_MODE, mode)
+        for early in (0, 1):
+            dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+            end, _ = dfa.exec_batch(rows)
+            assert np.array_equal(end, want), (mode, early)
+    end, _ = dfa.exec_batch(rows, lens)      # the ragged kernel's whole-chunk fast path
+    assert np.array_equal(end, want)
+    dfa.close()
