@@ -219,6 +219,19 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			d->table_lds = lds_bytes_btab() + ((a.tab_bytes + 15u) & ~15u);
 			break;
 		}
+		case FSM_HIP_LAYOUT_LDSSELF: {
+			uint16_t *t = nullptr;
+			HIP_TRY(upload(&t, p.lds_tab));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
+			a.tab_bytes = (uint32_t)(p.lds_tab.size() * 2);
+			a.start = p.start * p.row_bytes;
+			a.abs_min = p.abs_min * p.row_bytes;
+			a.fin_div = p.row_bytes;
+			d->table_lds = LdsSelfPol::lds_bytes(a.tab_bytes);
+			break;
+		}
 		case FSM_HIP_LAYOUT_COMB: {
 			uint32_t *t = nullptr;
 			std::vector<uint32_t> img(p.comb);               /* image = comb[n], dflt[256] */
@@ -271,7 +284,8 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			switch (p.layout) {
 			case FSM_HIP_LAYOUT_TINY: d->enc_host[n2] = p.tiny5_col.empty() ? n2 : n2 * 5u; break;
 			case FSM_HIP_LAYOUT_SPARSE: d->enc_host[n2] = n2; break;
-			case FSM_HIP_LAYOUT_LDS: d->enc_host[n2] = n2 * p.row_bytes; break;
+			case FSM_HIP_LAYOUT_LDS:
+			case FSM_HIP_LAYOUT_LDSSELF: d->enc_host[n2] = n2 * p.row_bytes; break;
 			case FSM_HIP_LAYOUT_COMB:
 			case FSM_HIP_LAYOUT_COMBSELF: d->enc_host[n2] = p.comb_off[n2]; break;
 			case FSM_HIP_LAYOUT_COMB256: d->enc_host[n2] = p.comb256_off[n2]; break;
@@ -524,6 +538,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 				                    : launch_eager<TinyPol<uint64_t>>(c, a, grid, block, s);
 				break;
 			case FSM_HIP_LAYOUT_LDS: e = launch_eager<LdsPol<false>>(c, a, grid, block, s); break;
+			case FSM_HIP_LAYOUT_LDSSELF: e = launch_eager<LdsSelfPol>(c, a, grid, block, s); break;
 			default:                 e = launch_eager<GlobPol<false>>(c, a, grid, block, s); break;
 			}
 		} else
@@ -538,6 +553,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		case FSM_HIP_LAYOUT_COMB256: e = launch_masked<Comb256Pol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_COMBSELF: e = launch_pol<CombSelfPol>(c, a, grid, block, s); break;
 		case FSM_HIP_LAYOUT_SPARSE:  e = launch_pol<SparsePol>(c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_LDSSELF: e = launch_pol<LdsSelfPol>(c, a, grid, block, s); break;
 		default:                     e = launch_masked<GlobPol>(c, a, grid, block, s); break;
 		}
 	}
@@ -725,7 +741,8 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	out->nabsorbing = p.nabsorbing;
 	switch (p.layout) {
 	case FSM_HIP_LAYOUT_TINY: out->table_bytes = 256 * 8; break;
-	case FSM_HIP_LAYOUT_LDS: out->table_bytes = p.lds_tab.size() * 2; break;
+	case FSM_HIP_LAYOUT_LDS:
+	case FSM_HIP_LAYOUT_LDSSELF: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
 	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8 + 256; break;

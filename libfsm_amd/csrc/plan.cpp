@@ -301,6 +301,31 @@ try {
 		}
 		p.selfloop_fraction = p.abs_min ? (double)with_loop / p.abs_min : 0.0;
 	}
+	/* LDSSELF: the dense table with each row followed by the state's self-loop mask (bit c: class c
+	 * maps the state to itself; absorbing states: all ones).  The walk keeps the mask of the current
+	 * state in a register (LdsSelfPol), so bytes that do not change the state cost no table lookup and
+	 * whole 16-byte chunks can be skipped with one wave vote -- as CombSelfPol, but the states keep
+	 * their order, so eager-output DFAs can use it. */
+	auto emit_ldsself = [&]() -> int {
+		const uint32_t rb = Cpad * 2u + 4u;
+		if (C > 32u || (uint64_t)S1 * rb > lds_room || (uint64_t)S1 * (rb / 4u) > 65536u) return ENOTSUP;
+		p.row_bytes = rb;
+		const uint32_t rw = rb / 2u;   /* u16 slots per row */
+		p.lds_tab.assign((size_t)S1 * rw, 0);
+		for (uint32_t n = 0; n < S1; n++) {
+			uint32_t m = 0;
+			for (uint32_t c = 0; c < Cpad; c++) {
+				uint32_t t = c < C ? p.dense[(size_t)n * C + c] : n;
+				p.lds_tab[(size_t)n * rw + c] = (uint16_t)(t * (rb / 4u));
+				if (c < C && t == n) m |= 1u << c;
+			}
+			if (n >= p.abs_min) m = 0xFFFFFFFFu;
+			p.lds_tab[(size_t)n * rw + Cpad] = (uint16_t)(m & 0xffffu);
+			p.lds_tab[(size_t)n * rw + Cpad + 1] = (uint16_t)(m >> 16);
+		}
+		p.layout = FSM_HIP_LAYOUT_LDSSELF;
+		return 0;
+	};
 	auto emit_comb256 = [&]() -> int {
 		/* no byte->class table in LDS for this layout */
 		if (has_eager) return ENOTSUP;
@@ -325,6 +350,7 @@ try {
 
 	switch (want) {
 	case FSM_HIP_LAYOUT_SPARSE: return emit_sparse();
+	case FSM_HIP_LAYOUT_LDSSELF: return emit_ldsself();
 	case FSM_HIP_LAYOUT_TINY:   return emit_tiny();
 	case FSM_HIP_LAYOUT_LDS:    return emit_lds();
 	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
@@ -337,6 +363,7 @@ try {
 		 * cost one conflict-free lookup (CombSelfPol) */
 		if (p.selfloop_fraction >= 0.15 && emit_combself() == 0) return 0;
 		if (emit_comb256() == 0) return 0;
+		if (p.selfloop_fraction >= 0.15 && emit_ldsself() == 0) return 0;
 		if (emit_lds() == 0) return 0;
 		if (emit_comb() == 0) return 0;
 		/* too big for LDS: base-row records when they shrink the table at least 4x (Aho-Corasick

@@ -239,6 +239,54 @@ struct LdsPol {
 	}
 };
 
+/*
+ * LdsSelfPol: LdsPol plus the self-loop mask of the current state in a register (the planner stores it
+ * after each row).  Bytes whose class is a self-loop of the state cost no table lookup, whole chunks of
+ * them are skipped with one wave vote (skip16), and -- unlike the comb layouts -- states keep their
+ * order, so EagerPol can wrap it.  <= 32 classes.
+ */
+struct LdsSelfState {
+	uint32_t st;   /* byte offset of the row */
+	uint32_t sm;   /* bit c: class c maps the state to itself */
+};
+
+struct LdsSelfPol {
+	typedef uint32_t P;
+	typedef LdsSelfState S;
+	const uint8_t *bp;
+	const unsigned char *tab;
+	uint32_t smoff;   /* offset of the mask inside a row */
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
+	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		tab = lds + FSMHIP_BTAB_BYTES;
+		smoff = a.fin_div - 4u;   /* fin_div = row bytes */
+	}
+	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
+	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, mask_of(code) }; return s; }
+	__device__ __forceinline__ static uint32_t code(const S &s) { return s.st; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ bool skip16(const S &s, const P (&c)[16]) const
+	{
+		uint32_t m = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) m |= 1u << c[k];
+		return __all((m & ~s.sm) == 0u);
+	}
+	__device__ __forceinline__ S next(S s, P c) const
+	{
+		if (!((s.sm >> c) & 1u)) {
+			s.st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + s.st + c * 2u)) << 2;
+			s.sm = mask_of(s.st);
+		}
+		return s;
+	}
+};
+
 template <bool MASK>
 struct CombPol {
 	typedef uint32_t P;
@@ -495,6 +543,13 @@ struct EagerPol : Pol {
 		return st;
 	}
 	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
+	/* a chunk that changes no state emits nothing either */
+	template <class Q = Pol>
+	__device__ __forceinline__ auto skip16(const S &st, const P (&pre)[16]) const
+		-> decltype(static_cast<const Q *>(nullptr)->skip16(st.s, pre))
+	{
+		return Pol::skip16(st.s, pre);
+	}
 	__device__ __forceinline__ S next(S st, P p) const
 	{
 		const uint32_t before = Pol::code(st.s);
@@ -558,6 +613,12 @@ struct EagerWidePol : Pol {
 		return st;
 	}
 	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
+	template <class Q = Pol>
+	__device__ __forceinline__ auto skip16(const S &st, const P (&pre)[16]) const
+		-> decltype(static_cast<const Q *>(nullptr)->skip16(st.s, pre))
+	{
+		return Pol::skip16(st.s, pre);   /* pending outputs stay pending: the state is unchanged */
+	}
 	/* The kernels may compute next() for a byte past the end of a ragged input and drop the result,
 	 * so a step must not write.  The state handed IN is committed: its pending outputs are written
 	 * here, the new state's are left pending (the last one is written by finish()). */

@@ -529,7 +529,7 @@ def test_eager_outputs_golden_and_random(hip):
                 rnd[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
         o = Oracle(g.flat)
         rret, rend, rsets = o.exec_eager(rnd)
-        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_GLOBAL):
+        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_LDSSELF, hip.LAYOUT_GLOBAL):
             try:
                 dfa = hip.HipDfa(g.flat, L)
             except OSError:
@@ -615,7 +615,7 @@ def test_eager_outputs_wide_sets(hip, nids):
         o = Oracle(flat)
         want = {None: o.exec_eager(rows, None, cap=nids + 8), "r": o.exec_eager(rows, lens, cap=nids + 8)}
         assert max(len(x) for x in want[None][2]) >= 3
-        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_GLOBAL, hip.LAYOUT_AUTO):
+        for L in (hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_LDSSELF, hip.LAYOUT_GLOBAL, hip.LAYOUT_AUTO):
             try:
                 dfa = hip.HipDfa(flat, L)
             except OSError:

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from common import Golden, all_golden_paths, golden_id
-from libfsm_amd import (ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_SPARSE, LAYOUT_TINY,
+from libfsm_amd import (ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_LDSSELF, LAYOUT_SPARSE, LAYOUT_TINY,
                         FlatDfa, Plan)
 
 NO = 0xFFFFFFFF
@@ -126,13 +126,21 @@ def check_plan(flat, layout):
         if len(col5):   # Tiny5Pol: state code 5*s, field s of the byte's column = 5 * next(s)
             got5 = np.stack([(col5 >> (5 * s)) & 31 for s in range(S1)])
             assert np.array_equal(got5, 5 * got) and (col5 < (1 << 30)).all()
-    elif p.layout == LAYOUT_LDS:
+    elif p.layout in (LAYOUT_LDS, LAYOUT_LDSSELF):
         tab = p.get("lds_tab").astype(np.int64)
         rb = p.row_bytes
         st = np.arange(S1)[:, None] * rb                      # encoded state = byte offset of row
         e = tab[(st + cls[bytes_][None, :] * 2) // 2]
         got = (e << 2) // rb
         assert ((e << 2) % rb == 0).all()
+        if p.layout == LAYOUT_LDSSELF:                        # each row ends with the state's self-loop mask
+            assert Cn <= 32 and rb == ((Cn + 1) // 2 * 2) * 2 + 4
+            sm = tab[(st[:, 0] + rb - 4) // 2] | (tab[(st[:, 0] + rb - 2) // 2] << 16)
+            rep = np.array([np.nonzero(cls == c)[0][0] for c in range(Cn)])
+            loops = want[:, rep] == np.arange(S1)[:, None]
+            bits = (sm[:, None] >> np.arange(Cn)[None, :]) & 1
+            assert np.array_equal(bits[~absorbing].astype(bool), loops[~absorbing])
+            assert (sm[absorbing] == 0xFFFFFFFF).all()
     elif p.layout in (LAYOUT_COMB, LAYOUT_COMBSELF):
         comb = p.get("comb").astype(np.int64)
         off = p.get("comb_off").astype(np.int64)

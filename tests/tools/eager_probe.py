@@ -4,6 +4,7 @@ it exists for: fsm_union_repeated_pattern_group over K unanchored literal patter
 built by the real reference; random lowercase text with a pattern planted in every 4th input.
 (Under tests/: uses the reference to build the automaton and the oracle as checker.)"""
 import argparse
+import ctypes as C
 import os
 import sys
 
@@ -18,6 +19,7 @@ def main():
     ap.add_argument("--k", default="40,150")
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--len", type=int, default=1024)
+    ap.add_argument("--layouts", default="0", help="comma list: 0 auto, 2 lds, 8 ldsself, 4 global")
     a = ap.parse_args()
     import torch
     import libfsm_amd as hip
@@ -34,28 +36,31 @@ def main():
         words = sorted(set(bytes(al[rng.randint(0, 26, rng.randint(4, 8))]) for _ in range(2 * K)))[:K]
         f = RefFsm.union_repeated("pcre", words, 1, False)
         flat = f.flatten()
-        dfa = hip.HipDfa(flat)
-        info = dfa.info()
-        W = dfa.eager_words()
         hip.gen_inputs_device(buf.data_ptr(), n, L, 0, 7, alpha, words[0], 4)
         torch.cuda.synchronize()
-        sets = torch.zeros((n, W), dtype=torch.int64, device="cuda")
-        for name, fn in (("plain walk", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)),
-                         ("eager walk", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n, end.data_ptr(), sets.data_ptr()))):
-            ms = []
-            for _ in range(4):
-                fn()
-                ms.append(dfa.last_kernel_ms())
-            torch.cuda.synchronize()
-            t = min(ms[1:])
-            print(f"K={K:4d} states={flat.nstates:6d} layout={info['layout_name']:8s} words/input={W} {name}: {t:8.3f} ms  {n * L / t / 1e6:8.1f} GB/s", flush=True)
         k = 256
         _, wend, wsets = Oracle(flat).exec_eager(buf[:k].cpu().numpy(), None, cap=K + 8)
-        ids = np.array([dfa._lib.fsm_hip_eager_id(__import__("ctypes").c_void_p(dfa._h), b) for b in range(dfa.eager_id_count())], np.uint32)
-        bits = np.unpackbits(sets[:k].cpu().numpy().view(np.uint8).reshape(k, W * 8), axis=1, bitorder="little")[:, :len(ids)].astype(bool)
-        ok = np.array_equal(end[:k].cpu().numpy().view(np.uint32), wend) and all(np.array_equal(ids[bits[i]], wsets[i]) for i in range(k))
-        print(f"K={K:4d} first {k} inputs vs oracle: {'OK' if ok else 'MISMATCH'}; inputs with outputs: {int((sets != 0).any(dim=1).sum())}", flush=True)
-        dfa.close()
+        for layout in [int(x) for x in a.layouts.split(",")]:
+            dfa = hip.HipDfa(flat, layout)
+            info = dfa.info()
+            W = dfa.eager_words()
+            sets = torch.zeros((n, W), dtype=torch.int64, device="cuda")
+            for name, fn in (("plain walk", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)),
+                             ("eager walk", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n, end.data_ptr(), sets.data_ptr()))):
+                ms = []
+                for _ in range(4):
+                    fn()
+                    ms.append(dfa.last_kernel_ms())
+                torch.cuda.synchronize()
+                t = min(ms[1:])
+                print(f"K={K:4d} states={flat.nstates:6d} layout={info['layout_name']:8s} words/input={W} {name}: {t:8.3f} ms  "
+                      f"{n * L / t / 1e6:8.1f} GB/s", flush=True)
+            ids = np.array([dfa._lib.fsm_hip_eager_id(C.c_void_p(dfa._h), b) for b in range(dfa.eager_id_count())], np.uint32)
+            bits = np.unpackbits(sets[:k].cpu().numpy().view(np.uint8).reshape(k, W * 8), axis=1, bitorder="little")[:, :len(ids)].astype(bool)
+            ok = np.array_equal(end[:k].cpu().numpy().view(np.uint32), wend) and all(np.array_equal(ids[bits[i]], wsets[i]) for i in range(k))
+            print(f"K={K:4d} layout={info['layout_name']:8s} first {k} inputs vs oracle: {'OK' if ok else 'MISMATCH'}; "
+                  f"inputs with outputs: {int((sets != 0).any(dim=1).sum())}", flush=True)
+            dfa.close()
 
 
 if __name__ == "__main__":
