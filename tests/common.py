@@ -70,6 +70,10 @@ def all_golden_paths():
             + [p for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))) if not p.endswith("fsm_corpus.npz")])
 
 
+def ac_golden_paths():
+    return sorted(glob.glob(os.path.join(GOLDEN, "ac", "*.npz")))
+
+
 def eager_golden_paths():
     return sorted(glob.glob(os.path.join(GOLDEN, "eager", "*.npz")))
 

@@ -19,6 +19,8 @@ own sources) and freezes its answers as small .npz fixtures:
                    (rx-style, not minimised), end-id = pattern index, with
                    fsm_exec + end-id answers on 512 x 1 KiB inputs.
 
+  ac/in<n><m>.npz  tests/aho_corasick: the regex side of the reference's re_strings == regex check
+                   (4 anchor modes x 3 word lists) with fsm_exec on every short string.
   recorded/*.npz   every fsm_exec call made by the reference's own tests/endids, tests/re_strings and
                    tests/capture programs (compiled in place with fsm_exec routed through
                    record_exec.c), grouped per distinct automaton.
@@ -528,6 +530,31 @@ def gen_recorded():
     print(f"recorded: {nprog} reference test programs, {ncalls} fsm_exec calls, {nfsm} automata, {nunsup} calls on capture automata (ENOTSUP)")
 
 
+def gen_aho_corasick():
+    """tests/aho_corasick: the reference checks that re_strings over in<n>.txt equals, as a language, the regex
+    ^(w1|..)$ / ^(w1|..).* / .*(w1|..)$ / .*(w1|..).* (Makefile:28-92, modes a l r u).  Frozen here: the REGEX side
+    (native dialect, determinised + minimised) with fsm_exec's answer on EVERY string up to a length bound over
+    the words' letters plus one foreign letter; the tests hold the literal-set builder against it."""
+    import itertools
+    d = os.path.join(OUT, "ac")
+    os.makedirs(d, exist_ok=True)
+    forms = {"a": (b"^(", b")$", 3), "l": (b"^(", b").*", 1), "r": (b".*(", b")$", 2), "u": (b".*(", b").*", 0)}
+    total = 0
+    for k in (1, 2, 3):
+        words = open(os.path.join(REF, "tests/aho_corasick", f"in{k}.txt"), "rb").read().split()
+        alpha = sorted(set(b"".join(words))) + [ord("x")]
+        maxlen = {1: 5, 2: 5, 3: 7}[k]
+        strings = [bytes(t) for n in range(maxlen + 1) for t in itertools.product(alpha, repeat=n)]
+        for mode, (pre, post, flags) in forms.items():
+            regex = pre + b"|".join(words) + post
+            f = RefFsm.re_comp("native", regex, 0, True, True)
+            meta = dict(source=f"tests/aho_corasick/in{k}.txt", mode=mode, regex=regex.decode(), words=[w.decode() for w in words],
+                        strings_flags=flags, maxlen=maxlen)
+            save_case(os.path.join(d, f"in{k}{mode}.npz"), f, strings, meta)
+            total += len(strings)
+    print(f"aho_corasick: 12 automata, {total} inputs")
+
+
 if __name__ == "__main__":
     assert build_ref(), "needs /root/reference to build oracle/_ref"
     gen_retest()
@@ -538,3 +565,4 @@ if __name__ == "__main__":
     gen_eager()
     gen_fsm_corpus()
     gen_recorded()
+    gen_aho_corasick()

@@ -926,3 +926,19 @@ def test_chunk_skip_never_skips_a_state_change(hip):
     end, _ = dfa.exec_batch(rows, lens)      # the ragged kernel's whole-chunk fast path
     assert np.array_equal(end, want)
     dfa.close()
+
+
+def test_aho_corasick_fixtures_on_device(hip):
+    """tests/aho_corasick through the library alone: fsm_hip_strings_* -> table -> walk accepts exactly what the
+    reference's regex form accepts, for the 3 word lists x 4 anchor modes, on every layout that holds the DFA."""
+    from common import ac_golden_paths
+    paths = ac_golden_paths()
+    assert len(paths) == 12
+    for path in paths:
+        g = Golden(path)
+        flat = hip.FlatDfa.from_strings([w.encode() for w in g.meta["words"]], g.meta["strings_flags"], None)
+        base, off = g.packed()
+        for L, dfa in layouts_for(hip, flat):
+            end, bm = dfa.exec_batch_offsets(base, off)
+            assert np.array_equal(end != NO, g.ret == 1), (g.meta["source"], g.meta["mode"], L)
+            dfa.close()

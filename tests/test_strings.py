@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from common import GOLDEN, Golden
+from common import GOLDEN, Golden, ac_golden_paths, golden_id
 from libfsm_amd import FlatDfa
 from oracle.pyoracle import RefFsm, have_ref
 
@@ -104,3 +104,18 @@ def test_errors_and_reuse():
     lib.fsm_hip_desc_free(d2)
     lib.fsm_hip_strings_free(g)
     lib.fsm_hip_strings_free(None)
+
+
+@pytest.mark.parametrize("path", ac_golden_paths(), ids=golden_id)
+def test_aho_corasick_language_equals_the_regex(path):
+    """The reference's tests/aho_corasick claim, on the frozen regex side: the literal set of in<n>.txt, built
+    with the matching anchor flags, accepts exactly the strings the regex accepts -- every string up to the
+    golden's length bound (oracle walk of the builder's DFA vs the reference's fsm_exec on the regex DFA)."""
+    from oracle.pyoracle import Oracle
+    g = Golden(path)
+    words = [w.encode() for w in g.meta["words"]]
+    flat = FlatDfa.from_strings(words, g.meta["strings_flags"], None)
+    base, off = g.packed()
+    ret, _ = Oracle(flat).exec_offsets(base, off)
+    assert np.array_equal(ret == 1, g.ret == 1), g.meta
+    assert 0 < int((g.ret == 1).sum()) < len(g.ret)
