@@ -67,6 +67,7 @@ class Golden:
 def all_golden_paths():
     return (sorted(glob.glob(os.path.join(GOLDEN, "retest", "*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "eager", "*.npz")))
             + sorted(glob.glob(os.path.join(GOLDEN, "recorded", "*.npz")))
+            + sorted(glob.glob(os.path.join(GOLDEN, "reperf", "*.npz")))
             + [p for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))) if not p.endswith("fsm_corpus.npz")])
 
 

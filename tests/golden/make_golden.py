@@ -21,6 +21,7 @@ own sources) and freezes its answers as small .npz fixtures:
 
   ac/in<n><m>.npz  tests/aho_corasick: the regex side of the reference's re_strings == regex check
                    (4 anchor modes x 3 word lists) with fsm_exec on every short string.
+  reperf/NNN.npz   reperf/boost.scr: the 5 string cases (regex DFA, string, fsm_exec answer = the script's R).
   recorded/*.npz   every fsm_exec call made by the reference's own tests/endids, tests/re_strings and
                    tests/capture programs (compiled in place with fsm_exec routed through
                    record_exec.c), grouped per distinct automaton.
@@ -555,6 +556,41 @@ def gen_aho_corasick():
     print(f"aho_corasick: 12 automata, {total} inputs")
 
 
+def gen_reperf():
+    """reperf/boost.scr (format: src/retest/reperf.c:400-560): "- name", M regex, D dialect, S string (repeated S
+    lines join with a newline), N iterations, R expected matches, X run.  The string cases are frozen: DFA,
+    string, fsm_exec's answer, the script's own R.  (F cases name files that are not in the tree.)"""
+    d = os.path.join(OUT, "reperf")
+    os.makedirs(d, exist_ok=True)
+    cur, last, k = {}, "", 0
+    for ln, raw in enumerate(open(os.path.join(REF, "reperf", "boost.scr"), "rb").read().split(b"\n"), 1):
+        if not raw or raw[:1] == b"#":
+            continue
+        op, arg = raw[:1], raw[1:]
+        if op == b"-":
+            cur = dict(name=arg.strip().decode(), line=ln)
+        elif op == b"M":
+            cur["regex"] = arg[1:] if arg[:1] == b" " else arg
+        elif op == b"D":
+            cur["dialect"] = arg.strip().decode()
+        elif op == b"S":
+            b_ = arg[1:] if arg[:1] == b" " else arg
+            cur["string"] = b_ if last != b"S" else cur["string"] + b"\n" + b_
+        elif op == b"F":
+            cur.pop("string", None)
+        elif op in (b"N", b"R"):
+            cur["count" if op == b"N" else "expected"] = int(arg.strip())
+        elif op == b"X" and "string" in cur:
+            f = RefFsm.re_comp(cur["dialect"], cur["regex"], 0, True, True)
+            meta = dict(source="reperf/boost.scr", line=cur["line"], name=cur["name"], dialect=cur["dialect"],
+                        regex=cur["regex"].decode("latin1"), count=cur["count"], expected_matches=cur["expected"])
+            save_case(os.path.join(d, f"{k:03d}.npz"), f, [cur["string"]], meta, [cur["expected"]])
+            k += 1
+        last = op
+    print(f"reperf: {k} string cases")
+    assert k == 5, "SURVEY section 8c count"
+
+
 if __name__ == "__main__":
     assert build_ref(), "needs /root/reference to build oracle/_ref"
     gen_retest()
@@ -566,3 +602,4 @@ if __name__ == "__main__":
     gen_fsm_corpus()
     gen_recorded()
     gen_aho_corasick()
+    gen_reperf()

@@ -942,3 +942,26 @@ def test_aho_corasick_fixtures_on_device(hip):
             end, bm = dfa.exec_batch_offsets(base, off)
             assert np.array_equal(end != NO, g.ret == 1), (g.meta["source"], g.meta["mode"], L)
             dfa.close()
+
+
+def test_reperf_script_cases_as_batches(hip):
+    """reperf/boost.scr runs each string N times through fsm_runner_run and expects R matches per run
+    (src/retest/reperf.c:772-784).  Here the N runs are ONE batch of N copies: N * R accepts, every end state
+    the one fsm_exec returned."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "reperf", "*.npz")))
+    assert len(paths) == 5
+    n = 100_000
+    for path in paths:
+        g = Golden(path)
+        s_ = g.strings()[0]
+        stride = (len(s_) + 15) // 16 * 16
+        rows = np.zeros((n, stride), np.uint8)
+        rows[:, :len(s_)] = np.frombuffer(s_, np.uint8)
+        lens = np.full(n, len(s_), np.uint32)
+        dfa = hip.HipDfa(g.flat)
+        end, bm = dfa.exec_batch(rows, lens)
+        assert int((end != NO).sum()) == n * g.meta["expected_matches"], g.meta
+        assert (end == g.end[0]).all()
+        assert int(np.unpackbits(bm.view(np.uint8)).sum()) == n * g.meta["expected_matches"]
+        dfa.close()
