@@ -68,8 +68,9 @@ struct fsm_hip_dfa {
 };
 
 /* GLOBAL layout: how much of the table head (rows nearest the start state) every workgroup
- * keeps in LDS.  40 KiB + the 32 KiB byte->class table still lets two 16-wave workgroups share a
- * CU, which the HBM/L2 gathers of the cold rows need for latency hiding. */
+ * keeps in LDS.  The walk is bound by L2 gather requests and every lookup served from LDS is one
+ * less: on a 6.7 MB table 0 / 40 / 80 / 120 KiB of hot rows measured 265 / 314 / 350 / 360 GB/s
+ * (profiles/r01_c5_global_hot.txt), so the default takes what LDS offers. */
 static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
 {
 	uint64_t hot = want;
@@ -259,7 +260,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.fin_div = p.C * 4u;
 			d->glob_row_bytes = p.C * 4u;
 			d->glob_tab_bytes = (uint64_t)p.glob_tab.size() * 4u;
-			set_hot_bytes(d, 40u * 1024u);
+			set_hot_bytes(d, 120u * 1024u);
 			break;
 		}
 		case FSM_HIP_LAYOUT_SPARSE: {

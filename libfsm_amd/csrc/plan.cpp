@@ -366,9 +366,11 @@ try {
 		if (p.selfloop_fraction >= 0.15 && emit_ldsself() == 0) return 0;
 		if (emit_lds() == 0) return 0;
 		if (emit_comb() == 0) return 0;
-		/* too big for LDS: base-row records when they shrink the table at least 4x (Aho-Corasick
-		 * and other DFAs whose rows repeat their predecessors'), else the plain table */
-		if (emit_sparse() == 0) {
+		/* too big for LDS.  A plain table that still fits the L2 (<= 8 MB) walks fastest with as much
+		 * of its head mirrored in LDS as fits (360 vs 302 GB/s on a 6.7 MB literal-set table); beyond
+		 * that, base-row records when they shrink the table at least 4x (Aho-Corasick and other DFAs
+		 * whose rows repeat their predecessors': 256 MB -> 20 MB, 180 -> 302 GB/s), else the plain table */
+		if ((uint64_t)S1 * C * 4u > ((uint64_t)8 << 20) && emit_sparse() == 0) {
 			if ((uint64_t)p.sparse_img.size() * 4u * 4u <= (uint64_t)S1 * C * 4u) return 0;
 			std::vector<uint32_t>().swap(p.sparse_img);
 		}

@@ -207,8 +207,8 @@ def test_auto_layout_choices(built):
     alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", np.uint8)
     words = [bytes(alpha[rng.randint(0, 36, rng.randint(6, 12))]) for _ in range(3000)]
     ac = FlatDfa.from_strings(words, 2, list(range(len(words))))
-    pa = Plan(ac)
-    assert pa.layout == LAYOUT_SPARSE
+    assert Plan(ac).layout == LAYOUT_GLOBAL          # 3 MB: an L2-resident plain table with a big LDS mirror
+    pa = Plan(ac, LAYOUT_SPARSE)
     img = pa.get("sparse")
     assert img.size * 4 * 4 < pa.S1 * pa.C * 4 and int(img[12]) <= 7
     want = decode_want(ac, pa)
