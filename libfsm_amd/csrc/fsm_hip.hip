@@ -618,90 +618,126 @@ extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
 /* ------------------------------------------------------------------ */
 
 /*
- * Host-pointer front.  One device arena per dfa (grow-only up to ARENA_KEEP, so repeated calls --
+ * Host-pointer fronts.  One device arena per dfa (grow-only up to ARENA_KEEP, so repeated calls --
  * retest / re(1) issue one per input line -- do no hipMalloc/hipFree), laid out
- *     [inputs (+32: the generic kernel reads whole aligned 16-byte chunks)] [len] [off] | [end] [bitmap]
- * Small calls gather their host arrays in one pinned buffer: one H2D copy, the kernel, one D2H copy,
- * one stream synchronise.  Large inputs are copied straight from the caller's pages.
+ *     [inputs ...] [in/out arrays ...] [outputs ...]
+ * Small calls gather their host arrays in one pinned buffer: one H2D copy (inputs + in/out), the
+ * kernel, one D2H copy (in/out + outputs), one stream synchronise.  Large calls copy each array
+ * straight from / to the caller's pages.
  */
 static const size_t ARENA_KEEP = (size_t)256 << 20, STAGE_BYTES = (size_t)1 << 20;
 
 static size_t up256(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
-static int exec_host(const struct fsm_hip_dfa *cd,
+struct HostCall {
+	enum Kind { IN = 0, INOUT = 1, OUT = 2 };
+	struct Part { const void *src; void *dst; size_t bytes, pad, off; int kind; };
+	fsm_hip_dfa *d;
+	Part parts[8];
+	int np = 0;
+	unsigned char *arena = nullptr;
+	bool temp = false, small = false;
+	size_t h2d_end = 0, d2h_begin = 0, total = 0;
+
+	explicit HostCall(const fsm_hip_dfa *cd) : d(const_cast<fsm_hip_dfa *>(cd)) {}
+	~HostCall() { if (temp && arena) { int e = errno; (void)hipFree(arena); errno = e; } }
+	/* declare the arrays in the order IN..., INOUT..., OUT...; returns the part's index (or -1 for a NULL array) */
+	int add(int kind, const void *src, void *dst, size_t bytes, size_t pad = 0)
+	{
+		if (kind != IN && dst == nullptr) return -1;
+		if (kind == IN && src == nullptr && bytes != 0) return -1;
+		Part &p = parts[np];
+		p.src = src; p.dst = dst; p.bytes = bytes; p.pad = pad; p.kind = kind; p.off = 0;
+		return np++;
+	}
+	template <class T> T *dev(int part) const { return part < 0 ? nullptr : reinterpret_cast<T *>(arena + parts[part].off); }
+
+	int begin()
+	{
+		size_t o = 0;
+		h2d_end = 0;
+		d2h_begin = (size_t)-1;
+		for (int i = 0; i < np; i++) {   /* declared in the order IN, INOUT, OUT */
+			Part &p = parts[i];
+			p.off = o;
+			o += up256(p.bytes + p.pad);
+			if (p.kind != OUT) h2d_end = o;
+			if (p.kind != IN && d2h_begin == (size_t)-1) d2h_begin = p.off;
+		}
+		total = o;
+		if (d2h_begin == (size_t)-1) d2h_begin = total;
+		if (total <= d->arena_bytes) {
+			arena = d->arena;
+		} else if (total <= ARENA_KEEP) {
+			if (d->arena) { (void)hipFree(d->arena); d->arena = nullptr; d->arena_bytes = 0; }
+			size_t want = (size_t)2 << 20;
+			while (want < total) want *= 2;
+			HIP_TRY(hipMalloc((void **)&d->arena, want));
+			d->arena_bytes = want;
+			arena = d->arena;
+		} else {
+			HIP_TRY(hipMalloc((void **)&arena, total));
+			temp = true;
+		}
+		small = total <= STAGE_BYTES;
+		if (small && d->stage == nullptr) HIP_TRY(hipHostMalloc((void **)&d->stage, STAGE_BYTES, hipHostMallocDefault));
+		if (small) {
+			for (int i = 0; i < np; i++)
+				if (parts[i].kind != OUT && parts[i].bytes) memcpy(d->stage + parts[i].off, parts[i].src, parts[i].bytes);
+			if (h2d_end) HIP_TRY(hipMemcpyAsync(arena, d->stage, h2d_end, hipMemcpyHostToDevice, nullptr));
+		} else {
+			for (int i = 0; i < np; i++)
+				if (parts[i].kind != OUT && parts[i].bytes)
+					HIP_TRY(hipMemcpy(arena + parts[i].off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice));
+		}
+		return 0;
+	fail:
+		return -1;
+	}
+
+	int end()
+	{
+		if (small) {
+			if (total > d2h_begin) HIP_TRY(hipMemcpyAsync(d->stage + d2h_begin, arena + d2h_begin, total - d2h_begin, hipMemcpyDeviceToHost, nullptr));
+			HIP_TRY(hipStreamSynchronize(nullptr));
+			for (int i = 0; i < np; i++)
+				if (parts[i].kind != IN && parts[i].bytes) memcpy(parts[i].dst, d->stage + parts[i].off, parts[i].bytes);
+		} else {
+			HIP_TRY(hipStreamSynchronize(nullptr));
+			for (int i = 0; i < np; i++)
+				if (parts[i].kind != IN && parts[i].bytes)
+					HIP_TRY(hipMemcpy(parts[i].dst, arena + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost));
+		}
+		return 0;
+	fail:
+		return -1;
+	}
+};
+
+static int exec_host(const struct fsm_hip_dfa *d,
 	const unsigned char *base, size_t in_bytes, size_t stride,
 	const uint32_t *len, const uint64_t *off, size_t n,
 	uint32_t *end_out, uint64_t *accept_bitmap)
 {
-	if (cd == nullptr) { errno = EINVAL; return -1; }
+	if (d == nullptr) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
-	if (hipSetDevice(cd->device) != hipSuccess) { errno = ENODEV; return -1; }
-	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(cd);
-	const size_t nwords = (n + 63) / 64;
-	const size_t o_in = 0, o_len = up256(in_bytes + 32);
-	const size_t o_off = o_len + (len ? up256(n * sizeof(uint32_t)) : 0);
-	const size_t o_end = o_off + (off ? up256((n + 1) * sizeof(uint64_t)) : 0);
-	const size_t o_bm = o_end + (end_out ? up256(n * sizeof(uint32_t)) : 0);
-	const size_t total = o_bm + (accept_bitmap ? up256(nwords * sizeof(uint64_t)) : 0);
-	unsigned char *arena = nullptr;
-	bool temp = false;
-	int rc = -1;
-	if (total <= d->arena_bytes) {
-		arena = d->arena;
-	} else if (total <= ARENA_KEEP) {
-		if (d->arena) { (void)hipFree(d->arena); d->arena = nullptr; d->arena_bytes = 0; }
-		size_t want = d->arena_bytes ? d->arena_bytes : ((size_t)2 << 20);
-		while (want < total) want *= 2;
-		HIP_TRY(hipMalloc((void **)&d->arena, want));
-		d->arena_bytes = want;
-		arena = d->arena;
+	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	/* +32: the generic kernel reads whole aligned 16-byte chunks */
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	const int p_bm = hc.add(HostCall::OUT, nullptr, accept_bitmap, ((n + 63) / 64) * sizeof(uint64_t));
+	if (hc.begin() != 0) return -1;
+	if (off) {
+		if (fsm_hip_exec_batch_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
+		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), nullptr) != 0) return -1;
 	} else {
-		HIP_TRY(hipMalloc((void **)&arena, total));
-		temp = true;
+		if (fsm_hip_exec_batch_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
+		                              hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), nullptr) != 0) return -1;
 	}
-	{
-		unsigned char *d_in = arena + o_in;
-		uint32_t *d_len = len ? reinterpret_cast<uint32_t *>(arena + o_len) : nullptr;
-		uint64_t *d_off = off ? reinterpret_cast<uint64_t *>(arena + o_off) : nullptr;
-		uint32_t *d_end = end_out ? reinterpret_cast<uint32_t *>(arena + o_end) : nullptr;
-		uint64_t *d_bm = accept_bitmap ? reinterpret_cast<uint64_t *>(arena + o_bm) : nullptr;
-		const bool small = total <= STAGE_BYTES;
-		if (small && d->stage == nullptr) HIP_TRY(hipHostMalloc((void **)&d->stage, STAGE_BYTES, hipHostMallocDefault));
-		if (small) {
-			/* inputs and side arrays are contiguous in the arena up to o_end: one copy */
-			if (in_bytes) memcpy(d->stage + o_in, base, in_bytes);
-			if (len) memcpy(d->stage + o_len, len, n * sizeof(uint32_t));
-			if (off) memcpy(d->stage + o_off, off, (n + 1) * sizeof(uint64_t));
-			HIP_TRY(hipMemcpyAsync(arena, d->stage, o_end, hipMemcpyHostToDevice, nullptr));
-		} else {
-			if (in_bytes) HIP_TRY(hipMemcpy(d_in, base, in_bytes, hipMemcpyHostToDevice));
-			if (len) HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-			if (off) HIP_TRY(hipMemcpy(d_off, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-		}
-		if (off) {
-			if (fsm_hip_exec_batch_offsets_device(d, d_in, d_off, n, d_end, d_bm, nullptr) != 0) goto fail;
-		} else {
-			if (fsm_hip_exec_batch_device(d, d_in, stride, d_len, n, d_end, d_bm, nullptr) != 0) goto fail;
-		}
-		if (small) {
-			if (total > o_end) HIP_TRY(hipMemcpyAsync(d->stage + o_end, arena + o_end, total - o_end, hipMemcpyDeviceToHost, nullptr));
-			HIP_TRY(hipStreamSynchronize(nullptr));
-			if (end_out) memcpy(end_out, d->stage + o_end, n * sizeof(uint32_t));
-			if (accept_bitmap) memcpy(accept_bitmap, d->stage + o_bm, nwords * sizeof(uint64_t));
-		} else {
-			HIP_TRY(hipStreamSynchronize(nullptr));
-			if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-			if (accept_bitmap) HIP_TRY(hipMemcpy(accept_bitmap, d_bm, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
-		}
-	}
-	rc = 0;
-fail:
-	if (temp) {
-		int e = errno;
-		(void)hipFree(arena);
-		errno = e;
-	}
-	return rc;
+	return hc.end();
 }
 
 extern "C" int fsm_hip_exec_batch(const struct fsm_hip_dfa *d,
@@ -1118,29 +1154,14 @@ extern "C" int fsm_hip_exec_batch_ids(const struct fsm_hip_dfa *d,
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
 	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
-	unsigned char *d_in = nullptr;
-	uint32_t *d_len = nullptr, *d_out = nullptr;
-	int rc = -1;
-	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
-	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
-	if (len) {
-		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
-		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	}
-	HIP_TRY(hipMalloc((void **)&d_out, n * sizeof(uint32_t)));
-	if (fsm_hip_exec_batch_ids_device(d, d_in, stride, d_len, n, mode, d_out, nullptr) != 0) goto fail;
-	HIP_TRY(hipStreamSynchronize(nullptr));
-	HIP_TRY(hipMemcpy(id_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	rc = 0;
-fail:
-	{
-		int e = errno;
-		if (d_in) (void)hipFree(d_in);
-		if (d_len) (void)hipFree(d_len);
-		if (d_out) (void)hipFree(d_out);
-		errno = e;
-	}
-	return rc;
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	if (fsm_hip_exec_batch_ids_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n, mode,
+	                                  hc.dev<uint32_t>(p_out), nullptr) != 0) return -1;
+	return hc.end();
 }
 
 extern "C" size_t fsm_hip_ret_count(const struct fsm_hip_dfa *dc)
@@ -1219,33 +1240,15 @@ extern "C" int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *d,
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
 	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
-	unsigned char *d_in = nullptr;
-	uint32_t *d_len = nullptr, *d_st = nullptr, *d_end = nullptr;
-	int rc = -1;
-	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
-	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
-	if (len) {
-		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
-		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	}
-	HIP_TRY(hipMalloc((void **)&d_st, n * sizeof(uint32_t)));
-	HIP_TRY(hipMemcpy(d_st, state_io, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
-	if (fsm_hip_exec_batch_resume_device(d, d_in, stride, d_len, n, d_st, d_end, nullptr, nullptr) != 0) goto fail;
-	HIP_TRY(hipStreamSynchronize(nullptr));
-	HIP_TRY(hipMemcpy(state_io, d_st, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	rc = 0;
-fail:
-	{
-		int e = errno;
-		if (d_in) (void)hipFree(d_in);
-		if (d_len) (void)hipFree(d_len);
-		if (d_st) (void)hipFree(d_st);
-		if (d_end) (void)hipFree(d_end);
-		errno = e;
-	}
-	return rc;
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_st = hc.add(HostCall::INOUT, state_io, state_io, n * sizeof(uint32_t));
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	if (fsm_hip_exec_batch_resume_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
+	                                     hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, nullptr) != 0) return -1;
+	return hc.end();
 }
 
 /* ------------------------------------------------------------------ */
@@ -1307,32 +1310,13 @@ extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
 	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
-	unsigned char *d_in = nullptr;
-	uint32_t *d_len = nullptr, *d_end = nullptr;
-	uint64_t *d_eo = nullptr;
-	const size_t words = fsm_hip_eager_words(d);
-	int rc = -1;
-	HIP_TRY(hipMalloc((void **)&d_in, n * stride + 32));
-	if (n * stride) HIP_TRY(hipMemcpy(d_in, base, n * stride, hipMemcpyHostToDevice));
-	if (len) {
-		HIP_TRY(hipMalloc((void **)&d_len, n * sizeof(uint32_t)));
-		HIP_TRY(hipMemcpy(d_len, len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	}
-	if (end_out) HIP_TRY(hipMalloc((void **)&d_end, n * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **)&d_eo, n * words * sizeof(uint64_t)));
-	if (fsm_hip_exec_batch_eager_device(d, d_in, stride, d_len, n, d_end, d_eo, nullptr) != 0) goto fail;
-	HIP_TRY(hipStreamSynchronize(nullptr));
-	if (end_out) HIP_TRY(hipMemcpy(end_out, d_end, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(eager_out, d_eo, n * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
-	rc = 0;
-fail:
-	{
-		int e = errno;
-		if (d_in) (void)hipFree(d_in);
-		if (d_len) (void)hipFree(d_len);
-		if (d_end) (void)hipFree(d_end);
-		if (d_eo) (void)hipFree(d_eo);
-		errno = e;
-	}
-	return rc;
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
+	if (hc.begin() != 0) return -1;
+	if (fsm_hip_exec_batch_eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
+	                                    hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), nullptr) != 0) return -1;
+	return hc.end();
 }
