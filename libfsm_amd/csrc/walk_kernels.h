@@ -15,6 +15,8 @@
  *              one word), replicated once per LDS bank so lane l always reads
  *              bank l%32: conflict-free by construction.  pre = the column,
  *              next = shift+mask: the state chain never touches memory.
+ *   Tiny5Pol   <= 6 states: 5-bit fields of 5 * next state, one private column copy per lane at LDS
+ *              address (byte << 8) | (lane << 2): one v_perm_b32 + one v_bfe_u32 per input byte.
  *   LdsPol     class-compressed dense table T[state][class] (u16) in LDS plus a
  *              256-byte byte->class map (conflict-free for 7-bit text, <= 2-way otherwise).
  *   CombPol    column-default + comb exceptions over byte CLASSES (B table
@@ -24,9 +26,13 @@
  *              per input byte in total.
  *   CombSelfPol CombPol + a self-loop mask per state kept in a register: bytes on
  *              which the state does not change cost only the conflict-free B lookup.
+ *   LdsSelfPol LdsPol + the current state's self-loop mask in a register (rows carry their mask).
  *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS (+ LDS mirror of its head).
  *   SparsePol  per-state record {exception bitmap, base state} + exception lists in HBM/L2, the
  *              records nearest the start state in LDS (failure-link form of big tables).
+ * Wrappers: EagerPol (<= 64 eager-output ids, set in registers), EagerWidePol (more: set in memory).
+ * Optional policy hooks, found by SFINAE: pre_dw (lookup from the raw input dword), skip16 (one wave
+ * vote skips a 16-byte chunk that changes no lane's state), init_at / finish_at (input index).
  * MASK: lanes already in an absorbing state skip the state-dependent lookup
  * (exec-masked), which takes their addresses out of the LDS bank arbitration.
  *
