@@ -129,7 +129,7 @@ struct TinyPol {
 	typedef W P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
-	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static uint32_t code(S s) { return sizeof(W) == 8 ? (s & 15u) : s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
@@ -145,10 +145,15 @@ struct TinyPol {
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const
 	{
 		if (sizeof(W) == 8) {
-			/* 32-bit ops only: pick the dword holding nibble `st`, then shift */
-			const uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
-			const uint32_t h = (st & 8u) ? hi : lo;
-			return (h >> ((st & 7u) * 4u)) & 15u;
+			/* One 64-bit shift.  Its destination must not overlap its sources: the compiler's own
+			 * allocation of v_lshrrev_b64 did, and ~45 % of 16-wave launches then returned wrong
+			 * states (tests/test_gpu_parity.py::test_sixteen_state_columns_under_full_occupancy) --
+			 * hence inline asm with an early-clobber output.  The shift uses bits 5:0 of its amount,
+			 * so the state is carried unmasked (code() masks it): 2 operations per byte. */
+			uint64_t t;
+			const uint32_t sh = st << 2;
+			asm volatile("v_lshrrev_b64 %0, %1, %2" : "=&v"(t) : "v"(sh), "v"((uint64_t)v));
+			return (uint32_t)t;
 		}
 		return (uint32_t)(v >> (st * 4u)) & 15u;
 	}

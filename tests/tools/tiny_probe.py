@@ -29,6 +29,8 @@ def main():
             nt[:, c] = rng.randint(0, S, S)       # complete on the alphabet: no lane ever dies
         flat = hip.FlatDfa.from_dense(nt, 0, (rng.rand(S) < 0.5).astype(int).tolist())
         dfa = hip.HipDfa(flat)
+        if os.environ.get("TINY_WAVES"):
+            dfa.tune(hip.KNOB_WAVES, int(os.environ["TINY_WAVES"]))
         ms = []
         for _ in range(5):
             dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)
