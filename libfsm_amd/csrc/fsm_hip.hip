@@ -164,7 +164,9 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.start = p.start;
 			a.abs_min = p.abs_min;
 			a.fin_div = 1;
-			d->table_lds = p.S1 <= 8 ? TinyPol<uint32_t>::lds_bytes(0) : TinyPol<uint64_t>::lds_bytes(0);
+			/* 7..16 states: 64-bit columns; a 32-bit format for <= 8 states measured slower on the same box
+			 * (4.95-5.06 vs 5.10-5.61 TB/s, profiles/r01_tiny_by_states.txt) and was dropped */
+			d->table_lds = TinyPol<uint64_t>::lds_bytes(0);
 			break;
 		}
 		case FSM_HIP_LAYOUT_COMBSELF: {
@@ -535,7 +537,6 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 			switch (d->plan.layout) {
 			case FSM_HIP_LAYOUT_TINY:
 				e = !d->plan.tiny5_col.empty() ? launch_eager<Tiny5Pol>(c, a, grid, block, s)
-				  : d->plan.S1 <= 8 ? launch_eager<TinyPol<uint32_t>>(c, a, grid, block, s)
 				                    : launch_eager<TinyPol<uint64_t>>(c, a, grid, block, s);
 				break;
 			case FSM_HIP_LAYOUT_LDS: e = launch_eager<LdsPol<false>>(c, a, grid, block, s); break;
@@ -546,7 +547,6 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		switch (d->plan.layout) {
 		case FSM_HIP_LAYOUT_TINY:
 			e = !d->plan.tiny5_col.empty() ? launch_pol<Tiny5Pol>(c, a, grid, block, s)
-			  : d->plan.S1 <= 8 ? launch_pol<TinyPol<uint32_t>>(c, a, grid, block, s)
 			                    : launch_pol<TinyPol<uint64_t>>(c, a, grid, block, s);
 			break;
 		case FSM_HIP_LAYOUT_LDS:     e = launch_masked<LdsPol>(c, a, grid, block, s); break;

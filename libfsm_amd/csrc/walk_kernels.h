@@ -10,7 +10,7 @@
  * Table policies (how delta(state, byte) is evaluated).  Each policy splits a
  * step into  pre(byte)  -- independent of the state, so all 16 of a 16-byte
  * chunk are issued together --  and  next(state, pre)  -- the dependent chain:
- *   TinyPol<W> <=8 (W=uint32) or <=16 (W=uint64) states.  LDS holds, per byte
+ *   TinyPol<W> 7..16 states (W=uint64; a W=uint32 format for <= 8 states measured slower and is unused).  LDS holds, per byte
  *              value, the whole transition COLUMN (4-bit next states packed in
  *              one word), replicated once per LDS bank so lane l always reads
  *              bank l%32: conflict-free by construction.  pre = the column,
@@ -53,6 +53,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fsmhip {
 
@@ -140,8 +141,19 @@ struct TinyPol {
 		const uint64_t *src = static_cast<const uint64_t *>(a.tab);
 		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) col[i] = (W)src[i >> 5];
 		colp = col + (threadIdx.x & 31u);
+		/* pre_dw forms LDS addresses by permutation: the table must start at LDS address 0 */
+		if (sizeof(W) == 8 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return colp[b * 32u]; }
+	/* 64-bit columns: a column row is 32 x 8 = 256 bytes, so -- the table starting at LDS address 0 --
+	 * the address is the byte permutation [0, 0, input byte, (lane % 32) << 3]: one v_perm_b32 */
+	template <class Q = W>
+	__device__ __forceinline__ auto pre_dw(uint32_t d, int k) const -> typename std::enable_if<sizeof(Q) == 8, P>::type
+	{
+		typedef const uint64_t __attribute__((address_space(3))) *lds_u64p;
+		const uint32_t sel = 0x0c0c0400u + ((uint32_t)k << 8);
+		return *(lds_u64p)(uintptr_t)__builtin_amdgcn_perm(d, (threadIdx.x & 31u) << 3, sel);
+	}
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const
 	{
 		if (sizeof(W) == 8) {
@@ -155,7 +167,7 @@ struct TinyPol {
 			asm volatile("v_lshrrev_b64 %0, %1, %2" : "=&v"(t) : "v"(sh), "v"((uint64_t)v));
 			return (uint32_t)t;
 		}
-		return (uint32_t)(v >> (st * 4u)) & 15u;
+		return (uint32_t)(v >> (st * 4u)) & 15u;   /* 32-bit columns (<= 8 states): not instantiated any more */
 	}
 };
 
