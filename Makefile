@@ -21,4 +21,11 @@ check-gpu:         # on an MI355X
 bench:
 	$(PY) bench.py
 
-.PHONY: all lib oracle golden check check-gpu bench
+# plain-C callers of the boundary; LIBFSM = where the host's libfsm / libre live (here: the oracle's build of the reference)
+LIBFSM ?= oracle/_ref
+examples: lib
+	$(CC) -std=c99 -Wall -Iinclude examples/hipgrep.c -o examples/hipgrep -Llibfsm_amd -lfsm_hip -Wl,-rpath,$(CURDIR)/libfsm_amd -Wl,-rpath-link,/opt/rocm/lib
+	$(CC) -std=c99 -Wall -Iinclude examples/retest_hip.c -o examples/retest_hip -L$(LIBFSM) -lfsm_ref -Llibfsm_amd -lfsm_hip \
+		-Wl,-rpath,$(CURDIR)/$(LIBFSM) -Wl,-rpath,$(CURDIR)/libfsm_amd -Wl,-rpath-link,/opt/rocm/lib
+
+.PHONY: all lib oracle golden check check-gpu bench examples
