@@ -68,8 +68,10 @@ void fsm_hip_plan_free(struct fsm_hip_plan *plan);
 /* Borrowed pointer into the plan (count = number of elements). */
 int fsm_hip_plan_get(const struct fsm_hip_plan *plan, int what, const void **data, size_t *count);
 
-/* Measurement aid: average milliseconds of a trivially coalesced read-only pass over `bytes`
- * device bytes (16 B per lane, grid-stride), i.e. the HBM read rate this device actually sustains.
+/* Measurement aid: average milliseconds of the fastest of three read-only passes over `bytes`
+ * device bytes -- 16 B per lane grid-stride with plain loads, the same with nontemporal loads, and
+ * LDS-DMA of 128-byte segments of 1 KiB rows into per-wave tiles (the walk's own input path
+ * without the walk) -- i.e. the HBM read rate this device actually sustains.
  * d_scratch4 = 4 writable device bytes.  <0 on error. */
 double fsm_hip_stream_read_probe_ms(const void *d_base, size_t bytes, void *d_scratch4, int reps, void *hip_stream);
 

@@ -1216,8 +1216,7 @@ gen_affix_kernel(const GenArgs g, const AffixArgs x)
 
 /* Read-only streaming probe: the HBM read rate a trivially coalesced kernel reaches on this
  * device (16 B per lane, grid-stride, optionally nontemporal), reported by bench.py next to the
- * spec peak.  A lower bound of the achievable stream rate, not a roof: the walk kernels' LDS-DMA
- * path has measured above it. */
+ * spec peak.  (The LDS-DMA probe below reads faster: it is the third candidate of the probe.) */
 template <bool NT>
 __global__ void __launch_bounds__(256)
 stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
@@ -1240,6 +1239,41 @@ stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
 	for (; i < nvec; i += step) acc ^= src[i];
 	const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
 	if (x == 0x9E3779B9u) out[0] = x; /* practically never: keeps the loads alive */
+}
+
+/* The same probe through the walk's own input path: LDS-DMA of 128-byte row segments into a per-wave
+ * 8 KiB tile (the access pattern of walk_ldsdma<..., 128, 2>), one LDS word per tile consumed, no walk. */
+__global__ void __launch_bounds__(1024)
+dma_stream_kernel(const uint8_t *base, uint64_t nrows, uint64_t stride, uint32_t *out)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	unsigned char *stg = lds + wave * 8192u;
+	const uint64_t ntiles = nrows / 64u;
+	const uint32_t nseg = (uint32_t)(stride / 128u);
+	const uint32_t lr = lane / 8u, lq = lane % 8u;
+	uint32_t acc = 0;
+	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
+		const unsigned char *src[8];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++) src[j] = base + (tile * 64u + j * 8u + lr) * stride + lq * 16u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++)
+			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 2);
+		for (uint32_t s_ = 0; s_ < nseg; s_++) {
+			__builtin_amdgcn_s_waitcnt(0x0F70);
+			__asm__ volatile("" ::: "memory");
+			acc ^= *reinterpret_cast<const uint32_t *>(stg + lane * 16u);
+			__builtin_amdgcn_s_waitcnt(0xC07F);
+			__asm__ volatile("" ::: "memory");
+			if (s_ + 1 < nseg) {
+#pragma unroll
+				for (uint32_t j = 0; j < 8; j++)
+					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s_ + 1) * 128u), (lds_void_t *)(stg + j * 1024u), 16, 0, 2);
+			}
+		}
+	}
+	if (acc == 0x9E3779B9u) out[0] = acc;
 }
 
 } // namespace fsmhip
