@@ -1066,23 +1066,24 @@ extern "C" double fsm_hip_stream_read_probe_ms(const void *d_base, size_t bytes,
 	}
 	if (bytes >= ((size_t)64 << 20)) {
 		/* third candidate: the walk's own input path without the walk -- LDS-DMA of 128-byte segments of
-		 * 1 KiB rows into per-wave tiles, 12 waves (8 and 16 measured the same: 6.86-6.89 TB/s) */
+		 * 1 KiB rows into per-wave tiles (6.5-7.06 TB/s; a few waves per CU already saturate it) */
 		const uint64_t stride = 1024, nrows = (bytes / stride) / 64u * 64u;
-		const int waves = 12;
-		const size_t ldsb = (size_t)waves * 8192u;
-		float t = -1.f;
-		HIP_TRY(hipFuncSetAttribute((const void *)dma_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-		hipLaunchKernelGGL(dma_stream_kernel, dim3((unsigned)ncu * 2u), dim3((unsigned)waves * 64u), ldsb, s,
-		                   static_cast<const uint8_t *>(d_base), nrows, stride, static_cast<uint32_t *>(d_scratch4));
-		HIP_TRY(hipEventRecord(e0, s));
-		for (int r = 0; r < reps; r++)
+		for (int waves = 3; waves <= 12; waves *= 2) {   /* 3, 6, 12 waves per workgroup, two workgroups per CU */
+			const size_t ldsb = (size_t)waves * 8192u;
+			float t = -1.f;
+			HIP_TRY(hipFuncSetAttribute((const void *)dma_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
 			hipLaunchKernelGGL(dma_stream_kernel, dim3((unsigned)ncu * 2u), dim3((unsigned)waves * 64u), ldsb, s,
 			                   static_cast<const uint8_t *>(d_base), nrows, stride, static_cast<uint32_t *>(d_scratch4));
-		HIP_TRY(hipEventRecord(e1, s));
-		HIP_TRY(hipEventSynchronize(e1));
-		HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-		t = t / (float)reps * (float)((double)bytes / (double)(nrows * stride));   /* normalise to `bytes` */
-		if (t > 0.f && t < ms) ms = t;
+			HIP_TRY(hipEventRecord(e0, s));
+			for (int r = 0; r < reps; r++)
+				hipLaunchKernelGGL(dma_stream_kernel, dim3((unsigned)ncu * 2u), dim3((unsigned)waves * 64u), ldsb, s,
+				                   static_cast<const uint8_t *>(d_base), nrows, stride, static_cast<uint32_t *>(d_scratch4));
+			HIP_TRY(hipEventRecord(e1, s));
+			HIP_TRY(hipEventSynchronize(e1));
+			HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+			t = t / (float)reps * (float)((double)bytes / (double)(nrows * stride));   /* normalise to `bytes` */
+			if (t > 0.f && t < ms) ms = t;
+		}
 	}
 fail:
 	if (e0) (void)hipEventDestroy(e0);
