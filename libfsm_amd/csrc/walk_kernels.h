@@ -10,7 +10,7 @@
  * Table policies (how delta(state, byte) is evaluated).  Each policy splits a
  * step into  pre(byte)  -- independent of the state, so all 16 of a 16-byte
  * chunk are issued together --  and  next(state, pre)  -- the dependent chain:
- *   TinyPol<W> 7..16 states (W=uint64; a W=uint32 format for <= 8 states measured slower and is unused).  LDS holds, per byte
+ *   TinyPol<uint64_t> 7..16 states (a 32-bit column format for <= 8 states measured slower: dropped).  LDS holds, per byte
  *              value, the whole transition COLUMN (4-bit next states packed in
  *              one word), replicated once per LDS bank so lane l always reads
  *              bank l%32: conflict-free by construction.  pre = the column,
@@ -53,7 +53,6 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 namespace fsmhip {
 
@@ -127,10 +126,11 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 
 template <class W>
 struct TinyPol {
+	static_assert(sizeof(W) == 8, "16 states x 4 bits per column");
 	typedef W P;
-	typedef uint32_t S;
+	typedef uint32_t S;   /* carried unmasked: only bits 3:0 are the state (see next) */
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
-	__device__ __forceinline__ static uint32_t code(S s) { return sizeof(W) == 8 ? (s & 15u) : s; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s & 15u; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
@@ -142,13 +142,12 @@ struct TinyPol {
 		for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) col[i] = (W)src[i >> 5];
 		colp = col + (threadIdx.x & 31u);
 		/* pre_dw forms LDS addresses by permutation: the table must start at LDS address 0 */
-		if (sizeof(W) == 8 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
+		if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return colp[b * 32u]; }
-	/* 64-bit columns: a column row is 32 x 8 = 256 bytes, so -- the table starting at LDS address 0 --
-	 * the address is the byte permutation [0, 0, input byte, (lane % 32) << 3]: one v_perm_b32 */
-	template <class Q = W>
-	__device__ __forceinline__ auto pre_dw(uint32_t d, int k) const -> typename std::enable_if<sizeof(Q) == 8, P>::type
+	/* a column row is 32 x 8 = 256 bytes, so -- the table starting at LDS address 0 -- the address is
+	 * the byte permutation [0, 0, input byte, (lane % 32) << 3]: one v_perm_b32 */
+	__device__ __forceinline__ P pre_dw(uint32_t d, int k) const
 	{
 		typedef const uint64_t __attribute__((address_space(3))) *lds_u64p;
 		const uint32_t sel = 0x0c0c0400u + ((uint32_t)k << 8);
@@ -156,18 +155,15 @@ struct TinyPol {
 	}
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const
 	{
-		if (sizeof(W) == 8) {
-			/* One 64-bit shift.  Its destination must not overlap its sources: the compiler's own
-			 * allocation of v_lshrrev_b64 did, and ~45 % of 16-wave launches then returned wrong
-			 * states (tests/test_gpu_parity.py::test_sixteen_state_columns_under_full_occupancy) --
-			 * hence inline asm with an early-clobber output.  The shift uses bits 5:0 of its amount,
-			 * so the state is carried unmasked (code() masks it): 2 operations per byte. */
-			uint64_t t;
-			const uint32_t sh = st << 2;
-			asm volatile("v_lshrrev_b64 %0, %1, %2" : "=&v"(t) : "v"(sh), "v"((uint64_t)v));
-			return (uint32_t)t;
-		}
-		return (uint32_t)(v >> (st * 4u)) & 15u;   /* 32-bit columns (<= 8 states): not instantiated any more */
+		/* One 64-bit shift.  Its destination must not overlap its sources: the compiler's own
+		 * allocation of v_lshrrev_b64 did, and ~45 % of 16-wave launches then returned wrong
+		 * states (tests/test_gpu_parity.py::test_sixteen_state_columns_under_full_occupancy) --
+		 * hence inline asm with an early-clobber output.  The shift uses bits 5:0 of its amount,
+		 * so the state is carried unmasked (code() masks it): 2 operations per byte. */
+		uint64_t t;
+		const uint32_t sh = st << 2;
+		asm volatile("v_lshrrev_b64 %0, %1, %2" : "=&v"(t) : "v"(sh), "v"((uint64_t)v));
+		return (uint32_t)t;
 	}
 };
 
