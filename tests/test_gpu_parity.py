@@ -966,3 +966,22 @@ def test_reperf_script_cases_as_batches(hip):
         assert (end == g.end[0]).all()
         assert int(np.unpackbits(bm.view(np.uint8)).sum()) == n * g.meta["expected_matches"]
         dfa.close()
+
+
+def test_host_front_arena_sizes(hip):
+    """The host-pointer front's three staging regimes -- pinned staging (<= 1 MiB), the per-dfa device arena
+    (grows, <= 256 MiB) and a temporary allocation above that -- give the same answers, in any order."""
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    dfa = hip.HipDfa(g.flat)
+    o = Oracle(g.flat)
+    big = hip.gen_inputs_host(300_000, 1024, 0, 5, None, b"Libfsm", 8)       # 307 MB: temporary allocation
+    for n in (3, 300_000, 50_000, 700, 300_000, 1):
+        rows = big[:n]
+        end, bm = dfa.exec_batch(rows)
+        want = o.table_walk(rows[:2000])
+        assert np.array_equal(end[:2000], want), n
+        assert int((end != NO).sum()) == int(np.unpackbits(bm.view(np.uint8)).sum())
+        if n == 300_000:
+            assert abs(int((end != NO).sum()) - n // 8) < 40
+    dfa.close()
