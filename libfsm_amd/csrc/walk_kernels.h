@@ -538,7 +538,7 @@ struct EagerPol : Pol {
 	typedef EagerState<Pol> S;
 	typedef typename Pol::P P;
 	const uint64_t *emask;
-	uint32_t lo_end, hi_begin, fin_div;
+	uint32_t lo_end, hi_begin, span, fin_div;
 
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
@@ -546,6 +546,7 @@ struct EagerPol : Pol {
 		emask = a.emask;
 		lo_end = a.eager_lo_end;
 		hi_begin = a.eager_hi_begin;
+		span = hi_begin - lo_end;
 		fin_div = a.fin_div;
 	}
 	__device__ __forceinline__ uint64_t outputs_of(uint32_t c) const
@@ -575,7 +576,8 @@ struct EagerPol : Pol {
 		st.s = Pol::next(st.s, p);
 		const uint32_t c = Pol::code(st.s);
 		/* OR is idempotent: staying in the same state emits nothing new */
-		if (c != before && (c < lo_end || c >= hi_begin)) st.acc |= emask[c / fin_div];
+		/* outside [lo_end, hi_begin) in one unsigned compare */
+		if (c != before && (c - lo_end) >= span) st.acc |= emask[c / fin_div];
 		return st;
 	}
 	__device__ __forceinline__ static void finish(const WalkArgs &a, uint64_t i, bool valid, const S &st)
@@ -615,7 +617,7 @@ struct EagerWidePol : Pol {
 		hi_begin = a.eager_hi_begin;
 		fin_div = a.fin_div;
 	}
-	__device__ __forceinline__ bool emits(uint32_t c) const { return c < lo_end || c >= hi_begin; }
+	__device__ __forceinline__ bool emits(uint32_t c) const { return (c - lo_end) >= (hi_begin - lo_end); }   /* outside [lo_end, hi_begin) */
 	__device__ __forceinline__ void emit(uint32_t c, uint64_t *row) const
 	{
 		if (c != 0xFFFFFFFFu && row != nullptr) {
