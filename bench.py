@@ -317,6 +317,7 @@ def main():
         dist.all_reduce(acc_t)
     if rank != 0:
         if world > 1:
+            dist.barrier()   # leave together with rank 0, which still probes the stream rate and prints
             dist.destroy_process_group()
         return
 
@@ -377,6 +378,7 @@ def main():
             res["value"] = None  # a fast wrong answer is not a result
     print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
