@@ -24,10 +24,15 @@
  * There is NO CPU fallback: without a usable HIP device every exec call fails
  * with -1/ENODEV.
  *
- * Threading: a struct fsm_hip_dfa is immutable after creation except for its
- * timing events and tuning knobs; concurrent exec calls on ONE dfa from several
- * host threads must be serialised by the caller (distinct dfa objects are
- * independent).  Exec calls make the dfa's device current (hipSetDevice).
+ * Threading: the table of a struct fsm_hip_dfa is immutable after creation.  What
+ * exec calls do mutate -- the staging arena of the host-pointer fronts, the
+ * timing events, the lazily built end-id / resume tables -- sits behind a
+ * per-dfa mutex, so several host threads may share one dfa: host-pointer calls
+ * on it run one after the other, device-pointer calls only serialise their
+ * enqueue (tuning knobs are not locked: set them before sharing).  Distinct dfa
+ * objects are fully independent.  A call makes the dfa's device current while
+ * it runs and restores the caller's device before it returns; host-pointer
+ * fronts run on a private non-blocking stream, never on the NULL stream.
  */
 #ifndef FSM_HIP_H
 #define FSM_HIP_H
@@ -202,7 +207,8 @@ int fsm_hip_exec(const struct fsm_hip_dfa *dfa,
 /* cf. fsm_vm_match_buffer() src/libfsm/vm.c:218-229: 1 / 0, -1 on error. */
 int fsm_hip_match_buffer(const struct fsm_hip_dfa *dfa, const char *buf, size_t n);
 
-/* cf. fsm_vm_match_file() src/libfsm/vm.c:188-216 (reads the whole file). */
+/* cf. fsm_vm_match_file() src/libfsm/vm.c:188-216: the file is read in 64 KiB chunks, the state
+ * carried from chunk to chunk on the device; reading stops once the result is decided. */
 int fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f);
 
 /* Flatten a struct fsm * into a malloc'd description (free with
@@ -237,6 +243,12 @@ int fsm_hip_print(FILE *f, const struct fsm *fsm);
 #define FSM_HIP_STATE_START 0xFFFFFFFDu
 #define FSM_HIP_STATE_DEAD  0xFFFFFFFCu
 
+/* 1 if no input byte can move the DFA out of `state` (a caller's state id, FSM_HIP_STATE_START or
+ * FSM_HIP_STATE_DEAD) -- the condition under which the reference VM stops reading (STOP success on an
+ * absorbing end state, src/libfsm/vm/ir.c:763-766; STOP fail on a missing edge); 0 otherwise;
+ * -1 + errno=EINVAL for a bad id.  A streaming caller may stop feeding such an input. */
+int fsm_hip_state_is_absorbing(const struct fsm_hip_dfa *dfa, uint32_t state);
+
 int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *state_io, uint32_t *end_out);
@@ -255,12 +267,21 @@ int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dfa,
  *   FSM_HIP_IDS_RET       the index of the end state's id SET in the
  *                         de-duplicated, sorted list of sets (AMBIG_MULTIPLE; the
  *                         list is built like build_retlist, src/libfsm/vm/retlist.c:93-138:
- *                         ordered by count, then lexicographically); resolve it
+ *                         ordered by count, then by memcmp of the id arrays, cmp_ret :63-79 --
+ *                         so the index equals the reference's ret index); resolve it
  *                         with fsm_hip_ret_get().
  * Rejected inputs get FSM_HIP_NO_MATCH, accepted inputs whose end state carries
  * no id get FSM_HIP_NO_ID (EARLIEST) or the index of the empty set (RET). */
 #define FSM_HIP_NO_ID 0xFFFFFFFEu
-enum { FSM_HIP_IDS_EARLIEST = 1, FSM_HIP_IDS_RET = 2 };
+enum { FSM_HIP_IDS_EARLIEST = 1, FSM_HIP_IDS_RET = 2, FSM_HIP_IDS_ERROR = 3 };
+
+/* AMBIG_ERROR (include/fsm/options.h:35-43): "emit a single endid", refusing DFAs in which some
+ * end state carries more than one -- fsm_print fails with EINVAL there (src/libfsm/print/c.c:67-72)
+ * after calling hook.conflict().  FSM_HIP_IDS_ERROR makes fsm_hip_exec_batch_ids*() fail the same
+ * way (-1, errno = EINVAL, nothing launched); on a conflict-free DFA it is FSM_HIP_IDS_EARLIEST.
+ * fsm_hip_ids_conflict() plays the hook: 1 and *state = the lowest such end state, 0 if none,
+ * -1 + errno on error. */
+int fsm_hip_ids_conflict(const struct fsm_hip_dfa *dfa, fsm_state_t *state);
 
 int fsm_hip_exec_batch_ids(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
@@ -347,7 +368,6 @@ void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
 	const unsigned char *suffixes, unsigned nsfx,
 	unsigned every);
 
-/* Library/ABI version: major*10000 + minor*100 + patch. */
 /* ------------------------------------------------------------------ */
 /* literal sets: the Aho-Corasick caller of the path                   */
 /* ------------------------------------------------------------------ */
@@ -378,6 +398,7 @@ struct fsm_hip_dfa_desc *fsm_hip_strings_build(struct fsm_hip_strings *g, unsign
 /* re_strings() in one call (re_strings.c:21-52): NUL-terminated words, no end-ids. */
 struct fsm_hip_dfa_desc *fsm_hip_strings(const char *const a[], size_t n, unsigned flags);
 
+/* Library/ABI version: major*10000 + minor*100 + patch. */
 int fsm_hip_version(void);
 
 #ifdef __cplusplus

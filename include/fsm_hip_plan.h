@@ -17,18 +17,18 @@ extern "C" {
 #endif
 
 enum {
-	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles, 2 generic; -1 auto */
-	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (1,2,4,8)      */
-	FSM_HIP_KNOB_ROWS          = 3,  /* direct mode: independent inputs per lane (1 or 2)             */
+	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles (both: uniform 16-byte-aligned rows only),
+	                                  * 2 generic (per-lane loads, any input), 3 ragged (coalesced + lane refill, any input); -1 auto */
+	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
+	FSM_HIP_KNOB_ROWS          = 3,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
-	FSM_HIP_KNOB_MASK          = 7,  /* 0/1: absorbing lanes skip the state-dependent table lookup    */
+	FSM_HIP_KNOB_MASK          = 7,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_HOT_BYTES     = 8,  /* global layout: bytes of the table head mirrored in LDS        */
 	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */
 	FSM_HIP_KNOB_PREFETCH      = 10, /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
-	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
-	FSM_HIP_KNOB_QUEUE         = 12  /* ragged fronts: 1 = lanes claim inputs from a device counter (walk_queue); default 0 = 64 fixed inputs per wave */
+	FSM_HIP_KNOB_NT            = 11  /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
@@ -36,8 +36,9 @@ int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);
 struct fsm_hip_plan;
 
 enum {
-	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[13]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off,
-	                              *          comb256_abs_min_off,comb256_dflt,eager_lo_end,eager_hi_begin */
+	FSM_HIP_PLAN_SCALARS   = 0,  /* u32[17]: nstates,S1,start,C,abs_min,nabsorbing,layout,row_bytes,comb_abs_min_off,
+	                              *          comb256_abs_min_off,comb256_dflt,eager_lo_end,eager_hi_begin,
+	                              *          comb_eager_lo_off,comb_eager_hi_off,comb256_eager_lo_off,comb256_eager_hi_off */
 	FSM_HIP_PLAN_CLS       = 1,  /* u8[256]  */
 	FSM_HIP_PLAN_NEW2OLD   = 2,  /* u32[S1]  */
 	FSM_HIP_PLAN_FIN       = 3,  /* u32[S1]  */

@@ -24,8 +24,8 @@ LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "c
 ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_LDSSELF, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
 
-KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT, KNOB_QUEUE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
-IN_DIRECT, IN_LDSDMA, IN_GENERIC = 0, 1, 2
+KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsm_hip.so")
@@ -322,7 +322,8 @@ class Plan:
         s = self.get("scalars")
         (self.nstates, self.S1, self.start, self.C, self.abs_min, self.nabsorbing, self.layout, self.row_bytes,
          self.comb_abs_min_off, self.comb256_abs_min_off, self.comb256_dflt, self.eager_lo_end,
-         self.eager_hi_begin) = (int(x) for x in s)
+         self.eager_hi_begin, self.comb_eager_lo_off, self.comb_eager_hi_off, self.comb256_eager_lo_off,
+         self.comb256_eager_hi_off) = (int(x) for x in s)
 
     def get(self, what: str) -> np.ndarray:
         w, dt = self._WHAT[what]

@@ -10,13 +10,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/fsm_hip.h"
 #include "../../include/fsm_hip_plan.h"
 #include "plan.h"
-#include "walk_kernels.h"
+#include "launch.h"
+#include "gen_kernels.h"
 
 using namespace fsmhip;
 
@@ -35,6 +37,7 @@ struct fsm_hip_dfa {
 	uint32_t *d_fin_earliest = nullptr, *d_fin_ret = nullptr;
 	std::vector<uint32_t> ret_off, ret_ids;          /* de-duplicated id sets, CSR */
 	bool ids_ready = false;
+	uint32_t ids_conflict = FSM_HIP_NO_MATCH;        /* lowest end state carrying more than one id */
 	/* resume tables (built on first use) */
 	uint32_t *d_enc_of = nullptr, *d_orig_of = nullptr;
 	std::vector<uint32_t> enc_host;                  /* [S1] encoded state per renumbered state */
@@ -42,11 +45,14 @@ struct fsm_hip_dfa {
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	uint32_t *d_ew_off = nullptr, *d_ew_word = nullptr; /* wide eager sets (> 64 ids) */
 	uint64_t *d_ew_mask = nullptr;
-	unsigned long long *d_counter = nullptr;         /* work counter of walk_queue */
 	unsigned char *arena = nullptr;                  /* device scratch of the host-pointer front */
 	size_t arena_bytes = 0;
 	unsigned char *stage = nullptr;                  /* pinned host staging for small calls */
-	int knob_queue = -1;                             /* > 0: ragged fronts claim work per lane (walk_queue) */
+	hipStream_t hs = nullptr;                        /* private stream of the host-pointer fronts */
+	/* guards everything an exec call mutates: arena / stage, the timing events, the lazily built
+	 * end-id and resume tables.  Host-pointer fronts hold it for the whole call (they share the
+	 * arena), device-pointer fronts only while they enqueue. */
+	std::recursive_mutex mu;
 	WalkArgs proto;
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -56,11 +62,9 @@ struct fsm_hip_dfa {
 	int knob_nb = 0;             /* 0 auto */
 	uint32_t glob_row_bytes = 4;
 	uint64_t glob_tab_bytes = 0;
-	int knob_rows = 0;           /* 0 auto */
 	int knob_seg = 0;            /* 0 auto (128) */
 	int knob_prefetch = -1;      /* -1 auto (on) */
 	int knob_nt = -1;            /* -1 auto */
-	int knob_mask = -1;          /* -1 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
@@ -78,7 +82,7 @@ static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
 	if (hot + lds_bytes_btab() + 8u * 4096u > d->lds_limit) hot = d->lds_limit - lds_bytes_btab() - 8u * 4096u;
 	hot -= hot % d->glob_row_bytes;
 	d->proto.tab_bytes = (uint32_t)hot;
-	d->table_lds = GlobPol<false>::lds_bytes((uint32_t)hot);
+	d->table_lds = GlobPol::lds_bytes((uint32_t)hot);
 }
 
 static int hip_errno(hipError_t e)
@@ -98,7 +102,23 @@ static int hip_errno(hipError_t e)
 	if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: %s -> %s\n", #expr, hipGetErrorString(e_)); \
 	errno = hip_errno(e_); goto fail; } } while (0)
 
-extern "C" int fsm_hip_version(void) { return 100; }
+/* make the dfa's device current for the duration of a call and give the caller's device back */
+struct DevGuard {
+	int prev = -1;
+	bool good = true;
+	explicit DevGuard(int dev)
+	{
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != dev && hipSetDevice(dev) != hipSuccess) good = false;
+		if (prev == dev) prev = -1;
+	}
+	~DevGuard() { if (prev >= 0 && good) { int e = errno; (void)hipSetDevice(prev); errno = e; } }
+	bool ok() const { return good; }
+};
+
+typedef std::lock_guard<std::recursive_mutex> DfaLock;
+
+extern "C" int fsm_hip_version(void) { return 200; }
 
 /* ------------------------------------------------------------------ */
 /* create / free / info                                               */
@@ -206,7 +226,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.abs_min = p.comb256_abs_min_off;
 			a.dflt = p.comb256_dflt;
 			a.fin_div = 1;
-			d->table_lds = Comb256Pol<false>::lds_bytes(a.tab_bytes);
+			d->table_lds = Comb256Pol::lds_bytes(a.tab_bytes);
 			break;
 		}
 		case FSM_HIP_LAYOUT_LDS: {
@@ -299,19 +319,46 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : p.fin;
 		if (!p.emask.empty()) {
 			/* eager masks indexed like fin; thresholds in encoded-state units */
-			std::vector<uint64_t> em(d->fin_host.size(), 0);
-			for (uint32_t n2 = 0; n2 < p.S1; n2++) em[d->enc_host[n2] / a.fin_div] = p.emask[n2];
+			const size_t F = d->fin_host.size();
+			std::vector<uint64_t> em(F, 0);
+			std::vector<uint32_t> state_of(F, 0xFFFFFFFFu);   /* fin index -> renumbered state */
+			for (uint32_t n2 = 0; n2 < p.S1; n2++) {
+				em[d->enc_host[n2] / a.fin_div] = p.emask[n2];
+				state_of[d->enc_host[n2] / a.fin_div] = n2;
+			}
 			HIP_TRY(upload(&d->d_emask, em));
 			a.emask = d->d_emask;
-			a.eager_lo_end = p.eager_lo_end < p.S1 ? d->enc_host[p.eager_lo_end] : 0xFFFFFFFFu;
-			a.eager_hi_begin = p.eager_hi_begin < p.S1 ? d->enc_host[p.eager_hi_begin] : 0xFFFFFFFFu;
+			switch (p.layout) {
+			case FSM_HIP_LAYOUT_COMB:
+			case FSM_HIP_LAYOUT_COMBSELF:   /* rows placed region by region: thresholds on row offsets (plan.cpp build_comb) */
+				a.eager_lo_end = p.comb_eager_lo_off;
+				a.eager_hi_begin = p.comb_eager_hi_off;
+				break;
+			case FSM_HIP_LAYOUT_COMB256:
+				a.eager_lo_end = p.comb256_eager_lo_off;
+				a.eager_hi_begin = p.comb256_eager_hi_off;
+				break;
+			default:
+				a.eager_lo_end = p.eager_lo_end < p.S1 ? d->enc_host[p.eager_lo_end] : 0xFFFFFFFFu;
+				a.eager_hi_begin = p.eager_hi_begin < p.S1 ? d->enc_host[p.eager_hi_begin] : 0xFFFFFFFFu;
+				break;
+			}
 			a.eager_words = p.eager_words;
 			if (p.eager_words > 1) {
-				/* eager-capable layouts (tiny, lds, global) all have fin index == renumbered state */
-				std::vector<uint32_t> w(p.ew_word);
-				std::vector<uint64_t> m(p.ew_mask);
+				/* wide sets: the (word, mask) runs re-laid in fin-index order (= renumbered state except in
+				 * the comb layouts, whose fin index is the row offset) */
+				std::vector<uint32_t> off(F + 1, 0), w;
+				std::vector<uint64_t> m;
+				for (size_t i = 0; i < F; i++) {
+					off[i] = (uint32_t)w.size();
+					const uint32_t n2 = state_of[i];
+					if (n2 == 0xFFFFFFFFu) continue;
+					w.insert(w.end(), p.ew_word.begin() + p.ew_off[n2], p.ew_word.begin() + p.ew_off[n2 + 1]);
+					m.insert(m.end(), p.ew_mask.begin() + p.ew_off[n2], p.ew_mask.begin() + p.ew_off[n2 + 1]);
+				}
+				off[F] = (uint32_t)w.size();
 				if (w.empty()) { w.push_back(0); m.push_back(0); }
-				HIP_TRY(upload(&d->d_ew_off, p.ew_off));
+				HIP_TRY(upload(&d->d_ew_off, off));
 				HIP_TRY(upload(&d->d_ew_word, w));
 				HIP_TRY(upload(&d->d_ew_mask, m));
 				a.ew_off = d->d_ew_off;
@@ -326,7 +373,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 	}
 	HIP_TRY(hipEventCreate(&d->ev0));
 	HIP_TRY(hipEventCreate(&d->ev1));
-	HIP_TRY(hipMalloc((void **)&d->d_counter, 16));
+	HIP_TRY(hipStreamCreateWithFlags(&d->hs, hipStreamNonBlocking));
 	return d;
 fail:
 	{
@@ -351,9 +398,9 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_ew_off) (void)hipFree(d->d_ew_off);
 	if (d->d_ew_word) (void)hipFree(d->d_ew_word);
 	if (d->d_ew_mask) (void)hipFree(d->d_ew_mask);
-	if (d->d_counter) (void)hipFree(d->d_counter);
 	if (d->arena) (void)hipFree(d->arena);
 	if (d->stage) (void)hipHostFree(d->stage);
+	if (d->hs) (void)hipStreamDestroy(d->hs);
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	delete d;
@@ -363,199 +410,105 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* launch                                                             */
 /* ------------------------------------------------------------------ */
 
-struct LaunchCfg {
-	int mode, nb, rows, mask, waves, blocks_per_cu, seg, prefetch, nt, queue;
-	uint32_t lds;
-	unsigned long long *counter;
-};
-
-static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride)
+static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager)
 {
 	LaunchCfg c;
 	const uint32_t layout = d->plan.layout;
-	c.mode = IN_GENERIC;
-	c.nb = 1;
-	c.rows = 1;
-	c.seg = 64;
-	c.queue = d->knob_queue > 0; /* opt-in: measured 2-4x slower than fixed assignment (profiles/r01_ragged.txt) */
-	c.counter = d->d_counter;
+	c.nb = 8;
+	c.seg = 128;
 	/* every input line is consumed by exactly one DMA instruction (SEG = 128): nontemporal loads
 	 * measured +7.5 % on the HBM-bound tiny layout (profiles/r01_sweep8*), neutral elsewhere */
 	c.nt = d->knob_nt >= 0 ? (d->knob_nt != 0) : 1;
 	/* CombSelfPol's branchy chain is latency-bound: drop the register double-buffer (<= 64 VGPRs)
 	 * so two 16-wave workgroups share a CU (profiles/r01_sweep5*: 4.52 vs 4.32 TB/s) */
 	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF || layout == FSM_HIP_LAYOUT_SPARSE ? 0 : 1);
-	/* skipping lookups of absorbing lanes only pays where the lookup depends on the state */
-	/* measured: the exec-mask bookkeeping costs more than the bank conflicts it removes
-	 * (profiles/r01_sweep2*: comb256 4.17 TB/s unmasked vs 3.20 masked), so it is opt-in */
-	c.mask = d->knob_mask > 0 ? 1 : 0;
-	if (fast_ok) {
+	/* ragged / packed / unaligned inputs: the coalesced, lane-refilling kernel whenever at least four
+	 * waves' tiles and rings fit next to the table, else per-lane loads (walk_generic) */
+	const bool ragged_fits = d->table_lds + 4u * FSMHIP_RAGGED_WAVE_LDS <= d->lds_limit;
+	int mode = ragged_fits ? IN_RAGGED : IN_GENERIC;
+	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits)) mode = d->knob_input_mode;
+	else if (fast_ok) {
 		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging (8 KiB tile per wave) is the better input
 		 * path whenever at least 12 waves of tiles fit next to the table (lds layout 5.1 vs 4.8 TB/s;
 		 * combself, once whole self-loop chunks are skipped, 6.1 vs 5.0 TB/s: profiles/r01_sweep11*);
 		 * per-lane loads with 8 chunks in flight next to a bigger LDS table */
 		const bool dma_fits = d->table_lds + 12u * 8192u <= d->lds_limit;
-		int mode = (layout == FSM_HIP_LAYOUT_TINY || dma_fits) ? IN_LDSDMA : IN_DIRECT;
-		if (d->knob_input_mode >= 0) mode = d->knob_input_mode;
-		if (mode == IN_LDSDMA && stride % 64u != 0) mode = IN_DIRECT;
-		c.mode = mode;
-		if (c.mode == IN_LDSDMA) {
+		int m = (layout == FSM_HIP_LAYOUT_TINY || dma_fits) ? IN_LDSDMA : IN_DIRECT;
+		if (d->knob_input_mode == IN_DIRECT || d->knob_input_mode == IN_LDSDMA) m = d->knob_input_mode;
+		if (m == IN_LDSDMA && stride % 64u != 0) m = IN_DIRECT;
+		if (m == IN_LDSDMA) {
 			c.seg = d->knob_seg == 64 ? 64 : 128;
 			if (stride % 128u != 0) c.seg = 64;
+			/* the eager kernels exist for 128-byte segments and register-held sets only (2.3 vs 1.1 TB/s for
+			 * those; wide sets measured 1.8 behind LDS-DMA vs 2.1 with per-lane loads: tests/tools/eager_probe.py) */
+			if (eager && (c.seg != 128 || eager == 2)) m = IN_DIRECT;
 		}
-		if (c.mode == IN_DIRECT) {
-			/* the sparse layout waits on gathers, not on its input: 4 chunks keep it under 64 VGPRs */
-			c.nb = d->knob_nb > 0 ? d->knob_nb : (layout == FSM_HIP_LAYOUT_SPARSE ? 4 : 8);
-			while (c.nb > 1 && (stride / 16u) % (unsigned)c.nb != 0) c.nb >>= 1;
-			c.rows = d->knob_rows == 2 ? 2 : 1;
-			if (c.rows == 2 && c.nb > 4) c.nb = 4;
+		if (m == IN_DIRECT) {
+			/* the sparse layout waits on gathers, not on its input: 4 chunks keep it under 64 VGPRs;
+			 * the eager kernel is instantiated for 4 chunks only */
+			c.nb = d->knob_nb == 4 || d->knob_nb == 8 ? d->knob_nb : (layout == FSM_HIP_LAYOUT_SPARSE ? 4 : 8);
+			if (eager || !c.prefetch) c.nb = 4;
+			if ((stride / 16u) % 8u != 0) c.nb = 4;
+			if ((stride / 16u) % 4u != 0) m = -1;   /* rows shorter than / not a multiple of 64 bytes */
 		}
+		if (m >= 0) mode = m;
 	}
-	const uint32_t per_wave = c.mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : 0u;
-	/* waves per block: as many as LDS allows, 16 at most */
-	/* 16 waves behind one table copy; with nontemporal DMA loads the 16-wave workgroup (32 KiB
-	 * table + 16 x 8 KiB tiles = all 160 KiB of LDS) measured best for tiny (profiles/r01_sweep8*) */
-	/* combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72) */
-	int waves = d->knob_waves > 0 ? d->knob_waves : (layout == FSM_HIP_LAYOUT_COMBSELF && c.mode == IN_LDSDMA ? 12 : 16);
-	if (waves > 16) waves = 16;
+	c.mode = mode;
+	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
+	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
+	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
+	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
+	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12,
+	 * eager ragged / generic 8. */
+	int wmax = 16;
+	if (mode == IN_RAGGED) wmax = eager ? 8 : 12;
+	else if (eager && mode == IN_GENERIC) wmax = 8;
+	else if (eager && mode == IN_LDSDMA) wmax = 12;
+	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
+	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
+	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16) waves = d->knob_waves;
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
 	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
 	if (bpc * waves > 32) bpc = 32 / waves;
 	if (bpc < 1) bpc = 1;
-	/* twice the resident workgroups: the tail of the persistent grid balances better */
-	if (c.mode != IN_GENERIC) bpc *= 2;
+	/* twice the resident workgroups: the tail of the persistent grid balances better (the ragged kernel
+	 * partitions statically: one range per resident wave) */
+	if (mode == IN_DIRECT || mode == IN_LDSDMA) bpc *= 2;
 	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
 	c.blocks_per_cu = bpc;
 	return c;
 }
 
-/* ragged fronts: lanes claim inputs from a device counter (walk_queue); the counter and, if
- * wanted, the bitmap (filled with atomicOr) are cleared on the launch stream first */
-template <class Pol>
-static hipError_t launch_queue(const LaunchCfg &c, const WalkArgs &a, unsigned long long *counter, dim3 grid, dim3 block, hipStream_t s)
-{
-	void (*k)(const WalkArgs, unsigned long long *) = walk_queue<Pol>;
-	hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
-	if (e == hipSuccess && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ((a.n + 63) / 64) * sizeof(uint64_t), s);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, grid, block, c.lds, s, a, counter);
-	return hipGetLastError();
-}
-
-template <class Pol>
-static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
-{
-	void (*k)(const WalkArgs) = nullptr;
-	if (c.mode == IN_GENERIC && c.queue) return launch_queue<Pol>(c, a, c.counter, grid, block, s);
-	if (c.mode == IN_GENERIC) k = walk_generic<Pol>;
-	else if (c.mode == IN_LDSDMA) {
-		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2> : walk_ldsdma<Pol, 128, 0>;
-		else k = walk_ldsdma<Pol, 64, 0>;
-	}
-	else if (!c.prefetch && c.rows == 1 && c.nb >= 4) {
-		k = c.nb == 4 ? walk_direct_np<Pol, 4> : walk_direct_np<Pol, 8>;
-	} else if (c.rows == 2) {
-		switch (c.nb) {
-		case 1: k = walk_direct<Pol, 1, 2>; break;
-		case 2: k = walk_direct<Pol, 2, 2>; break;
-		default: k = walk_direct<Pol, 4, 2>; break;
-		}
-	} else {
-		switch (c.nb) {
-		case 1: k = walk_direct<Pol, 1, 1>; break;
-		case 2: k = walk_direct<Pol, 2, 1>; break;
-		case 4: k = walk_direct<Pol, 4, 1>; break;
-		default: k = walk_direct<Pol, 8, 1>; break;
-		}
-	}
-	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
-	return hipGetLastError();
-}
-
-/* eager-output walks: the policy wrapped in EagerPol, two kernels only (per-lane loads with four
- * chunks in flight, or the generic one) */
-template <class EP>
-static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
-{
-	void (*k)(const WalkArgs) = nullptr;
-	if (c.mode == IN_GENERIC && c.queue) return launch_queue<EP>(c, a, c.counter, grid, block, s);
-	if (c.mode == IN_GENERIC) k = walk_generic<EP>;
-	else if (c.mode == IN_LDSDMA) k = c.nt ? walk_ldsdma<EP, 128, 2> : walk_ldsdma<EP, 128, 0>;
-	else k = walk_direct<EP, 4, 1>;
-	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
-	return hipGetLastError();
-}
-
-template <class Pol>
-static hipError_t launch_eager(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
-{
-	/* up to 64 ids: the set rides in a register pair; more: it lives in device memory */
-	return a.eager_words > 1 ? launch_eager_pol<EagerWidePol<Pol>>(c, a, grid, block, s)
-	                         : launch_eager_pol<EagerPol<Pol>>(c, a, grid, block, s);
-}
-
-template <template <bool> class PolT>
-static hipError_t launch_masked(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
-{
-	return c.mask ? launch_pol<PolT<true>>(c, a, grid, block, s) : launch_pol<PolT<false>>(c, a, grid, block, s);
-}
-
 static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s)
 {
 	if (a.n == 0) return 0;
-	const bool eager = a.eager_out != nullptr;
-	if (eager && (a.stride / 16u) % 4u != 0) fast_ok = false;
-	LaunchCfg c = pick_cfg(d, fast_ok, a.stride);
-	if (eager && c.mode == IN_DIRECT) {
-		/* the per-lane-load eager kernel is instantiated for NB = 4 only */
-		c.nb = 4; c.rows = 1;
-	}
-	if (eager && c.mode == IN_LDSDMA && (c.seg != 128 || a.eager_words > 1)) {
-		/* LDS-DMA eager kernels: 128-byte segments, register-held sets only (2.3 vs 1.1 TB/s for those;
-		 * wide sets measured 1.8 behind LDS-DMA vs 2.1 with per-lane loads: tests/tools/eager_probe.py) */
-		c.mode = IN_DIRECT; c.nb = 4; c.rows = 1;
-		c.waves = d->knob_waves > 0 && d->knob_waves <= 16 ? d->knob_waves : 16;
-		c.lds = d->table_lds;
-	}
-	const uint64_t ntiles = (a.n + 64u * c.rows - 1) / (64u * c.rows);
+	const int eager = a.eager_out == nullptr ? 0 : a.eager_words > 1 ? 2 : 1;
+	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager);
+	const uint64_t ntiles = (a.n + 63u) / 64u;
 	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
-	hipError_t e = hipEventRecord(md->ev0, s);
+	DfaLock lk(md->mu);   /* the timing events are per dfa */
+	hipError_t e = hipSuccess;
+	/* the ragged kernel sets bitmap bits one input at a time */
+	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
+	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
 	if (e == hipSuccess) {
-		dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
-		if (eager) {
-			switch (d->plan.layout) {
-			case FSM_HIP_LAYOUT_TINY:
-				e = !d->plan.tiny5_col.empty() ? launch_eager<Tiny5Pol>(c, a, grid, block, s)
-				                    : launch_eager<TinyPol<uint64_t>>(c, a, grid, block, s);
-				break;
-			case FSM_HIP_LAYOUT_LDS: e = launch_eager<LdsPol<false>>(c, a, grid, block, s); break;
-			case FSM_HIP_LAYOUT_LDSSELF: e = launch_eager<LdsSelfPol>(c, a, grid, block, s); break;
-			default:                 e = launch_eager<GlobPol<false>>(c, a, grid, block, s); break;
-			}
-		} else
-		switch (d->plan.layout) {
-		case FSM_HIP_LAYOUT_TINY:
-			e = !d->plan.tiny5_col.empty() ? launch_pol<Tiny5Pol>(c, a, grid, block, s)
-			                    : launch_pol<TinyPol<uint64_t>>(c, a, grid, block, s);
-			break;
-		case FSM_HIP_LAYOUT_LDS:     e = launch_masked<LdsPol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMB:    e = launch_masked<CombPol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMB256: e = launch_masked<Comb256Pol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMBSELF: e = launch_pol<CombSelfPol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_SPARSE:  e = launch_pol<SparsePol>(c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_LDSSELF: e = launch_pol<LdsSelfPol>(c, a, grid, block, s); break;
-		default:                     e = launch_masked<GlobPol>(c, a, grid, block, s); break;
+		const dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
+		const Plan &p = d->plan;
+		switch (p.layout) {
+		case FSM_HIP_LAYOUT_TINY:     e = launch_tiny(p.tiny5_col.empty() ? POL_TINY64 : POL_TINY5, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_LDS:      e = launch_lds(POL_LDS, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_LDSSELF:  e = launch_lds(POL_LDSSELF, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMB:     e = launch_comb(POL_COMB, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMB256:  e = launch_comb(POL_COMB256, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_COMBSELF: e = launch_comb(POL_COMBSELF, eager, c, a, grid, block, s); break;
+		case FSM_HIP_LAYOUT_SPARSE:   e = launch_glob(POL_SPARSE, eager, c, a, grid, block, s); break;
+		default:                      e = launch_glob(POL_GLOB, eager, c, a, grid, block, s); break;
 		}
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
@@ -573,7 +526,8 @@ extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
 {
 	if (d == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = stride;
@@ -592,7 +546,8 @@ extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
 {
 	if (d == nullptr || (n != 0 && d_off == nullptr)) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = 0;
@@ -606,7 +561,9 @@ extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
 
 extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
 {
-	if (d == nullptr || !d->timed) return -1.0;
+	if (d == nullptr) return -1.0;
+	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
+	if (!d->timed) return -1.0;
 	float ms = 0.f;
 	if (hipEventSynchronize(d->ev1) != hipSuccess) return -1.0;
 	if (hipEventElapsedTime(&ms, d->ev0, d->ev1) != hipSuccess) return -1.0;
@@ -633,13 +590,14 @@ struct HostCall {
 	enum Kind { IN = 0, INOUT = 1, OUT = 2 };
 	struct Part { const void *src; void *dst; size_t bytes, pad, off; int kind; };
 	fsm_hip_dfa *d;
+	DfaLock lk;       /* arena and staging buffer are shared by the calls on one dfa */
 	Part parts[8];
 	int np = 0;
 	unsigned char *arena = nullptr;
 	bool temp = false, small = false;
 	size_t h2d_end = 0, d2h_begin = 0, total = 0;
 
-	explicit HostCall(const fsm_hip_dfa *cd) : d(const_cast<fsm_hip_dfa *>(cd)) {}
+	explicit HostCall(const fsm_hip_dfa *cd) : d(const_cast<fsm_hip_dfa *>(cd)), lk(d->mu) {}
 	~HostCall() { if (temp && arena) { int e = errno; (void)hipFree(arena); errno = e; } }
 	/* declare the arrays in the order IN..., INOUT..., OUT...; returns the part's index (or -1 for a NULL array) */
 	int add(int kind, const void *src, void *dst, size_t bytes, size_t pad = 0)
@@ -684,11 +642,11 @@ struct HostCall {
 		if (small) {
 			for (int i = 0; i < np; i++)
 				if (parts[i].kind != OUT && parts[i].bytes) memcpy(d->stage + parts[i].off, parts[i].src, parts[i].bytes);
-			if (h2d_end) HIP_TRY(hipMemcpyAsync(arena, d->stage, h2d_end, hipMemcpyHostToDevice, nullptr));
+			if (h2d_end) HIP_TRY(hipMemcpyAsync(arena, d->stage, h2d_end, hipMemcpyHostToDevice, d->hs));
 		} else {
 			for (int i = 0; i < np; i++)
 				if (parts[i].kind != OUT && parts[i].bytes)
-					HIP_TRY(hipMemcpy(arena + parts[i].off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice));
+					HIP_TRY(hipMemcpyAsync(arena + parts[i].off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, d->hs));
 		}
 		return 0;
 	fail:
@@ -698,15 +656,15 @@ struct HostCall {
 	int end()
 	{
 		if (small) {
-			if (total > d2h_begin) HIP_TRY(hipMemcpyAsync(d->stage + d2h_begin, arena + d2h_begin, total - d2h_begin, hipMemcpyDeviceToHost, nullptr));
-			HIP_TRY(hipStreamSynchronize(nullptr));
+			if (total > d2h_begin) HIP_TRY(hipMemcpyAsync(d->stage + d2h_begin, arena + d2h_begin, total - d2h_begin, hipMemcpyDeviceToHost, d->hs));
+			HIP_TRY(hipStreamSynchronize(d->hs));
 			for (int i = 0; i < np; i++)
 				if (parts[i].kind != IN && parts[i].bytes) memcpy(parts[i].dst, d->stage + parts[i].off, parts[i].bytes);
 		} else {
-			HIP_TRY(hipStreamSynchronize(nullptr));
 			for (int i = 0; i < np; i++)
 				if (parts[i].kind != IN && parts[i].bytes)
-					HIP_TRY(hipMemcpy(parts[i].dst, arena + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpyAsync(parts[i].dst, arena + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost, d->hs));
+			HIP_TRY(hipStreamSynchronize(d->hs));
 		}
 		return 0;
 	fail:
@@ -721,7 +679,8 @@ static int exec_host(const struct fsm_hip_dfa *d,
 {
 	if (d == nullptr) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HostCall hc(d);
 	/* +32: the generic kernel reads whole aligned 16-byte chunks */
 	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
@@ -732,10 +691,10 @@ static int exec_host(const struct fsm_hip_dfa *d,
 	if (hc.begin() != 0) return -1;
 	if (off) {
 		if (fsm_hip_exec_batch_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
-		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), nullptr) != 0) return -1;
+		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;
 	} else {
 		if (fsm_hip_exec_batch_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-		                              hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), nullptr) != 0) return -1;
+		                              hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;
 	}
 	return hc.end();
 }
@@ -777,7 +736,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	out->layout = p.layout;
 	out->nabsorbing = p.nabsorbing;
 	switch (p.layout) {
-	case FSM_HIP_LAYOUT_TINY: out->table_bytes = 256 * 8; break;
+	case FSM_HIP_LAYOUT_TINY: out->table_bytes = p.tiny5_col.empty() ? 256 * 8 : 256 * 4; break;
 	case FSM_HIP_LAYOUT_LDS:
 	case FSM_HIP_LAYOUT_LDSSELF: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
@@ -786,7 +745,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_SPARSE: out->table_bytes = p.sparse_img.size() * 4; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
-	LaunchCfg c = pick_cfg(d, true, 1024);
+	LaunchCfg c = pick_cfg(d, true, 1024, 0);
 	out->lds_bytes = c.lds;
 	out->waves_per_block = (uint32_t)c.waves;
 	out->device = (uint32_t)d->device;
@@ -799,12 +758,11 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
-	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;
-	case FSM_HIP_KNOB_MASK: d->knob_mask = value; break;
+	case FSM_HIP_KNOB_ROWS: break;   /* retired: two inputs per lane never helped (profiles/r01_sweep2*) */
+	case FSM_HIP_KNOB_MASK: break;   /* retired: exec-masking absorbing lanes cost more than it saved */
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;
 	case FSM_HIP_KNOB_NT: d->knob_nt = value; break;
-	case FSM_HIP_KNOB_QUEUE: d->knob_queue = value; break;
 	case FSM_HIP_KNOB_HOT_BYTES:
 		if (d->plan.layout != FSM_HIP_LAYOUT_GLOBAL || value < 0) { errno = EINVAL; return -1; }
 		set_hot_bytes(d, (uint32_t)value);
@@ -854,14 +812,16 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 {
 	if (pl == nullptr || data == nullptr || count == nullptr) { errno = EINVAL; return -1; }
 	const Plan &p = pl->p;
-	static thread_local uint32_t scalars[16];
+	static thread_local uint32_t scalars[20];
 	switch (what) {
 	case FSM_HIP_PLAN_SCALARS:
 		scalars[0] = p.nstates; scalars[1] = p.S1; scalars[2] = p.start; scalars[3] = p.C;
 		scalars[4] = p.abs_min; scalars[5] = p.nabsorbing; scalars[6] = p.layout; scalars[7] = p.row_bytes;
 		scalars[8] = p.comb_abs_min_off; scalars[9] = p.comb256_abs_min_off; scalars[10] = p.comb256_dflt;
 		scalars[11] = p.eager_lo_end; scalars[12] = p.eager_hi_begin;
-		*data = scalars; *count = 13; return 0;
+		scalars[13] = p.comb_eager_lo_off; scalars[14] = p.comb_eager_hi_off;
+		scalars[15] = p.comb256_eager_lo_off; scalars[16] = p.comb256_eager_hi_off;
+		*data = scalars; *count = 17; return 0;
 	case FSM_HIP_PLAN_CLS: *data = p.cls; *count = 256; return 0;
 	case FSM_HIP_PLAN_NEW2OLD: *data = p.new2old.data(); *count = p.new2old.size(); return 0;
 	case FSM_HIP_PLAN_FIN: *data = p.fin.data(); *count = p.fin.size(); return 0;
@@ -1101,10 +1061,11 @@ fail:
 /* Build, once, the per-encoded-state tables the kernel copies into id_out[]:
  *   earliest: lowest end-id of the state (AMBIG_EARLIEST, src/libfsm/print/c.c:67-85)
  *   ret:      index of the state's id set in the de-duplicated list of sets, ordered by
- *             count, then lexicographically -- the order build_retlist() produces
+ *             count, then memcmp of the id arrays -- the order build_retlist() produces
  *             (src/libfsm/vm/retlist.c:93-138, cmp_ret). */
 static int ensure_ids(fsm_hip_dfa *d)
 {
+	DfaLock lk(d->mu);
 	if (d->ids_ready) return 0;
 	const Plan &p = d->plan;
 	typedef std::vector<uint32_t> Set;
@@ -1114,9 +1075,11 @@ static int ensure_ids(fsm_hip_dfa *d)
 	for (uint32_t v : p.fin) if (v != FSM_HIP_NO_MATCH) is_end[v] = 1;
 	for (uint32_t s = 0; s < p.nstates; s++)
 		if (is_end[s]) sets.emplace_back(p.endids.begin() + p.endid_off[s], p.endids.begin() + p.endid_off[s + 1]);
+	/* cmp_ret (src/libfsm/vm/retlist.c:63-79): by count, then memcmp over the raw id array -- byte-wise,
+	 * i.e. NOT numeric for ids >= 256 on a little-endian host ({256} sorts before {1}) */
 	std::sort(sets.begin(), sets.end(), [](const Set &a, const Set &b) {
 		if (a.size() != b.size()) return a.size() < b.size();
-		return a < b;
+		return !a.empty() && memcmp(a.data(), b.data(), a.size() * sizeof(uint32_t)) < 0;
 	});
 	sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
 	std::map<Set, uint32_t> index;
@@ -1133,9 +1096,11 @@ static int ensure_ids(fsm_hip_dfa *d)
 		if (s == FSM_HIP_NO_MATCH) continue;
 		const uint32_t a = p.endid_off[s], b = p.endid_off[s + 1];
 		fe[i] = b > a ? p.endids[a] : FSM_HIP_NO_ID;
+		if (b - a > 1 && s < d->ids_conflict) d->ids_conflict = s;
 		fr[i] = index[Set(p.endids.begin() + a, p.endids.begin() + b)];
 	}
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HIP_TRY(upload(&d->d_fin_earliest, fe));
 	HIP_TRY(upload(&d->d_fin_ret, fr));
 	d->ids_ready = true;
@@ -1149,10 +1114,17 @@ extern "C" int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dc,
 	int mode, uint32_t *d_id_out, void *hip_stream)
 {
 	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
-	if (d == nullptr || d_id_out == nullptr || (mode != FSM_HIP_IDS_EARLIEST && mode != FSM_HIP_IDS_RET) ||
+	if (d == nullptr || d_id_out == nullptr || (mode != FSM_HIP_IDS_EARLIEST && mode != FSM_HIP_IDS_RET && mode != FSM_HIP_IDS_ERROR) ||
 	    (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	if (ensure_ids(d) != 0) return -1;
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	if (mode == FSM_HIP_IDS_ERROR) {
+		/* AMBIG_ERROR: an end state with more than one id is refused (print/c.c:67-72 fails the
+		 * print with EINVAL); without such a state it is AMBIG_EARLIEST */
+		if (d->ids_conflict != FSM_HIP_NO_MATCH) { errno = EINVAL; return -1; }
+		mode = FSM_HIP_IDS_EARLIEST;
+	}
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = stride;
@@ -1174,15 +1146,26 @@ extern "C" int fsm_hip_exec_batch_ids(const struct fsm_hip_dfa *d,
 	if (len != nullptr)
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HostCall hc(d);
 	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
 	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
 	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (fsm_hip_exec_batch_ids_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n, mode,
-	                                  hc.dev<uint32_t>(p_out), nullptr) != 0) return -1;
+	                                  hc.dev<uint32_t>(p_out), hc.d->hs) != 0) return -1;
 	return hc.end();
+}
+
+extern "C" int fsm_hip_ids_conflict(const struct fsm_hip_dfa *dc, fsm_state_t *state)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (ensure_ids(d) != 0) return -1;
+	if (d->ids_conflict == FSM_HIP_NO_MATCH) return 0;
+	if (state != nullptr) *state = d->ids_conflict;
+	return 1;
 }
 
 extern "C" size_t fsm_hip_ret_count(const struct fsm_hip_dfa *dc)
@@ -1210,6 +1193,7 @@ extern "C" int fsm_hip_ret_get(const struct fsm_hip_dfa *dc, uint32_t ret_index,
 
 static int ensure_resume(fsm_hip_dfa *d)
 {
+	DfaLock lk(d->mu);
 	if (d->resume_ready) return 0;
 	const Plan &p = d->plan;
 	/* caller id (+ nstates = DEAD) -> encoded state */
@@ -1218,13 +1202,23 @@ static int ensure_resume(fsm_hip_dfa *d)
 	/* encoded index (as used for fin) -> caller id, DEAD marker for the synthetic state */
 	std::vector<uint32_t> orig(d->fin_host.size(), FSMHIP_STATE_DEAD);
 	for (uint32_t n2 = 0; n2 + 1 < p.S1; n2++) orig[d->enc_host[n2] / d->proto.fin_div] = p.new2old[n2];
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HIP_TRY(upload(&d->d_enc_of, enc));
 	HIP_TRY(upload(&d->d_orig_of, orig));
 	d->resume_ready = true;
 	return 0;
 fail:
 	return -1;
+}
+
+extern "C" int fsm_hip_state_is_absorbing(const struct fsm_hip_dfa *d, uint32_t state)
+{
+	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (state == FSMHIP_STATE_DEAD) return 1;
+	if (state == FSMHIP_STATE_START) state = d->plan.new2old[d->plan.start];
+	if (state >= d->plan.nstates) { errno = EINVAL; return -1; }
+	return d->plan.old2new[state] >= d->plan.abs_min ? 1 : 0;
 }
 
 extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
@@ -1234,7 +1228,8 @@ extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
 	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
 	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	if (ensure_resume(d) != 0) return -1;
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = stride;
@@ -1260,7 +1255,8 @@ extern "C" int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *d,
 	if (len != nullptr)
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HostCall hc(d);
 	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
 	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
@@ -1268,7 +1264,7 @@ extern "C" int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *d,
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (fsm_hip_exec_batch_resume_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-	                                     hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, nullptr) != 0) return -1;
+	                                     hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs) != 0) return -1;
 	return hc.end();
 }
 
@@ -1297,7 +1293,8 @@ extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
 	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream)
 {
 	if (d == nullptr || d_eager_out == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	if (d->plan.emask.empty()) {
 		/* no state emits anything: the answer is all zeros, the walk is the plain one */
 		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
@@ -1330,7 +1327,8 @@ extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 	if (len != nullptr)
 		for (size_t i = 0; i < n; i++)
 			if (len[i] > stride) { errno = EINVAL; return -1; }
-	if (hipSetDevice(d->device) != hipSuccess) { errno = ENODEV; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
 	HostCall hc(d);
 	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
 	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
@@ -1338,6 +1336,6 @@ extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
 	if (fsm_hip_exec_batch_eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-	                                    hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), nullptr) != 0) return -1;
+	                                    hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs) != 0) return -1;
 	return hc.end();
 }

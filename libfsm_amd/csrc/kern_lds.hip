@@ -1,0 +1,12 @@
+/* kern_lds.hip -- walk kernels of the dense LDS-table policies; see launch.h */
+#include "launch.h"
+
+namespace fsmhip {
+
+hipError_t launch_lds(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	if (pol == POL_LDSSELF) return launch_family<LdsSelfPol>(eager, c, a, grid, block, s);
+	return launch_family<LdsPol>(eager, c, a, grid, block, s);
+}
+
+} // namespace fsmhip

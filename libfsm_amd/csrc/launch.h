@@ -1,0 +1,96 @@
+/*
+ * launch.h -- kernel selection shared by the per-policy translation units.
+ *
+ * The walk kernels are templates over the table policy; instantiating every (policy, kernel) pair in
+ * one translation unit made the build serial (two minutes).  Each kern_*.hip instantiates the kernels
+ * of one policy family through launch_family<>() below and exports one plain function; build.sh
+ * compiles the units in parallel.  fsm_hip.hip holds the host side only.
+ */
+#ifndef FSM_HIP_LAUNCH_H
+#define FSM_HIP_LAUNCH_H
+
+#include "walk_kernels.h"
+
+namespace fsmhip {
+
+struct LaunchCfg {
+	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED */
+	int nb;              /* direct: 16-byte chunks in flight per lane (4 or 8) */
+	int waves, blocks_per_cu;
+	int seg;             /* LDS-DMA: 64 or 128 */
+	int prefetch;        /* direct: register double-buffer (0: <= 64 VGPRs, occupancy instead) */
+	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
+	uint32_t lds;        /* dynamic LDS bytes per workgroup */
+};
+
+/* which policy of a family */
+enum {
+	POL_TINY5 = 0, POL_TINY64 = 1,
+	POL_LDS = 0, POL_LDSSELF = 1,
+	POL_COMB = 0, POL_COMB256 = 1, POL_COMBSELF = 2,
+	POL_GLOB = 0, POL_SPARSE = 1
+};
+/* eager: 0 = plain walk, 1 = EagerPol (<= 64 ids, set in registers), 2 = EagerWidePol */
+hipError_t launch_tiny(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
+hipError_t launch_lds(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
+hipError_t launch_comb(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
+hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
+
+typedef void (*walk_fn)(const WalkArgs);
+
+static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
+	return hipGetLastError();
+}
+
+/* plain walk: every input path */
+template <class Pol>
+static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	walk_fn k = nullptr;
+	switch (c.mode) {
+	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
+	case IN_GENERIC: k = walk_generic<Pol>; break;
+	case IN_LDSDMA:
+		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2> : walk_ldsdma<Pol, 128, 0>;
+		else k = walk_ldsdma<Pol, 64, 0>;
+		break;
+	default:
+		if (!c.prefetch && c.nb == 4) k = walk_direct_np<Pol, 4>;
+		else k = c.nb == 4 ? walk_direct<Pol, 4, 1> : walk_direct<Pol, 8, 1>;
+		break;
+	}
+	return launch_fn(k, c, a, grid, block, s);
+}
+
+/* eager-output walks: the policy wrapped; the register-set form also behind LDS-DMA (128-byte
+ * segments, 12 waves at most so that the set and the tile fit the register file without spills) */
+template <class EP, bool DMA>
+static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	walk_fn k = nullptr;
+	switch (c.mode) {
+	case IN_RAGGED:  k = walk_ragged<EP, 512>; break;
+	case IN_GENERIC: k = walk_generic<EP, 512>; break;
+	case IN_LDSDMA:
+		if (DMA) { k = walk_ldsdma<EP, 128, 2, 768>; break; }
+		/* fallthrough */
+	default: k = walk_direct<EP, 4, 1>; break;
+	}
+	return launch_fn(k, c, a, grid, block, s);
+}
+
+template <class Pol>
+static hipError_t launch_family(int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	if (eager == 0) return launch_pol<Pol>(c, a, grid, block, s);
+	if (eager == 1) return launch_eager_pol<EagerPol<Pol>, true>(c, a, grid, block, s);
+	return launch_eager_pol<EagerWidePol<Pol>, false>(c, a, grid, block, s);
+}
+
+} // namespace fsmhip
+
+#endif

@@ -268,7 +268,6 @@ try {
 		return 0;
 	};
 	auto emit_comb = [&]() -> int {
-		if (has_eager) return ENOTSUP; /* comb offsets do not keep the eager ordering */
 		uint32_t max_entries = lds_room > 1024u ? (uint32_t)std::min<uint64_t>((lds_room - 1024u) / 4u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
@@ -276,7 +275,7 @@ try {
 		return 0;
 	};
 	auto emit_combself = [&]() -> int {
-		if (C > 32 || has_eager) return ENOTSUP;
+		if (C > 32) return ENOTSUP;
 		/* LDS image = 8 bytes per comb entry (entry + mask of its target) + 256 */
 		uint32_t max_entries = lds_room > 256u ? (uint32_t)std::min<uint64_t>((lds_room - 256u) / 8u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
@@ -328,7 +327,6 @@ try {
 	};
 	auto emit_comb256 = [&]() -> int {
 		/* no byte->class table in LDS for this layout */
-		if (has_eager) return ENOTSUP;
 		uint32_t max_entries = (uint32_t)std::min<uint64_t>((lds_room + lds_bytes_btab()) / 4u, 65535u);
 		int r = build_comb(p, max_entries, true);
 		if (r) return r;
@@ -344,8 +342,7 @@ try {
 	};
 
 	auto emit_sparse = [&]() -> int {
-		if (has_eager) return ENOTSUP;
-		return build_sparse(p, lds_limit);
+		return build_sparse(p, lds_limit);   /* states keep their renumbered ids: eager ranges hold as they are */
 	};
 
 	switch (want) {
@@ -400,7 +397,7 @@ try {
  * state's) on more than half the classes stays dense, so the form is never much larger than the
  * table and the result is the same for any choice.
  *
- * Records are 16 bytes {bits lo, bits hi, base | DENSE, offset}; those of the states nearest the
+ * Records are 16 bytes {bits lo, bits hi, base | DENSE | CONSEC, offset}; those of the states nearest the
  * start state, and the dense rows among them, are mirrored in LDS (breadth-first numbering puts
  * the states a walk visits most first), the rest stays in HBM/L2.
  *
@@ -483,9 +480,30 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		}
 	}
 
+	/* CONSEC records: the targets of the exceptions are consecutive state ids in class (= bit) order.
+	 * Breadth-first numbering hands the children of a trie node consecutive ids, so on an Aho-Corasick
+	 * DFA every record with at least one exception qualifies: the walk then computes the next state as
+	 * first + rank(bit) and the exception list -- one dependent gather per hit -- is not stored at all. */
+	const uint32_t CONSEC = 0x40000000u;
+	if (N >= CONSEC) return ENOTSUP;
+	std::vector<uint8_t> consec(N, 0);
+	for (uint32_t n = 0; n < N; n++) {
+		if (base[n] == NONE || nexc[n] == 0) continue;
+		const uint32_t *ra = row(n), *rb = row(base[n]);
+		uint32_t first = NONE, k = 0;
+		bool ok = true;
+		for (uint32_t c = 0; c < C && ok; c++) {
+			if (ra[c] == rb[c]) continue;
+			if (first == NONE) first = ra[c];
+			ok = ra[c] == first + k;
+			k++;
+		}
+		consec[n] = ok;
+	}
+
 	/* sizes; which states live in LDS */
 	uint64_t ndense = 0, ntot_exc = 0;
-	for (uint32_t n = 0; n < N; n++) { if (base[n] == NONE) ndense++; else ntot_exc += nexc[n]; }
+	for (uint32_t n = 0; n < N; n++) { if (base[n] == NONE) ndense++; else if (!consec[n]) ntot_exc += nexc[n]; }
 	const uint64_t words = 16u + 128u + (uint64_t)N * 4u + ndense * C + ntot_exc;
 	if (words * 4u + 160u * 1024u >= 0xFFFFFFFFull) return ENOTSUP;
 	/* half the LDS, so that two 16-wave workgroups share a CU: the walk waits on gathers, and 32
@@ -514,7 +532,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		uint16_t *pm = reinterpret_cast<uint16_t *>(&img[16]);
 		for (unsigned b = 0; b < 256; b++) pm[b] = (uint16_t)(p.cls[b] | (bit_of[p.cls[b]] << 8));
 	}
-	uint32_t drow = 0, eoff = 0, maxchain = 0;
+	uint32_t drow = 0, eoff = 0, maxchain = 0, nconsec = 0;
 	for (uint32_t n = 0; n < N; n++) {
 		uint32_t *r = &img[grec_w + (size_t)n * 4u];
 		if (base[n] == NONE) {
@@ -528,12 +546,18 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 			uint64_t bits = 0;
 			const uint32_t *ra = row(n), *rb = row(base[n]);
 			r[3] = eoff;
+			bool first = true;
 			for (uint32_t c = 0; c < C; c++) {          /* bit order = class order (bit_of is monotone) */
-				if (ra[c] != rb[c]) { bits |= (uint64_t)1 << bit_of[c]; img[exc_w + eoff++] = ra[c]; }
+				if (ra[c] == rb[c]) continue;
+				bits |= (uint64_t)1 << bit_of[c];
+				if (!consec[n]) img[exc_w + eoff++] = ra[c];
+				else if (first) r[3] = ra[c];           /* the k-th exception goes to r[3] + k */
+				first = false;
 			}
 			r[0] = (uint32_t)bits;
 			r[1] = (uint32_t)(bits >> 32);
-			r[2] = base[n];
+			r[2] = base[n] | (consec[n] ? CONSEC : 0u);
+			nconsec += consec[n];
 			if (chain[n] > maxchain) maxchain = chain[n];
 		}
 		if (n < H) memcpy(&img[lds_rec_w + (size_t)n * 4u], r, 16);
@@ -551,6 +575,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	img[10] = (uint32_t)ndense;
 	img[11] = (uint32_t)ntot_exc;
 	img[12] = maxchain;
+	img[13] = nconsec;
 	p.sparse_lds_bytes = lds_words * 4u;
 	p.layout = FSM_HIP_LAYOUT_SPARSE;
 	return 0;
@@ -604,13 +629,17 @@ static int build_comb(Plan &p, uint32_t max_entries, bool bytewise)
 	}
 	if (total + W > max_entries || S1 > max_entries) return ENOTSUP;
 
-	/* place non-absorbing states densest first, then absorbing ones above */
+	/* place non-absorbing states densest first -- those with eager outputs (renumbered ids below
+	 * eager_lo_end) as a block of their own below the others --, then absorbing ones above, in index
+	 * order (eager absorbing states just below DEAD, as in the renumbering) */
+	const uint32_t lo_end = p.emask.empty() ? 0u : p.eager_lo_end;
+	auto region = [&](uint32_t n) { return n >= p.abs_min ? 2 : n < lo_end ? 0 : 1; };
 	std::vector<uint32_t> order(S1);
 	for (uint32_t n = 0; n < S1; n++) order[n] = n;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-		bool aa = a >= p.abs_min, ab = b >= p.abs_min;
-		if (aa != ab) return ab;              /* non-absorbing first */
-		if (aa) return a < b;                 /* absorbing: keep order, DEAD last */
+		const int ra = region(a), rb = region(b);
+		if (ra != rb) return ra < rb;
+		if (ra == 2) return a < b;            /* absorbing: keep order, DEAD last */
 		return nexc[a] > nexc[b];
 	});
 
@@ -629,16 +658,22 @@ static int build_comb(Plan &p, uint32_t max_entries, bool bytewise)
 	off.assign(S1, 0);
 	uint32_t hi = 0;         /* 1 + highest offset handed out so far */
 	uint32_t first_free = 0; /* lowest offset not yet handed out */
-	uint32_t abs_min_off = 0;
-	bool in_abs = false;
+	uint32_t abs_min_off = 0, eager_lo_off = 0, eager_hi_off = 0xFFFFFFFFu, floor = 0;
+	bool in_abs = false, in_plain = false;
 	for (uint32_t idx = 0; idx < S1; idx++) {
 		uint32_t n = order[idx];
+		if (!in_plain && !in_abs && region(n) == 1) {
+			in_plain = true;
+			eager_lo_off = floor = hi; /* rows without eager outputs sit above every row that has them */
+		}
 		if (!in_abs && n >= p.abs_min) {
 			in_abs = true;
 			abs_min_off = hi; /* absorbing states get offsets >= every other state's */
+			if (!in_plain) eager_lo_off = hi;
 		}
+		if (!p.emask.empty() && n == p.eager_hi_begin) eager_hi_off = hi;
 		/* absorbing offsets keep increasing so one compare identifies them */
-		uint32_t o = in_abs ? hi : first_free;
+		uint32_t o = in_abs ? hi : (first_free > floor ? first_free : floor);
 		for (;; o++) {
 			if (o + W > max_entries) return ENOTSUP;
 			if (off_used[o]) continue;
@@ -668,6 +703,9 @@ static int build_comb(Plan &p, uint32_t max_entries, bool bytewise)
 			if (t != dflt[w]) comb[o + w] = (o << 16) | off[t];
 		}
 	}
+	if (p.emask.empty()) { eager_lo_off = 0; eager_hi_off = 0xFFFFFFFFu; }
+	(bytewise ? p.comb256_eager_lo_off : p.comb_eager_lo_off) = eager_lo_off;
+	(bytewise ? p.comb256_eager_hi_off : p.comb_eager_hi_off) = eager_hi_off;
 	if (bytewise) {
 		p.comb256_dflt = off[dflt[0]];
 		p.comb256_abs_min_off = abs_min_off;

@@ -66,6 +66,11 @@ struct Plan {
 	std::vector<uint32_t> comb_off;       /* [S1] row offset of each renumbered state */
 	std::vector<uint32_t> comb_fin;       /* [comb.size()] fin by row offset (NO_MATCH elsewhere) */
 	uint32_t comb_abs_min_off = 0;        /* row offsets >= this are absorbing */
+	/* eager outputs in the comb layouts: rows are placed region by region (emitting non-absorbing,
+	 * other non-absorbing, absorbing in index order), so the same two thresholds work on row offsets:
+	 * a state emits iff off < eager_lo_off || off >= eager_hi_off */
+	uint32_t comb_eager_lo_off = 0, comb_eager_hi_off = 0xFFFFFFFFu;
+	uint32_t comb256_eager_lo_off = 0, comb256_eager_hi_off = 0xFFFFFFFFu;
 	/* COMBSELF: comb + per-row-offset self-loop masks (bit c: class c loops to the same state;
 	 * absorbing states: all ones).  Device image = comb[] followed by comb_smask[].   */
 	std::vector<uint32_t> comb_smask;

@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,18 +45,16 @@ struct api {
 };
 
 static struct api A;
+static pthread_once_t api_once = PTHREAD_ONCE_INIT;
 
-static int
-resolve(void)
+static void
+resolve_once(void)
 {
-	if (A.resolved) {
-		return A.resolved > 0;
-	}
 #define SYM(field, name) do { \
 		*(void **)(&A.field) = dlsym(RTLD_DEFAULT, name); \
-		if (A.field == NULL) { A.resolved = -1; } \
+		if (A.field == NULL) { ok = 0; } \
 	} while (0)
-	A.resolved = 1;
+	int ok = 1;
 	SYM(countstates, "fsm_countstates");
 	SYM(getstart, "fsm_getstart");
 	SYM(isend, "fsm_isend");
@@ -68,6 +67,14 @@ resolve(void)
 	SYM(eager_output_count, "fsm_eager_output_count");
 	SYM(eager_output_get, "fsm_eager_output_get");
 #undef SYM
+	A.resolved = ok ? 1 : -1;
+}
+
+/* first use from any thread resolves the table exactly once */
+static int
+resolve(void)
+{
+	(void) pthread_once(&api_once, resolve_once);
 	return A.resolved > 0;
 }
 
@@ -143,8 +150,9 @@ fsm_hip_flatten(const struct fsm *fsm)
 		errno = EINVAL;
 		return NULL;
 	}
-	/* captures and eager outputs are per-byte host side channels
-	 * (exec.c:41-44, :126-144): not representable in a table walk */
+	/* captures are per-byte host callbacks with positions (exec.c:41-44): not
+	 * representable in a table walk.  Eager outputs (exec.c:126-144) are carried:
+	 * flattened below, delivered by fsm_hip_exec_batch_eager*(). */
 	if (A.countcaptures(fsm) > 0) {
 		errno = ENOTSUP;
 		return NULL;
@@ -358,37 +366,52 @@ fsm_hip_exec(const struct fsm_hip_dfa *dfa,
 	return 1;
 }
 
+/*
+ * fsm_vm_match_file() keeps a struct vm_state across 4 KiB fread()s and stops reading as soon as
+ * the VM has decided (src/libfsm/vm.c:188-216).  Same shape here on the streaming front: the state
+ * is carried through fsm_hip_exec_batch_resume() chunk by chunk (64 KiB: one launch per chunk), and
+ * reading stops once the state can no longer change -- DEAD (a missing edge, the VM's STOP fail) or
+ * an absorbing state (the VM's STOP success shortcut, vm/ir.c:763-766).  A read error gives 0, as
+ * the reference's ferror() check does.  Memory use is one chunk, whatever the file size.
+ */
 int
 fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f)
 {
-	unsigned char *buf = NULL, *t;
-	size_t n = 0, cap = 0, got;
-	int r;
+	enum { CHUNK = 65536 };
+	unsigned char *buf;
+	uint32_t st = FSM_HIP_STATE_START, end = FSM_HIP_NO_MATCH;
+	size_t got;
+	int first = 1;
 
 	if (dfa == NULL || f == NULL) {
 		errno = EINVAL;
 		return -1;
 	}
+	buf = malloc(CHUNK);
+	if (buf == NULL) {
+		errno = ENOMEM;
+		return -1;
+	}
 	for (;;) {
-		if (cap - n < 4096) {
-			cap = cap ? cap * 2 : 65536;
-			t = realloc(buf, cap);
-			if (t == NULL) {
-				free(buf);
-				errno = ENOMEM;
-				return -1;
-			}
-			buf = t;
+		got = fread(buf, 1, CHUNK, f);
+		if (got == 0 && !first) {
+			break;
 		}
-		got = fread(buf + n, 1, cap - n, f);
-		n += got;
-		if (got == 0) {
+		first = 0;
+		/* an empty file still needs one call: it accepts iff the start state is an end state */
+		if (fsm_hip_exec_batch_resume(dfa, buf, CHUNK, (uint32_t[]){ (uint32_t) got }, 1, &st, &end) != 0) {
+			free(buf);
+			return -1;
+		}
+		if (got < CHUNK || st == FSM_HIP_STATE_DEAD || fsm_hip_state_is_absorbing(dfa, st) == 1) {
 			break;
 		}
 	}
-	r = fsm_hip_match_buffer(dfa, (const char *) buf, n);
 	free(buf);
-	return r;
+	if (ferror(f)) {
+		return 0;
+	}
+	return end != FSM_HIP_NO_MATCH;
 }
 
 /* ---- on-disk form of a flat DFA description -------------------------- */
@@ -459,19 +482,63 @@ fsm_hip_desc_write(const struct fsm_hip_dfa_desc *d, FILE *f)
 	return 0;
 }
 
+/* Read `count` elements of `elem` bytes into a fresh buffer that grows with the bytes actually
+ * present, so that a corrupt header cannot make the reader allocate more than the file holds
+ * (plus one 4 MiB step).  NULL + errno (EINVAL: truncated, ENOMEM). */
+static void *
+read_array(FILE *f, size_t count, size_t elem)
+{
+	const size_t step = (size_t) 4 << 20;
+	size_t want, have = 0, cap;
+	unsigned char *p, *t;
+
+	if (elem != 0 && count > (size_t) -1 / elem) {
+		errno = EINVAL;
+		return NULL;
+	}
+	want = count * elem;
+	cap = want < step ? (want ? want : 1) : step;
+	p = malloc(cap);
+	if (p == NULL) {
+		errno = ENOMEM;
+		return NULL;
+	}
+	while (have < want) {
+		size_t n = want - have < cap - have ? want - have : cap - have;
+		if (n == 0) {
+			cap = cap * 2 < want ? cap * 2 : want;
+			t = realloc(p, cap);
+			if (t == NULL) {
+				free(p);
+				errno = ENOMEM;
+				return NULL;
+			}
+			p = t;
+			continue;
+		}
+		if (fread(p + have, 1, n, f) != n) {
+			free(p);
+			errno = EINVAL; /* truncated */
+			return NULL;
+		}
+		have += n;
+	}
+	return p;
+}
+
 struct fsm_hip_dfa_desc *
 fsm_hip_desc_read(FILE *f)
 {
 	struct flat *fl = NULL;
 	char magic[8];
-	uint32_t hdr[4], n, nr, nid, s;
+	uint32_t hdr[4], n, nr, nid, s, ne = 0;
 	unsigned char pad[4];
+	int v2;
 
 	if (f == NULL) {
 		errno = EINVAL;
 		return NULL;
 	}
-	int v2;
 	if (fread(magic, 1, 8, f) != 8 || (memcmp(magic, desc_magic, 8) != 0 && memcmp(magic, desc_magic2, 8) != 0) ||
 	    fread(hdr, 4, 4, f) != 4) {
 		errno = EINVAL;
@@ -481,7 +548,8 @@ fsm_hip_desc_read(FILE *f)
 	n = hdr[0];
 	nr = hdr[2];
 	nid = hdr[3];
-	if (n == 0 || n >= 0x00FFFFFFu || hdr[1] >= n) {
+	/* a DFA state has at most 256 byte ranges */
+	if (n == 0 || n >= 0x00FFFFFFu || hdr[1] >= n || (uint64_t) nr > (uint64_t) n * 256u) {
 		errno = EINVAL;
 		return NULL;
 	}
@@ -490,32 +558,26 @@ fsm_hip_desc_read(FILE *f)
 		errno = ENOMEM;
 		return NULL;
 	}
-	fl->edge_off = malloc(((size_t) n + 1) * 4);
-	fl->ranges = malloc(((size_t) nr ? nr : 1) * sizeof *fl->ranges);
-	fl->is_end = malloc(n);
-	fl->endid_off = malloc(((size_t) n + 1) * 4);
-	fl->endids = malloc(((size_t) nid ? nid : 1) * 4);
-	if (fl->edge_off == NULL || fl->ranges == NULL || fl->is_end == NULL || fl->endid_off == NULL || fl->endids == NULL) {
+	if ((fl->edge_off = read_array(f, (size_t) n + 1, 4)) == NULL ||
+	    (fl->ranges = read_array(f, nr, sizeof *fl->ranges)) == NULL ||
+	    (fl->is_end = read_array(f, n, 1)) == NULL ||
+	    ((n & 3u) != 0 && fread(pad, 1, 4 - (n & 3u), f) != 4 - (n & 3u) && (errno = EINVAL, 1)) ||
+	    (fl->endid_off = read_array(f, (size_t) n + 1, 4)) == NULL ||
+	    (fl->endids = read_array(f, nid, 4)) == NULL) {
+		int e = errno;
 		fsm_hip_desc_free(&fl->d);
-		errno = ENOMEM;
+		errno = e;
 		return NULL;
 	}
-	if (fread(fl->edge_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
-	    (nr > 0 && fread(fl->ranges, sizeof *fl->ranges, nr, f) != nr) ||
-	    fread(fl->is_end, 1, n, f) != n ||
-	    ((n & 3u) != 0 && fread(pad, 1, 4 - (n & 3u), f) != 4 - (n & 3u)) ||
-	    fread(fl->endid_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
-	    (nid > 0 && fread(fl->endids, 4, nid, f) != nid)) {
-		fsm_hip_desc_free(&fl->d);
-		errno = EINVAL; /* truncated */
-		return NULL;
-	}
-	/* structural checks: offsets monotone and consistent with the header */
+	/* structural checks: offsets monotone and consistent with the header; ranges of one state
+	 * ascending and disjoint (so edge_off[] cannot claim more ranges than were supplied) */
 	if (fl->edge_off[0] != 0 || fl->edge_off[n] != nr || fl->endid_off[0] != 0 || fl->endid_off[n] != nid) {
 		goto bad;
 	}
 	for (s = 0; s < n; s++) {
-		if (fl->edge_off[s + 1] < fl->edge_off[s] || fl->endid_off[s + 1] < fl->endid_off[s]) {
+		if (fl->edge_off[s + 1] < fl->edge_off[s] || fl->edge_off[s + 1] > nr ||
+		    fl->edge_off[s + 1] - fl->edge_off[s] > 256u ||
+		    fl->endid_off[s + 1] < fl->endid_off[s] || fl->endid_off[s + 1] > nid) {
 			goto bad;
 		}
 	}
@@ -532,24 +594,21 @@ fsm_hip_desc_read(FILE *f)
 	fl->d.endid_off = fl->endid_off;
 	fl->d.endids = fl->endids;
 	if (v2) {
-		uint32_t ne;
 		if (fread(&ne, 4, 1, f) != 1) {
 			goto bad;
 		}
-		fl->eager_off = malloc(((size_t) n + 1) * 4);
-		fl->eager_ids = malloc(((size_t) ne ? ne : 1) * 4);
-		if (fl->eager_off == NULL || fl->eager_ids == NULL) {
+		if ((fl->eager_off = read_array(f, (size_t) n + 1, 4)) == NULL ||
+		    (fl->eager_ids = read_array(f, ne, 4)) == NULL) {
+			int e = errno;
 			fsm_hip_desc_free(&fl->d);
-			errno = ENOMEM;
+			errno = e;
 			return NULL;
 		}
-		if (fread(fl->eager_off, 4, (size_t) n + 1, f) != (size_t) n + 1 ||
-		    (ne > 0 && fread(fl->eager_ids, 4, ne, f) != ne) ||
-		    fl->eager_off[0] != 0 || fl->eager_off[n] != ne) {
+		if (fl->eager_off[0] != 0 || fl->eager_off[n] != ne) {
 			goto bad;
 		}
 		for (s = 0; s < n; s++) {
-			if (fl->eager_off[s + 1] < fl->eager_off[s]) {
+			if (fl->eager_off[s + 1] < fl->eager_off[s] || fl->eager_off[s + 1] > ne) {
 				goto bad;
 			}
 		}

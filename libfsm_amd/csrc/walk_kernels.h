@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t start_code(const WalkArgs &a, uint64_t i, bo
 	return a.enc_of[sid == FSMHIP_STATE_DEAD || sid >= a.nstates ? a.nstates : sid];
 }
 
-enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2 };
+enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3 };
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
 #define FSMHIP_BTAB_BYTES 256u
@@ -228,7 +228,6 @@ struct Tiny5Pol {
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const { return __builtin_amdgcn_ubfe(v, st, 5u); }
 };
 
-template <bool MASK>
 struct LdsPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
@@ -250,10 +249,6 @@ struct LdsPol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (MASK) {
-			if (st < abs_min) st = (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + c * 2u)) << 2;
-			return st;
-		}
 		return (uint32_t)(*reinterpret_cast<const uint16_t *>(tab + st + c * 2u)) << 2;
 	}
 };
@@ -306,7 +301,6 @@ struct LdsSelfPol {
 	}
 };
 
-template <bool MASK>
 struct CombPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
@@ -330,13 +324,11 @@ struct CombPol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (MASK && st >= abs_min) return st;
 		const uint32_t x = comb[st + c] ^ (st << 16);
 		return x < 0x10000u ? x : dfl[c];
 	}
 };
 
-template <bool MASK>
 struct Comb256Pol {
 	typedef uint32_t P;
 	typedef uint32_t S;
@@ -357,7 +349,6 @@ struct Comb256Pol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return b; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P b) const
 	{
-		if (MASK && st >= abs_min) return st;
 		const uint32_t x = comb[st + b] ^ (st << 16);
 		return x < 0x10000u ? x : dflt;
 	}
@@ -382,6 +373,7 @@ struct CombSelfPol {
 	                         * one ds_read_b64 brings the next state AND its self-loop mask */
 	const uint2 *dsm;       /* LDS [32]: {row offset, self-loop mask} of each class's default state */
 	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
+	uint32_t start, start_sm;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
@@ -392,8 +384,16 @@ struct CombSelfPol {
 		comb = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES);
 		dsm = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES + a.tab_bytes - 256u);
 		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
+		start = a.start;
+		start_sm = smask0[a.start];
 	}
-	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, smask0[code] }; return s; }
+	/* every input starts from the start state unless it is resumed: its mask is fetched once per
+	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
+	__device__ __forceinline__ S init(uint32_t code) const
+	{
+		S s = { code, code == start ? start_sm : smask0[code] };
+		return s;
+	}
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
@@ -424,7 +424,6 @@ struct CombSelfPol {
 	}
 };
 
-template <bool MASK>
 struct GlobPol {
 	typedef uint32_t P;
 	typedef uint32_t S;
@@ -450,7 +449,6 @@ struct GlobPol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (MASK && st >= abs_min) return st;
 		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
 		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
 	}
@@ -458,10 +456,11 @@ struct GlobPol {
 
 /*
  * SparsePol: base-row records (plan.cpp build_sparse).  A state is its renumbered id; its 16-byte
- * record {bits lo, bits hi, base | DENSE, offset} comes from LDS for the H states nearest the start
- * state and from HBM/L2 for the rest.  A lane follows base links until a record has the class's bit
- * set (next state = one gather from the exception list) or is dense (next state from the dense
- * row, LDS for the first rows).  The loop is lane-divergent; chains are bounded by the planner.
+ * record {bits lo, bits hi, base | DENSE | CONSEC, offset} comes from LDS for the H states nearest the
+ * start state and from HBM/L2 for the rest.  A lane follows base links until a record has the class's
+ * bit set -- next state = offset + rank of the bit when the record's targets are consecutive ids
+ * (CONSEC: pure arithmetic), else one gather from the exception list -- or is dense (next state from
+ * the dense row, LDS for the first rows).  The loop is lane-divergent; chains are bounded by the planner.
  */
 struct SparsePol {
 	typedef uint32_t P;   /* class | bit << 8 */
@@ -510,10 +509,14 @@ struct SparsePol {
 			} else {
 				const uint32_t sel = bit < 32u ? (r.x >> bit) & 1u : bit < 64u ? (r.y >> (bit - 32u)) & 1u : 0u;
 				if (sel) {
-					res = exc[r.w + __popc(r.x & lowmask_lo) + __popc(r.y & lowmask_hi)];
+					const uint32_t k = r.w + __popc(r.x & lowmask_lo) + __popc(r.y & lowmask_hi);
+					/* CONSEC: the exception targets are consecutive ids in bit order (breadth-first
+					 * numbering gives every trie node's children such ids), so the k-th one is
+					 * first + k: no gather at all */
+					res = (r.z & 0x40000000u) ? k : exc[k];
 					live = false;
 				} else {
-					st = r.z;
+					st = r.z & 0x3FFFFFFFu;
 				}
 			}
 		}
@@ -657,6 +660,37 @@ struct EagerWidePol : Pol {
 	__device__ __forceinline__ void finish_at(const S &st) const { emit(st.pend, st.row); }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
 };
+
+/* member-wise select of a walk state (a ternary on the aggregates themselves makes the compiler take
+ * their addresses: 48-64 bytes of scratch per lane in the first version of the ragged / generic kernels) */
+__device__ __forceinline__ uint32_t pick(bool c, uint32_t x, uint32_t y) { return c ? x : y; }
+__device__ __forceinline__ LdsSelfState pick(bool c, const LdsSelfState &x, const LdsSelfState &y)
+{
+	LdsSelfState r = { c ? x.st : y.st, c ? x.sm : y.sm };
+	return r;
+}
+__device__ __forceinline__ CombSelfState pick(bool c, const CombSelfState &x, const CombSelfState &y)
+{
+	CombSelfState r = { c ? x.st : y.st, c ? x.sm : y.sm };
+	return r;
+}
+template <class Pol>
+__device__ __forceinline__ EagerState<Pol> pick(bool c, const EagerState<Pol> &x, const EagerState<Pol> &y)
+{
+	EagerState<Pol> r;
+	r.s = pick(c, x.s, y.s);
+	r.acc = c ? x.acc : y.acc;
+	return r;
+}
+template <class Pol>
+__device__ __forceinline__ EagerWideState<Pol> pick(bool c, const EagerWideState<Pol> &x, const EagerWideState<Pol> &y)
+{
+	EagerWideState<Pol> r;
+	r.s = pick(c, x.s, y.s);
+	r.row = c ? x.row : y.row;
+	r.pend = c ? x.pend : y.pend;
+	return r;
+}
 
 /* the state an input starts from: policies that need the input index define init_at() */
 template <class Pol>
@@ -868,8 +902,8 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
  * AUX = 2 marks the DMA loads nontemporal: every input line is used exactly once (SEG = 128), so
  * it need not displace the transition table from L2.
  */
-template <class Pol, int SEG, int AUX>
-__global__ void __launch_bounds__(1024)
+template <class Pol, int SEG, int AUX, int MAXT = 1024>
+__global__ void __launch_bounds__(MAXT)
 walk_ldsdma(const WalkArgs a)
 {
 	constexpr uint32_t PIECES = SEG / 16u;      /* 4 | 8 */
@@ -941,8 +975,8 @@ walk_ldsdma(const WalkArgs a)
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
 
-template <class Pol>
-__global__ void __launch_bounds__(1024)
+template <class Pol, int MAXT = 1024>
+__global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
 {
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -988,7 +1022,7 @@ walk_generic(const WalkArgs a)
 #pragma unroll
 					for (int k = 0; k < 16; k++) {
 						const typename Pol::S nx = pol.next(st[0], pol.pre(byte_of(w[0], k)));
-						st[0] = ((uint32_t)k - lo) < cnt ? nx : st[0]; /* k < lo wraps: fails the test */
+						st[0] = pick(((uint32_t)k - lo) < cnt, nx, st[0]); /* k < lo wraps: fails the test */
 					}
 				}
 				w[0] = wn;
@@ -1001,10 +1035,11 @@ walk_generic(const WalkArgs a)
 }
 
 /* ------------------------------------------------------------------ */
-/* walk_queue: ragged inputs with per-lane work claiming               */
+/* walk_ragged: ragged lengths / packed offsets, coalesced + refilled   */
 /* ------------------------------------------------------------------ */
 
-/* per-lane result write (no wavefront-wide ballot: lanes finish at different times) */
+/* per-lane result write (lanes finish at different times: no wavefront-wide ballot).  The bitmap
+ * is filled with atomic ORs and must have been cleared on the launch stream. */
 __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i, uint32_t st)
 {
 	const uint32_t idx = st / a.fin_div;
@@ -1013,265 +1048,197 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
 	if (a.out2 != nullptr) a.out2[i] = a.fin2[idx];
 	if (a.state_io != nullptr) a.state_io[i] = a.orig_of[idx];
 	if (a.bitmap != nullptr && end != FSMHIP_NO_MATCH)
-		atomicOr(reinterpret_cast<unsigned long long *>(a.bitmap + (i >> 6)), 1ull << (i & 63u)); /* bitmap pre-zeroed */
+		atomicOr(reinterpret_cast<unsigned long long *>(a.bitmap + (i >> 6)), 1ull << (i & 63u));
 }
 
-/*
- * Ragged / packed inputs.  In walk_generic a wavefront owns 64 consecutive inputs and runs until
- * the longest one ends, so with lengths uniform in [0, L] half the lane-steps are idle.  Here every
- * lane claims its next input from a global counter as soon as its current one ends (one
- * wave-aggregated atomicAdd per refill: ballot, popcount, prefix rank), and an input that reaches
- * an absorbing state ends right there -- fsm_exec's own per-input early exit (exec.c:133-138).
- * Inputs are claimed in index order, so neighbouring lanes start on neighbouring (packed) inputs.
- */
+/* 16 bytes of which only [lo, lo + cnt) belong to the input */
 template <class Pol>
-__global__ void __launch_bounds__(1024)
-walk_queue(const WalkArgs a, unsigned long long *counter)
+__device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t lo, uint32_t cnt)
 {
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const typename Pol::S nx = pol.next(st, pol.pre(byte_of(w, k)));
+		st = pick(((uint32_t)k - lo) < cnt, nx, st); /* k < lo wraps: fails the test */
+	}
+}
+
+#define FSMHIP_RAGGED_RING 128u                                  /* staged (offset, length) pairs per wave */
+#define FSMHIP_RAGGED_WAVE_LDS (8192u + FSMHIP_RAGGED_RING * 16u) /* 8 KiB tile + the ring */
+
+/*
+ * The retest / rx front: inputs of any length at any byte offset (packed back to back with an offsets
+ * array, or fixed stride + lengths).  walk_generic gives every lane its own 16-byte loads with two
+ * chunks in flight (latency-bound, 1.1-1.4 TB/s) and runs a wavefront until its longest input ends
+ * (half the lane-steps idle at uniform 0..1024 B).  Here
+ *  - input bytes arrive as in walk_ldsdma: per 128-byte segment of a lane's input, 8 adjacent loader
+ *    lanes fetch its 8 16-byte pieces with ONE global_load_lds_dwordx4 (each row's source address is
+ *    the owner lane's current position, handed to the loaders by cross-lane shuffles; pieces beyond
+ *    the input's last chunk are masked off), piece-rotated so the row-per-lane ds_read_b128 that
+ *    follows is conflict-free; the next segment is in flight while the current one is walked;
+ *  - a wavefront owns a contiguous range of inputs and REFILLS its lanes at every segment boundary:
+ *    a lane whose input ends with the segment in hand (or sits in an absorbing state: fsm_exec's own
+ *    early exit, exec.c:133-138) claims the next unclaimed input of the range -- ballot, popcount
+ *    rank, no atomics -- so lanes stay busy whatever the length distribution.  The (offset, length)
+ *    pairs of the next <= 128 inputs wait in an LDS ring that is topped up 64 at a time, one
+ *    iteration ahead of their use.
+ * Results are written per lane when its input ends.
+ */
+template <class Pol, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+walk_ragged(const WalkArgs a)
+{
+	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);
 	__syncthreads();
 
-	const uint32_t lane = threadIdx.x & 63u;
-	bool have = false;
-	uint64_t i = 0, q0 = 0, span = 0, c = 0, nchunks = 0;
-	uint32_t head = 0;
-	typename Pol::S st[1] = { init_state(pol, a.start, a, 0, false, 0) };
-	u32x4 w[1] = { {0u, 0u, 0u, 0u} };
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * FSMHIP_RAGGED_WAVE_LDS;
+	uint64_t *ring = reinterpret_cast<uint64_t *>(stg + 8192u);   /* [RING][2]: byte offset, length */
 
-	/* wave-local pool of claimed input indices [pool, pool_end): one atomicAdd per QCHUNK inputs
-	 * (a single hot counter saturates near 88 atomics/us on this chip -- one atomic per refill
-	 * made the first version of this kernel 20x slower than walk_generic) */
-	constexpr uint64_t QCHUNK = 256;
-	uint64_t pool = 0, pool_end = 0;
+	/* contiguous range of whole bitmap words per wavefront */
+	const uint64_t nwaves = (uint64_t)gridDim.x * nw, gw = (uint64_t)blockIdx.x * nw + wave;
+	const uint64_t words = (a.n + 63u) / 64u, per = ((words + nwaves - 1u) / nwaves) * 64u;
+	const uint64_t w_lo = gw * per < a.n ? gw * per : a.n;
+	const uint64_t w_hi = w_lo + per < a.n ? w_lo + per : a.n;
+	if (w_lo >= w_hi) return;
+
+	const uint32_t lr = lane / 8u, lq = lane % 8u;                   /* loader role */
+	const unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
+	const uint32_t rot = (lane >> 1) & 7u;
+	const uint64_t lt = (1ull << lane) - 1ull;
+
+	uint64_t staged = w_lo, next = w_lo;      /* wave-uniform: ring holds [next, staged) */
+	uint64_t sb = 0, sl = 0;                  /* staging loads in flight (this lane's pair) */
+	uint32_t spend = 0;                       /* wave-uniform: how many pairs they are */
+
+	bool have = false;                        /* this lane holds an input whose segment is in the tile */
+	uint64_t ci = 0, csrc = 0, span = 0;      /* its index, address of its chunk kpos, head + length */
+	uint32_t nch = 0, kpos = 0, head = 0;     /* chunks in all / walked so far, offset of the first byte */
+	typename Pol::S st = init_state(pol, a.start, a, 0, false, 0);
+	bool tile = false;                        /* wave-uniform: a segment is in flight */
 
 	for (;;) {
-		/* refill the lanes without work */
-		const uint64_t need = __ballot(!have);
-		if (need != 0) {
-			if (pool >= pool_end) { /* wave-uniform */
-				unsigned long long base = 0;
-				if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(counter, (unsigned long long)QCHUNK);
-				base = __shfl(base, __builtin_ctzll(need));
-				pool = base;
-				pool_end = base + QCHUNK;
+		u32x4 w[8];
+		if (tile || spend != 0) {
+			__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): tile and staged pairs have landed */
+			__asm__ volatile("" ::: "memory");
+		}
+		if (spend != 0) {
+			if (lane < spend) {
+				ring[((staged + lane) & (RING - 1u)) * 2u] = sb;
+				ring[((staged + lane) & (RING - 1u)) * 2u + 1u] = sl;
 			}
-			const uint64_t mine = pool + (uint64_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-			const uint64_t wanted = (uint64_t)__builtin_popcountll(need);
-			const bool take = !have && mine < pool_end;
-			pool += wanted < pool_end - pool ? wanted : pool_end - pool;
+			staged += spend;
+			spend = 0;
+		}
+		if (tile) {
+#pragma unroll
+			for (uint32_t p = 0; p < 8; p++)
+				w[p] = *reinterpret_cast<const u32x4 *>(rd + ((p + rot) & 7u) * 16u);
+		}
+		__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile in registers (slot reusable), ring written */
+		__asm__ volatile("" ::: "memory");
+		__builtin_amdgcn_wave_barrier();
+
+		/* lanes whose input ends with the segment in hand */
+		const bool fin = have && (kpos + 8u >= nch || ((a.early & 1u) && Pol::code(st) >= a.abs_min));
+		const bool cont = have && !fin;
+		/* refill: every lane that will be idle claims the next unclaimed input, in lane order */
+		bool got = false;
+		uint64_t ni = 0, nq0 = 0, nspan = 0;
+		uint32_t nnch = 0, nhead = 0;
+		uint64_t need = __ballot(!cont);
+		while (need != 0 && next < staged) {   /* wave-uniform; repeats only over empty inputs */
+			const uint64_t idx = next + (uint64_t)__builtin_popcountll(need & lt);
+			const bool take = !cont && !got && idx < staged;
+			const uint64_t want = (uint64_t)__builtin_popcountll(need);
+			next = next + want < staged ? next + want : staged;
 			if (take) {
-				i = mine;
-				if (i < a.n) {
-					uint64_t beg, len;
-					if (a.off != nullptr) { beg = a.off[i]; len = a.off[i + 1] - beg; }
-					else { beg = i * a.stride; len = a.len != nullptr ? a.len[i] : a.stride; }
-					const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
-					q0 = p0 & ~(uint64_t)15;
-					head = (uint32_t)(p0 - q0);
-					span = len ? head + len : 0;
-					nchunks = (span + 15u) / 16u;
-					c = 0;
-					st[0] = init_state(pol, start_code(a, i, true), a, i, true, 0);
-					have = true;
-					if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
+				const uint64_t beg = ring[(idx & (RING - 1u)) * 2u], len = ring[(idx & (RING - 1u)) * 2u + 1u];
+				const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
+				nq0 = p0 & ~(uint64_t)15;
+				nhead = (uint32_t)(p0 - nq0);
+				nspan = len ? nhead + len : 0;
+				nnch = (uint32_t)((nspan + 15u) / 16u);
+				ni = idx;
+				if (nnch == 0) {
+					/* empty input: accepted iff the start state is an end state; no bytes to fetch */
+					const typename Pol::S e = init_state(pol, start_code(a, idx, true), a, idx, true, 0);
+					write_result_lane(a, idx, Pol::code(e));
+					finish_state(pol, a, idx, true, e, 0);
+				} else {
+					got = true;
+				}
+			}
+			need = __ballot(!cont && !got);
+		}
+
+		/* source and chunk budget of every row's next segment */
+		const uint64_t lsrc = cont ? csrc + 128u : nq0;
+		const uint32_t lrem = cont ? nch - (kpos + 8u) : (got ? nnch : 0u);
+		const bool more = __any(lrem != 0u);
+		if (more) {
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++) {
+				const uint32_t ri = j * 8u + lr;   /* the reader lane this row belongs to */
+				const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)lsrc, (int)ri);
+				const uint32_t hi32 = (uint32_t)__shfl((int)(uint32_t)(lsrc >> 32), (int)ri);
+				const uint32_t rem = (uint32_t)__shfl((int)lrem, (int)ri);
+				const uint32_t piece = (lq - ((ri >> 1) & 7u)) & 7u;
+				if (piece < rem) {
+					const unsigned char *src = reinterpret_cast<const unsigned char *>(((uint64_t)hi32 << 32) | lo32) + piece * 16u;
+					__builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
 				}
 			}
 		}
-		if (!__any(have)) {
-			if (pool >= a.n) break; /* the counter has passed the end: nothing left to claim */
-			continue;
+		/* top the ring up, one iteration ahead of the claims that will read it */
+		if (staged - next < 64u && staged < w_hi) {
+			const uint64_t c = w_hi - staged < 64u ? w_hi - staged : 64u;
+			if (lane < c) {
+				const uint64_t i = staged + lane;
+				if (a.off != nullptr) { sb = a.off[i]; sl = a.off[i + 1] - sb; }
+				else { sb = i * a.stride; sl = a.len != nullptr ? a.len[i] : a.stride; }
+			}
+			spend = (uint32_t)c;
 		}
-		if (have) {
-			if (c < nchunks) {
-				u32x4 wn = {0u, 0u, 0u, 0u};
-				if (c + 1 < nchunks) wn = *reinterpret_cast<const u32x4 *>(q0 + (c + 1) * 16u);
-				const uint32_t lo = c == 0 ? head : 0u;
-				const uint64_t left = span - c * 16u;
-				const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
-				if (__all(lo == 0u && hi == 16u)) {
-					step16<Pol, 1>(pol, st, w);
-				} else {
-					const uint32_t cnt = hi - lo;
+
+		/* walk the segment in hand */
+		if (tile && have) {
 #pragma unroll
-					for (int k = 0; k < 16; k++) {
-						const typename Pol::S nx = pol.next(st[0], pol.pre(byte_of(w[0], k)));
-						st[0] = ((uint32_t)k - lo) < cnt ? nx : st[0];
+			for (uint32_t p = 0; p < 8; p++) {
+				const uint32_t k = kpos + p;
+				if (k < nch) {
+					const uint32_t lo = k == 0 ? head : 0u;
+					const uint64_t left = span - (uint64_t)k * 16u;
+					const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
+					if (__all(lo == 0u && hi == 16u)) {
+						typename Pol::S s1[1] = { st };
+						const u32x4 w1[1] = { w[p] };
+						step16<Pol, 1>(pol, s1, w1);
+						st = s1[0];
+					} else {
+						step16_part(pol, st, w[p], lo, hi - lo);
 					}
 				}
-				w[0] = wn;
-				c++;
-			}
-			if (c >= nchunks || ((a.early & 1u) && Pol::code(st[0]) >= a.abs_min)) {
-				write_result_lane(a, i, Pol::code(st[0]));
-				finish_state(pol, a, i, true, st[0], 0);
-				have = false;
 			}
 		}
-	}
-}
-
-/* ------------------------------------------------------------------ */
-/* synthetic input generator                                          */
-/* ------------------------------------------------------------------ */
-
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z)
-{
-	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-	z ^= z >> 27; z *= 0x94D049BB133111EBull;
-	z ^= z >> 31;
-	return z;
-}
-
-struct GenArgs {
-	unsigned char *base;
-	uint64_t stride, n, first_index, seed;
-	uint32_t nalpha, plant_len, plant_every;
-	unsigned char alphabet[256];
-	unsigned char plant[64];
-};
-
-__host__ __device__ __forceinline__ uint64_t gen_word(const GenArgs &g, uint64_t gi, uint64_t wi)
-{
-	uint64_t r = mix64(g.seed ^ (gi * 0x9E3779B97F4A7C15ull) ^ wi);
-	if (g.nalpha != 0) {
-		uint64_t o = 0;
-		for (int k = 0; k < 8; k++)
-			o |= (uint64_t)g.alphabet[((r >> (8 * k)) & 0xff) % g.nalpha] << (8 * k);
-		r = o;
-	}
-	return r;
-}
-
-__host__ __device__ __forceinline__ uint64_t plant_offset(const GenArgs &g, uint64_t gi)
-{
-	return mix64(g.seed ^ gi ^ 0xA5A5A5A5A5A5A5A5ull) % (g.stride - g.plant_len + 1);
-}
-
-/* one thread = one 8-byte word of one row; rows are stride/8 words */
-__global__ void __launch_bounds__(256)
-gen_inputs_kernel(const GenArgs g)
-{
-	const uint64_t wpr = g.stride / 8u;
-	const uint64_t total = g.n * wpr;
-	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t row = t / wpr, wi = t - row * wpr;
-		const uint64_t gi = g.first_index + row;
-		uint64_t v = gen_word(g, gi, wi);
-		if (g.plant_len != 0 && gi % g.plant_every == 0) {
-			const uint64_t po = plant_offset(g, gi);
-			for (int k = 0; k < 8; k++) {
-				const uint64_t pos = wi * 8u + k;
-				if (pos >= po && pos < po + g.plant_len)
-					v = (v & ~(0xffull << (8 * k))) | ((uint64_t)g.plant[pos - po] << (8 * k));
-			}
+		if (fin) {
+			write_result_lane(a, ci, Pol::code(st));
+			finish_state(pol, a, ci, true, st, 0);
 		}
-		*reinterpret_cast<uint64_t *>(g.base + row * g.stride + wi * 8u) = v;
-	}
-}
-
-/* Affix generator (rx-style workload, BASELINE config 3): rows whose global
- * index is a multiple of `every` are  prefix + body alphabet + suffix  (exactly
- * stride bytes, so they can match ^<prefix>[0-9]+(x|yz)$-like patterns); all
- * other rows are random over the plain alphabet.  affix entries are 8 bytes:
- * [len, b0..b6]. */
-struct AffixArgs {
-	const unsigned char *pfx, *sfx; /* npfx / nsfx entries of 8 bytes */
-	uint32_t npfx, nsfx, every, nbody;
-	unsigned char body[256];
-};
-
-__host__ __device__ __forceinline__ uint64_t affix_word(const GenArgs &g, const AffixArgs &x, uint64_t gi, uint64_t wi)
-{
-	if (gi % x.every != 0) return gen_word(g, gi, wi);
-	const uint64_t r = mix64(g.seed ^ (gi * 0x9E3779B97F4A7C15ull) ^ wi);
-	const uint64_t h = mix64(g.seed ^ gi ^ 0x5A5A5A5A5A5A5A5Aull);
-	const unsigned char *pe = x.pfx + 8u * (uint32_t)((h & 0xffffffffu) % x.npfx);
-	const unsigned char *se = x.sfx + 8u * (uint32_t)((h >> 32) % x.nsfx);
-	const uint32_t pl = pe[0], sl = se[0];
-	uint64_t o = 0;
-	for (int k = 0; k < 8; k++) {
-		const uint64_t pos = wi * 8u + k;
-		unsigned char b = x.body[((r >> (8 * k)) & 0xff) % x.nbody];
-		if (pos < pl) b = pe[1 + pos];
-		else if (pos >= g.stride - sl) b = se[1 + (pos - (g.stride - sl))];
-		o |= (uint64_t)b << (8 * k);
-	}
-	return o;
-}
-
-__global__ void __launch_bounds__(256)
-gen_affix_kernel(const GenArgs g, const AffixArgs x)
-{
-	const uint64_t wpr = g.stride / 8u;
-	const uint64_t total = g.n * wpr;
-	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t row = t / wpr, wi = t - row * wpr;
-		*reinterpret_cast<uint64_t *>(g.base + row * g.stride + wi * 8u) = affix_word(g, x, g.first_index + row, wi);
-	}
-}
-
-/* Read-only streaming probe: the HBM read rate a trivially coalesced kernel reaches on this
- * device (16 B per lane, grid-stride, optionally nontemporal), reported by bench.py next to the
- * spec peak.  (The LDS-DMA probe below reads faster: it is the third candidate of the probe.) */
-template <bool NT>
-__global__ void __launch_bounds__(256)
-stream_read_kernel(const u32x4 *src, uint64_t nvec, uint32_t *out)
-{
-	u32x4 acc = {0u, 0u, 0u, 0u};
-	const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	for (; i + 3 * step < nvec; i += 4 * step) {
-		u32x4 a, b, c, d;
-		if (NT) {
-			a = __builtin_nontemporal_load(src + i);
-			b = __builtin_nontemporal_load(src + i + step);
-			c = __builtin_nontemporal_load(src + i + 2 * step);
-			d = __builtin_nontemporal_load(src + i + 3 * step);
-		} else {
-			a = src[i]; b = src[i + step]; c = src[i + 2 * step]; d = src[i + 3 * step];
+		if (cont) {
+			kpos += 8u;
+			csrc += 128u;
+		} else if (got) {
+			ci = ni; csrc = nq0; span = nspan; nch = nnch; head = nhead; kpos = 0;
+			st = init_state(pol, start_code(a, ni, true), a, ni, true, 0);
 		}
-		acc ^= a ^ b ^ c ^ d;
+		have = cont || got;
+		tile = more;
+		if (!more && spend == 0 && next >= w_hi) break;
 	}
-	for (; i < nvec; i += step) acc ^= src[i];
-	const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
-	if (x == 0x9E3779B9u) out[0] = x; /* practically never: keeps the loads alive */
-}
-
-/* The same probe through the walk's own input path: LDS-DMA of 128-byte row segments into a per-wave
- * 8 KiB tile (the access pattern of walk_ldsdma<..., 128, 2>), one LDS word per tile consumed, no walk. */
-__global__ void __launch_bounds__(1024)
-dma_stream_kernel(const uint8_t *base, uint64_t nrows, uint64_t stride, uint32_t *out)
-{
-	extern __shared__ __align__(16) unsigned char lds[];
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	unsigned char *stg = lds + wave * 8192u;
-	const uint64_t ntiles = nrows / 64u;
-	const uint32_t nseg = (uint32_t)(stride / 128u);
-	const uint32_t lr = lane / 8u, lq = lane % 8u;
-	uint32_t acc = 0;
-	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
-		const unsigned char *src[8];
-#pragma unroll
-		for (uint32_t j = 0; j < 8; j++) src[j] = base + (tile * 64u + j * 8u + lr) * stride + lq * 16u;
-#pragma unroll
-		for (uint32_t j = 0; j < 8; j++)
-			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j]), (lds_void_t *)(stg + j * 1024u), 16, 0, 2);
-		for (uint32_t s_ = 0; s_ < nseg; s_++) {
-			__builtin_amdgcn_s_waitcnt(0x0F70);
-			__asm__ volatile("" ::: "memory");
-			acc ^= *reinterpret_cast<const uint32_t *>(stg + lane * 16u);
-			__builtin_amdgcn_s_waitcnt(0xC07F);
-			__asm__ volatile("" ::: "memory");
-			if (s_ + 1 < nseg) {
-#pragma unroll
-				for (uint32_t j = 0; j < 8; j++)
-					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s_ + 1) * 128u), (lds_void_t *)(stg + j * 1024u), 16, 0, 2);
-			}
-		}
-	}
-	if (acc == 0x9E3779B9u) out[0] = acc;
 }
 
 } // namespace fsmhip

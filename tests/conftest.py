@@ -17,4 +17,5 @@ def built():
     """Build (or reuse) libfsm_hip.so + the oracle; hipcc cross-compiles without a GPU."""
     import __graft_entry__ as ge
     ge.build()
+    ge.build_checker()   # the oracle and (here) oracle/_ref: test infrastructure, not part of build()
     return True

@@ -65,29 +65,28 @@ def test_golden_vectors_all_layouts(hip, path):
 
 @pytest.mark.parametrize("name", ["c1.npz", "c3.npz"])
 def test_fast_paths_every_mode(hip, name):
-    """Fixed-stride aligned rows: direct (NB=1,2,4,8; 1 or 2 rows per lane), LDS-DMA, generic; 1..16 waves;
-    absorbing-lane masking on/off; early retire on/off."""
+    """Fixed-stride aligned rows through every input path: direct (NB = 4, 8; with and without the register
+    double-buffer), LDS-DMA (64 / 128-byte segments, nontemporal or not), generic, ragged; 1..16 waves;
+    early retire on/off."""
     g = Golden(os.path.join(GOLDEN, name))
     rows = g.rows
     n = len(rows)
     for L, dfa in layouts_for(hip, g.flat):
-        variants = [(hip.IN_GENERIC, 0, 1, 0), (hip.IN_LDSDMA, 64, 1, 0), (hip.IN_LDSDMA, 64, 1, 4),
-                    (hip.IN_LDSDMA, 128, 1, 0), (hip.IN_LDSDMA, 128, 1, 2)]
-        variants += [(hip.IN_DIRECT, nb, rows_, 0) for nb in (1, 2, 4, 8) for rows_ in (1, 2)]
-        variants += [(hip.IN_DIRECT, 4, 1, w) for w in (1, 2, 8)]
-        for mode, nb, rows_, waves in variants:
+        variants = [(hip.IN_GENERIC, 0, 0), (hip.IN_RAGGED, 0, 0), (hip.IN_RAGGED, 0, 3), (hip.IN_LDSDMA, 64, 0), (hip.IN_LDSDMA, 64, 4),
+                    (hip.IN_LDSDMA, 128, 0), (hip.IN_LDSDMA, 128, 2)]
+        variants += [(hip.IN_DIRECT, nb, 0) for nb in (4, 8)]
+        variants += [(hip.IN_DIRECT, 4, w) for w in (1, 2, 8)]
+        for mode, nb, waves in variants:
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
             dfa.tune(hip.KNOB_SEG, nb if mode == hip.IN_LDSDMA else 0)
             dfa.tune(hip.KNOB_NB, nb if mode == hip.IN_DIRECT else 0)
-            dfa.tune(hip.KNOB_ROWS, rows_)
             dfa.tune(hip.KNOB_WAVES, waves)
-            for early, mask in ((0, 0), (1, 1), (0, 1), (1, 2)):
+            for early, pre in ((0, 1), (1, 1), (0, 0), (1, 0)):
                 dfa.tune(hip.KNOB_EARLY_RETIRE, early)
-                dfa.tune(hip.KNOB_MASK, mask & 1)
-                dfa.tune(hip.KNOB_PREFETCH, 0 if mask & 2 else 1)
+                dfa.tune(hip.KNOB_PREFETCH, pre)
                 dfa.tune(hip.KNOB_NT, early)
                 end, bm = dfa.exec_batch(rows)
-                assert np.array_equal(end, g.end), (name, L, mode, nb, rows_, waves, early, mask)
+                assert np.array_equal(end, g.end), (name, L, mode, nb, waves, early, pre)
                 assert np.array_equal(bits(bm, n), g.ret == 1)
         dfa.close()
 
@@ -99,12 +98,11 @@ def test_batch_sizes(hip, n):
     rows = hip.gen_inputs_host(n, 128, 5, 77, None, b"libffsm", 3)
     want = Oracle(g.flat).table_walk(rows) if n else np.zeros(0, np.uint32)
     for L, dfa in layouts_for(hip, g.flat):
-        for mode, rows_, seg in ((hip.IN_DIRECT, 1, 0), (hip.IN_DIRECT, 2, 0), (hip.IN_LDSDMA, 1, 64), (hip.IN_LDSDMA, 1, 128), (hip.IN_GENERIC, 1, 0)):
+        for mode, seg in ((hip.IN_DIRECT, 0), (hip.IN_LDSDMA, 64), (hip.IN_LDSDMA, 128), (hip.IN_GENERIC, 0), (hip.IN_RAGGED, 0)):
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
-            dfa.tune(hip.KNOB_ROWS, rows_)
             dfa.tune(hip.KNOB_SEG, seg)
             end, bm = dfa.exec_batch(rows)
-            assert np.array_equal(end, want), (n, L, mode, rows_)
+            assert np.array_equal(end, want), (n, L, mode, seg)
             assert np.array_equal(bits(bm, n), want != NO)
         dfa.close()
 
@@ -121,12 +119,12 @@ def test_ragged_lengths_and_empty_inputs(hip):
         lens[:5] = [0, 1, 15, 16, 17]
         ret, want = Oracle(g.flat).exec_stride(rows, lens)
         for L, dfa in layouts_for(hip, g.flat):
-            for queue in (1, 0):          # per-lane work claiming (default) and fixed 64 inputs per wave
-                dfa.tune(hip.KNOB_QUEUE, queue)
+            for mode in (-1, hip.IN_RAGGED, hip.IN_GENERIC):   # auto (= ragged where it fits), coalesced + refill, per-lane loads
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 for early in (1, 0):
                     dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                     end, bm = dfa.exec_batch(rows, lens)
-                    assert np.array_equal(end, want), (name, L, queue, early)
+                    assert np.array_equal(end, want), (name, L, mode, early)
                     assert np.array_equal(bits(bm, len(rows)), ret == 1)
             dfa.close()
 
@@ -149,11 +147,13 @@ def test_packed_unaligned_offsets(hip):
     ret, want = Oracle(g.flat).exec_strings(strings)
     assert (ret == 1).sum() > 1000
     for L, dfa in layouts_for(hip, g.flat):
-        for queue in (1, 0):
-            dfa.tune(hip.KNOB_QUEUE, queue)
-            end, bm = dfa.exec_strings(strings)
-            assert np.array_equal(end, want), (L, queue)
-            assert np.array_equal(bits(bm, len(strings)), ret == 1)
+        for mode in (-1, hip.IN_RAGGED, hip.IN_GENERIC):
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            for waves in (0, 1, 5):
+                dfa.tune(hip.KNOB_WAVES, waves)
+                end, bm = dfa.exec_strings(strings)
+                assert np.array_equal(end, want), (L, mode, waves)
+                assert np.array_equal(bits(bm, len(strings)), ret == 1)
         dfa.close()
 
 

@@ -60,10 +60,11 @@ def decode_sparse(p, S1, lds_limit=160 * 1024):
             sel = (b < 64) & (((bits >> np.minimum(b, 63)) & 1) == 1)
             low = bits & ((1 << np.minimum(b, 63)) - 1)
             pop = np.array([bin(int(x)).count("1") for x in low], np.int64)
-            eval_ = img[np.minimum(exo // 4 + rec[:, 3] + pop, len(img) - 1)]
+            consec = (rec[:, 2] & 0x40000000) != 0                      # targets = first + rank: no list stored
+            eval_ = np.where(consec, rec[:, 3] + pop, img[np.minimum(exo // 4 + rec[:, 3] + pop, len(img) - 1)])
             fin_now = dense | sel
             res[idx[fin_now]] = np.where(dense, dval, eval_)[fin_now]
-            st[idx[~fin_now]] = rec[~fin_now, 2]
+            st[idx[~fin_now]] = rec[~fin_now, 2] & 0x3FFFFFFF
             live[idx[fin_now]] = False
             hops += 1
             assert hops <= maxchain + 1
@@ -105,8 +106,11 @@ def check_plan(flat, layout):
         assert len(em) == S1 and list(eids) == sorted(set(flat.eager_ids.tolist()))
         for nidx in range(S1 - 1):
             want_ids = flat.eager_of(int(new2old[nidx]))
-            got_ids = eids[[b for b in range(len(eids)) if (int(em[nidx]) >> b) & 1]]
-            assert np.array_equal(got_ids, want_ids)
+            if len(eids) <= 64:
+                got_ids = eids[[b for b in range(len(eids)) if (int(em[nidx]) >> b) & 1]]
+                assert np.array_equal(got_ids, want_ids)
+            else:   # wide sets: the mask only flags the state, the ids are in the (word, mask) lists (test_wide_eager_sets)
+                assert (em[nidx] != 0) == (len(want_ids) > 0)
             assert (len(want_ids) > 0) == (nidx < p.eager_lo_end or nidx >= p.eager_hi_begin)
         assert em[S1 - 1] == 0
     else:
@@ -155,6 +159,9 @@ def check_plan(flat, layout):
         got = back[nxt_off]
         assert np.array_equal(cfin[off], fin)
         assert ((off >= p.comb_abs_min_off) == absorbing).all()
+        if len(em):   # eager outputs: the two thresholds hold on row offsets too (DEAD may sit above the upper one)
+            emits = (off < p.comb_eager_lo_off) | (off >= p.comb_eager_hi_off)
+            assert np.array_equal(emits[:S1 - 1], em[:S1 - 1] != 0)
         if p.layout == LAYOUT_COMBSELF:
             sm = p.get("comb_smask").astype(np.int64)
             assert len(sm) == len(comb) and Cn <= 32
@@ -177,6 +184,9 @@ def check_plan(flat, layout):
         got = back[nxt_off]
         assert np.array_equal(cfin[off], fin)
         assert ((off >= p.comb256_abs_min_off) == absorbing).all()
+        if len(em):
+            emits = (off < p.comb256_eager_lo_off) | (off >= p.comb256_eager_hi_off)
+            assert np.array_equal(emits[:S1 - 1], em[:S1 - 1] != 0)
     elif p.layout == LAYOUT_SPARSE:
         got = decode_sparse(p, S1)
     else:
@@ -211,6 +221,8 @@ def test_auto_layout_choices(built):
     pa = Plan(ac, LAYOUT_SPARSE)
     img = pa.get("sparse")
     assert img.size * 4 * 4 < pa.S1 * pa.C * 4 and int(img[12]) <= 7
+    # breadth-first numbering makes every trie node's children consecutive: (nearly) no exception lists remain
+    assert int(img[13]) > 0.9 * (int(img[8]) - int(img[10])) * 0.5 and int(img[11]) < 0.05 * pa.S1
     want = decode_want(ac, pa)
     assert np.array_equal(decode_sparse(pa, pa.S1), want)
 
@@ -274,6 +286,19 @@ def test_random_dfas_all_layouts(built):
         flat = FlatDfa.from_dense(nt, int(rng.randint(S)), rng.randint(0, 2, S))
         for L in (0,) + tuple(ALL_LAYOUTS):
             check_plan(flat, L)
+        # the same automaton with eager outputs on a third of its states (narrow: <= 64 ids, wide: more):
+        # every layout must keep "emits" a two-threshold test on its state encoding
+        for nids in (40, 200):
+            off, ids = [0], []
+            for s_ in range(S):
+                if rng.rand() < 0.33:
+                    ids.extend(sorted(set(int(x) for x in rng.randint(1, nids + 1, rng.randint(1, 4)))))
+                off.append(len(ids))
+            if not ids:
+                continue
+            flat.eager_off, flat.eager_ids = np.array(off, np.uint32), np.array(ids, np.uint32)
+            for L in (0,) + tuple(ALL_LAYOUTS):
+                check_plan(flat, L)
 
 
 def test_layouts_on_reference_fsm_corpus(built):
