@@ -449,7 +449,7 @@ class HipDfa:
             raise _oserr("fsm_hip_exec_batch_offsets_device")
 
     def exec_batch_ids(self, data: np.ndarray, mode: int, lens: Optional[np.ndarray] = None) -> np.ndarray:
-        """Device-side end-id delivery: mode 1 = lowest id (AMBIG_EARLIEST), 2 = index into ret sets."""
+        """Device-side end-id delivery: mode 1 = lowest id (AMBIG_EARLIEST), 2 = index into ret sets, 3 = AMBIG_ERROR."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         n, stride = data.shape
         out = np.empty(n, dtype=np.uint32)
@@ -510,6 +510,38 @@ class HipDfa:
             assert self._lib.fsm_hip_ret_get(C.c_void_p(self._h), C.c_uint32(k), C.byref(p), C.byref(n)) == 0
             out.append(np.frombuffer((C.c_char * (n.value * 4)).from_address(p.value), dtype=np.uint32).copy() if n.value else np.zeros(0, np.uint32))
         return out
+
+    def ids_conflict(self):
+        """AMBIG_ERROR's check: None, or the lowest end state that carries more than one end-id."""
+        st = C.c_uint(0)
+        r = self._lib.fsm_hip_ids_conflict(C.c_void_p(self._h), C.byref(st))
+        if r < 0:
+            raise _oserr("fsm_hip_ids_conflict")
+        return int(st.value) if r == 1 else None
+
+    def state_is_absorbing(self, state: int) -> bool:
+        r = self._lib.fsm_hip_state_is_absorbing(C.c_void_p(self._h), C.c_uint32(state))
+        if r < 0:
+            raise _oserr("fsm_hip_state_is_absorbing")
+        return bool(r)
+
+    def match_file(self, path: str) -> int:
+        """fsm_hip_match_file(dfa, FILE *) on a file opened with the C library."""
+        libc = C.CDLL(None, use_errno=True)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        f = libc.fopen(path.encode(), b"rb")
+        if not f:
+            raise OSError(C.get_errno(), "fopen")
+        try:
+            C.set_errno(0)
+            r = self._lib.fsm_hip_match_file(C.c_void_p(self._h), C.c_void_p(f))
+        finally:
+            libc.fclose(f)
+        if r < 0:
+            raise _oserr("fsm_hip_match_file")
+        return r
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.fsm_hip_last_kernel_ms(self._h))

@@ -101,3 +101,35 @@ class Corpus:
         flat = FlatDfa(int(z[f"d{k}_nstates"]), int(z[f"d{k}_start"]), z[f"d{k}_edge_off"], r, z[f"d{k}_is_end"],
                        z[f"d{k}_endid_off"], z[f"d{k}_endids"])
         return flat, z[f"d{k}_in_bytes"], z[f"d{k}_in_off"], z[f"d{k}_ret"], z[f"d{k}_end"]
+
+
+def retest_tst_lines():
+    """The reference's tests/retest/*.tst (37 regexps, 115 +/- cases), re-emitted in retest's own file format
+    (src/retest/main.c:738-1177: R dialect, M flags, regexp, +/- lines, blank line) from the frozen goldens
+    tests/golden/retest/*.npz -- regex, dialect, flags, inputs and the fixture's expectations.
+    Returns (lines, index of one '+' line that a test may flip)."""
+    def esc(b):
+        return "".join("\\\\" if c == 0x5C else chr(c) if 32 <= c < 127 else "\\x%02x" % c for c in b)
+
+    letters = {1: "i", 2: "t", 4: "m", 8: "r", 16: "s", 32: "z", 64: "a", 128: "x"}
+    lines, ncases, nre = ["# regenerated from tests/golden/retest/*.npz", "O +e"], 0, 0
+    flip = None
+    for path in [q for q in all_golden_paths() if "/retest/" in q]:
+        g = Golden(path)
+        regex = g.meta["regex"].encode("latin1").split(b"\0")[0]
+        lines.append("R " + g.meta["dialect"])
+        fl = "".join(v for k, v in letters.items() if g.meta["flags"] & k)
+        if fl:
+            lines.append("M " + fl)
+        lines.append(("~" if regex[:1] in (b"#", b"~", b"R", b"O", b"M", b"+", b"-") or not regex else "") + esc(regex))
+        if not regex:
+            lines[-1] = "~"
+        for inp, r in zip(g.strings(), g.ret):
+            lines.append(("+" if r == 1 else "-") + esc(inp))
+            if flip is None and r == 1:
+                flip = len(lines) - 1
+            ncases += 1
+        lines.append("")
+        nre += 1
+    assert (nre, ncases) == (37, 115)
+    return lines, flip

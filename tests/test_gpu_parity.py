@@ -861,30 +861,8 @@ def test_retest_style_c_driver(hip, tmp_path):
                            "-o", exe, "-L" + ref_dir, "-lfsm_ref", "-L" + lib_dir, "-lfsm_hip",
                            "-Wl,-rpath," + ref_dir, "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
 
-    def esc(b):
-        return "".join("\\\\" if c == 0x5C else chr(c) if 32 <= c < 127 else "\\x%02x" % c for c in b)
-
-    letters = {1: "i", 2: "t", 4: "m", 8: "r", 16: "s", 32: "z", 64: "a", 128: "x"}
-    lines, ncases, nre = ["# regenerated from tests/golden/retest/*.npz", "O +e"], 0, 0
-    flip = None
-    for path in [q for q in all_golden_paths() if "/retest/" in q]:
-        g = Golden(path)
-        regex = g.meta["regex"].encode("latin1").split(b"\0")[0]
-        lines.append("R " + g.meta["dialect"])
-        fl = "".join(v for k, v in letters.items() if g.meta["flags"] & k)
-        if fl:
-            lines.append("M " + fl)
-        lines.append(("~" if regex[:1] in (b"#", b"~", b"R", b"O", b"M", b"+", b"-") or not regex else "") + esc(regex))
-        if not regex:
-            lines[-1] = "~"
-        for inp, r in zip(g.strings(), g.ret):
-            lines.append(("+" if r == 1 else "-") + esc(inp))
-            if flip is None and r == 1:
-                flip = len(lines) - 1
-            ncases += 1
-        lines.append("")
-        nre += 1
-    assert (nre, ncases) == (37, 115)
+    from common import retest_tst_lines
+    lines, flip = retest_tst_lines()
     tst = tmp_path / "all.tst"
     tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))

@@ -1,0 +1,495 @@
+"""GPU (-m gpu): parity tests added in round 2, all through the C ABI.
+
+  * the eager-output kernels the round-1 suite never reached: LDS-DMA and per-lane-load kernels on
+    uniform 128-byte-multiple rows, the ragged kernel, and eager outputs in the comb / sparse layouts;
+  * a > 6 GB resident batch: rows at byte offsets >= 2^32, the persistent grid's tail and the last partial
+    tile, pulled back and compared with the oracle;
+  * the ragged (coalesced, lane-refilling) kernel on hostile length distributions;
+  * ret-list order for end-ids >= 256 (cmp_ret is a memcmp), AMBIG_ERROR, chunked match_file,
+    two host threads sharing one dfa, the multi-device front, retest -l hip.
+Bit-exact everywhere."""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, Golden, eager_golden_paths
+
+pytestmark = pytest.mark.gpu
+
+NO = 0xFFFFFFFF
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    torch.cuda.set_device(0)
+    import libfsm_amd
+    libfsm_amd.load_library()
+    return libfsm_amd
+
+
+def bits(bm, n):
+    return np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def _need_ref():
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+
+
+EAGER_LAYOUTS = ("TINY", "COMBSELF", "COMB256", "LDSSELF", "LDS", "COMB", "SPARSE", "GLOBAL", "AUTO")
+
+
+def _eager_modes(hip):
+    return ((hip.IN_LDSDMA, 0), (hip.IN_LDSDMA, 5), (hip.IN_DIRECT, 0), (hip.IN_RAGGED, 0), (hip.IN_GENERIC, 0), (-1, 0))
+
+
+def test_eager_outputs_fast_kernels_golden_dfas(hip):
+    """Every tests/eager_output automaton on uniform 256-byte rows (no length array), so that the walk takes
+    walk_ldsdma<EagerPol<...>> / walk_direct<EagerPol<...>> -- the kernels behind the eager throughput numbers --
+    and the ragged and generic ones on the same rows: ids and end states against the oracle."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(77)
+    n_checked = 0
+    for path in eager_golden_paths():
+        g = Golden(path)
+        pats = [p.encode("latin1").strip(b"^$") for p in g.meta["patterns"]]
+        alpha = np.frombuffer((" ".join(g.meta["patterns"]) + " xyz").encode("latin1"), np.uint8)
+        rows = alpha[rng.randint(0, len(alpha), (330, 256))]
+        for i in range(0, 330, 3):                  # plant whole patterns so that outputs fire
+            p = pats[rng.randint(len(pats))]
+            if 0 < len(p) <= 60 and not any(c in p for c in b"[]()*+?|\\."):
+                at = rng.randint(0, 256 - len(p))
+                rows[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
+        wret, wend, wsets = Oracle(g.flat).exec_eager(rows)
+        assert sum(len(s) for s in wsets) > 0
+        for lname in EAGER_LAYOUTS:
+            try:
+                dfa = hip.HipDfa(g.flat, getattr(hip, "LAYOUT_" + lname))
+            except OSError:
+                continue
+            for mode, waves in _eager_modes(hip):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, waves)
+                end, sets = dfa.exec_batch_eager(rows)
+                assert np.array_equal(end, wend), (g.meta["source"], lname, mode, waves)
+                for i in range(len(rows)):
+                    assert np.array_equal(sets[i], wsets[i]), (g.meta["source"], lname, mode, waves, i)
+                n_checked += len(rows)
+            dfa.close()
+    assert n_checked > 100000
+
+
+@pytest.mark.parametrize("nids", [40, 64, 65, 300])
+def test_eager_outputs_fast_kernels_random_dfas(hip, nids):
+    """Random DFAs with register-held (<= 64 ids) and wide id sets: uniform rows through the LDS-DMA (register
+    sets; wide sets fall back to per-lane loads inside launch_walk), direct, ragged and generic kernels, in every
+    layout that can hold the automaton -- including comb / combself / comb256 / sparse, new in round 2."""
+    from oracle.pyoracle import Oracle
+    from test_gpu_parity import random_eager_dfa
+    rng = np.random.RandomState(1000 + nids)
+    for S in (6, 13, 250, 3000, 30000):
+        flat = random_eager_dfa(rng, S, nids)
+        rows = np.frombuffer(b"abcdefgh", np.uint8)[rng.randint(0, 8, (513, 128))]
+        lens = rng.randint(0, 129, 513).astype(np.uint32)
+        o = Oracle(flat)
+        want = {None: o.exec_eager(rows, None, cap=nids + 8), "r": o.exec_eager(rows, lens, cap=nids + 8)}
+        held = 0
+        for lname in EAGER_LAYOUTS:
+            try:
+                dfa = hip.HipDfa(flat, getattr(hip, "LAYOUT_" + lname))
+            except OSError:
+                continue
+            held += 1
+            assert dfa.eager_id_count() == nids
+            for mode, waves in _eager_modes(hip):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, waves)
+                for key, ln in ((None, None), ("r", lens)):
+                    end, sets = dfa.exec_batch_eager(rows, ln)
+                    _, wend, wsets = want[key]
+                    assert np.array_equal(end, wend), (S, lname, mode, waves, key)
+                    for i in range(len(rows)):
+                        assert np.array_equal(sets[i], wsets[i]), (S, lname, mode, waves, key, i)
+            dfa.close()
+        assert held >= 3
+
+
+def test_eager_union_in_a_comb_layout_live_reference(hip):
+    """An anchored eager union built by the reference (fsm_union_repeated_pattern_group) that lands in a comb
+    layout: before round 2 the planner sent every eager DFA that was not tiny/lds to `global`."""
+    _need_ref()
+    from oracle.pyoracle import RefFsm
+    rng = np.random.RandomState(4)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    pats = sorted(set(b"^" + bytes(alpha[rng.randint(0, 26, 3)]) + b"[0-9]+(x|yz)$" for _ in range(48)))[:40]
+    f = RefFsm.union_repeated("pcre", pats, 1, False)
+    strings = []
+    for i in range(900):
+        p = pats[rng.randint(len(pats))]
+        s = p[1:4] + bytes(rng.randint(48, 58, rng.randint(1, 60)).astype(np.uint8)) + (b"x" if i % 2 else b"yz")
+        strings.append(s if i % 3 else bytes(alpha[rng.randint(0, 26, rng.randint(0, 30))]))
+    ret, end, sets = f.exec_eager_strings(strings)
+    stride = 128
+    rows = np.zeros((len(strings), stride), np.uint8)
+    lens = np.array([len(s) for s in strings], np.uint32)
+    for i, s in enumerate(strings):
+        rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+    layouts = set()
+    for L in (hip.LAYOUT_AUTO, hip.LAYOUT_COMBSELF, hip.LAYOUT_COMB256, hip.LAYOUT_COMB, hip.LAYOUT_SPARSE):
+        try:
+            dfa = hip.HipDfa.compile_fsm(f.ptr, L)
+        except OSError:
+            continue
+        layouts.add(dfa.info()["layout_name"])
+        gend, gsets = dfa.exec_batch_eager(rows, lens)
+        assert np.array_equal(gend, end), L
+        for i in range(len(strings)):
+            assert np.array_equal(gsets[i], sets[i]), (L, strings[i])
+        dfa.close()
+    assert layouts & {"combself", "comb256", "comb"}, layouts
+    assert sum(len(s) for s in sets) > 300
+
+
+# ---------------------------------------------------------------------------
+# beyond 4 GiB
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_rows_beyond_4GiB_and_the_last_partial_tile(hip, workload):
+    """6.3e6 x 1 KiB = 6.45 GB resident: rows around byte offset 2^32 (row 4 194 304), a seeded spread over the
+    whole range, the rows walked last by the persistent grid and the last partial tile (n is not a multiple of
+    64) are pulled back and compared with the oracle -- for the default kernel, per-lane loads and the ragged
+    kernel.  The device rows themselves are compared with the host generator (counter-based: any row can be
+    regenerated on its own)."""
+    import torch
+    import bench
+    from oracle.pyoracle import Oracle
+    n, L = 6_300_037, 1024
+    flat = hip.FlatDfa.load(os.path.join(GOLDEN, "c1.npz" if workload == "c2" else "c3.npz"))
+    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    bench.generate(hip, workload, buf.data_ptr(), n, L, 0)
+    torch.cuda.synchronize()
+    edge = 1 << 22                                       # row whose first byte sits at offset 2^32
+    idx = np.unique(np.concatenate([
+        np.arange(edge - 160, edge + 160), np.arange(n - 300, n), np.arange(0, 130),
+        np.arange(2 * edge - 70, 2 * edge + 70) if 2 * edge + 70 < n else np.zeros(0, np.int64),
+        np.random.RandomState(5).randint(0, n, 6000)])).astype(np.int64)
+    rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
+    # the generator twin, on contiguous runs of the sample
+    for lo, cnt in ((edge - 160, 320), (n - 300, 300)):
+        assert np.array_equal(buf[lo:lo + cnt].cpu().numpy(), bench.generate_host(hip, workload, cnt, L, lo))
+    want = Oracle(flat).table_walk(rows)
+    assert 0 < int((want != NO).sum()) < len(idx)
+    end = torch.empty(n, dtype=torch.int32, device="cuda")
+    bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    dfa = hip.HipDfa(flat)
+    ref_end = None
+    for mode in (-1, hip.IN_DIRECT, hip.IN_RAGGED):
+        dfa.tune(hip.KNOB_INPUT_MODE, mode)
+        end.fill_(-2)
+        bm.fill_(-1)
+        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr())
+        torch.cuda.synchronize()
+        got = end[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (workload, mode)
+        assert int((end == -2).sum()) == 0                                   # every row was written
+        b = bits(bm.cpu().numpy(), n)
+        assert np.array_equal(b[idx], want != NO)
+        assert int(b.sum()) == int((end != -1).sum())
+        tail = bm.cpu().numpy().view(np.uint64)[-1]
+        assert int(tail) >> (n % 64) == 0                                    # no bits beyond n in the last word
+        if ref_end is None:
+            ref_end = end.clone()
+        else:
+            assert torch.equal(ref_end, end), (workload, mode)               # all 6.3e6 rows agree across kernels
+    dfa.close()
+
+
+# ---------------------------------------------------------------------------
+# the ragged kernel on hostile length distributions
+# ---------------------------------------------------------------------------
+
+def _packed(strings):
+    off = np.zeros(len(strings) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    return np.frombuffer(b"".join(strings), np.uint8), off
+
+
+@pytest.mark.parametrize("name,alpha", [("c1.npz", b"Llibfsmx\0"), ("c3.npz", b"abcdwxyz0123456789")])
+def test_ragged_kernel_length_distributions(hip, name, alpha):
+    """Packed inputs whose lengths are (a) uniform 0..1024, (b) mostly empty, (c) a few very long ones among
+    short ones (a lane keeps one input for hundreds of segments while its neighbours are refilled), (d) all
+    exactly 128 / 127 / 129 bytes, (e) one input: ragged (default) and generic kernels, 1 to 12 waves, against
+    the oracle -- end states, bitmap, and through the ids / resume fronts."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(len(alpha))
+    a = np.frombuffer(alpha, np.uint8)
+    g = Golden(os.path.join(GOLDEN, name))
+    o = Oracle(g.flat)
+
+    def rnd(k):
+        return bytes(a[rng.randint(0, len(a), k)])
+
+    pats = None
+    if name == "c3.npz":
+        pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+
+    def accepted(k):
+        if pats is None:
+            s = bytearray(rnd(max(k, 6)))
+            at = rng.randint(0, len(s) - 5)
+            s[at:at + 6] = b"Libfsm"
+            return bytes(s)
+        p = pats[rng.randint(len(pats))]
+        return p[1:p.index(b"[")] + bytes(rng.randint(48, 58, max(1, k - 6)).astype(np.uint8)) + b"yz"
+
+    cases = {
+        "uniform": [accepted(rng.randint(8, 1025)) if i % 4 == 0 else rnd(rng.randint(0, 1025)) for i in range(9000)],
+        "mostly_empty": [b"" if i % 7 else rnd(rng.randint(0, 300)) for i in range(5000)],
+        "long_among_short": [accepted(100_000) if i % 257 == 3 else rnd(rng.randint(0, 40)) for i in range(3000)],
+        "exact128": [accepted(128) if i % 2 else rnd(128) for i in range(1500)],
+        "exact127": [rnd(127) for _ in range(700)],
+        "exact129": [rnd(129) for _ in range(700)],
+        "single": [accepted(5000)],
+        "all_empty": [b""] * 300,
+    }
+    for cname, strings in cases.items():
+        ret, want = o.exec_strings(strings)
+        base, off = _packed(strings)
+        for L in (hip.LAYOUT_AUTO, hip.LAYOUT_LDS, hip.LAYOUT_GLOBAL, hip.LAYOUT_COMB256):
+            try:
+                dfa = hip.HipDfa(g.flat, L)
+            except OSError:
+                continue
+            for mode, waves in ((hip.IN_RAGGED, 0), (hip.IN_RAGGED, 1), (hip.IN_RAGGED, 7), (hip.IN_GENERIC, 0)):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, waves)
+                for early in (1, 0):
+                    dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                    end, bm = dfa.exec_batch_offsets(base, off)
+                    assert np.array_equal(end, want), (name, cname, L, mode, waves, early)
+                    assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, early)
+            dfa.close()
+    # stride + lengths through the ragged kernel, with the id and resume fronts
+    rows = a[rng.randint(0, len(a), (4000, 272))]
+    lens = rng.randint(0, 273, 4000).astype(np.uint32)
+    ret, want = o.exec_stride(rows, lens)
+    dfa = hip.HipDfa(g.flat)
+    dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_RAGGED)
+    end, bm = dfa.exec_batch(rows, lens)
+    assert np.array_equal(end, want)
+    st, end2 = dfa.exec_batch_resume(rows, np.full(len(rows), hip.STATE_START, np.uint32), lens)
+    assert np.array_equal(st, o.state_walk(rows, np.full(len(rows), hip.STATE_START, np.uint32), lens))
+    assert np.array_equal(end2, want)
+    ids = dfa.exec_batch_ids(rows, 1, lens)
+    for i in np.nonzero(want != NO)[0][:200]:
+        e = o.endids(int(want[i]))
+        assert ids[i] == (int(e[0]) if len(e) else 0xFFFFFFFE)
+    assert (ids[want == NO] == NO).all()
+    dfa.close()
+
+
+def test_ragged_kernel_large_packed_batch_on_device(hip):
+    """2e6 packed inputs of 0..1024 bytes resident on the device (1 GB): the ragged kernel agrees with
+    walk_generic on every input, a seeded sample agrees with the oracle, popcount(bitmap) = #accepts."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    n, L = 2_000_000, 1024
+    rng = np.random.RandomState(3)
+    lens = rng.randint(0, L + 1, n).astype(np.int64)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    buf = torch.empty(((total + 1023) // 1024 + 1, 1024), dtype=torch.uint8, device="cuda")
+    hip.gen_inputs_device(buf.data_ptr(), buf.shape[0], 1024, 0, 0x5EEDF5A1, None, b"Libfsm", 2)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    e = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    dfa = hip.HipDfa(g.flat)
+    for k, mode in enumerate((hip.IN_RAGGED, hip.IN_GENERIC)):
+        dfa.tune(hip.KNOB_INPUT_MODE, mode)
+        dfa.exec_batch_offsets_device(buf.data_ptr(), d_off.data_ptr(), n, e[k].data_ptr(), bm.data_ptr() if k == 0 else 0)
+    torch.cuda.synchronize()
+    assert torch.equal(e[0], e[1])
+    assert int((e[0] != -1).sum()) == int(bits(bm.cpu().numpy(), n).sum()) > n // 8
+    host = buf.reshape(-1)[:total].cpu().numpy()
+    idx = rng.randint(0, n, 5000)
+    strings = [bytes(host[int(off[i]):int(off[i + 1])]) for i in idx]
+    ret, want = Oracle(g.flat).exec_strings(strings)
+    assert np.array_equal(e[0].cpu().numpy().view(np.uint32)[idx], want)
+    dfa.close()
+
+
+# ---------------------------------------------------------------------------
+# end-id delivery: ret order, AMBIG_ERROR
+# ---------------------------------------------------------------------------
+
+def test_ret_order_is_cmp_ret_and_ambig_error(hip):
+    """The ret list is ordered like build_retlist sorts it (src/libfsm/vm/retlist.c:63-79: by count, then
+    memcmp over the uint32 ids -- byte-wise, so {256} sorts BEFORE {1} on a little-endian host), and
+    FSM_HIP_IDS_ERROR refuses a DFA with an end state that carries two ids (print/c.c:67-72)."""
+    S = 9
+    nt = np.full((S, 256), -1, np.int64)
+    for k in range(1, S):
+        nt[0, ord("a") + k - 1] = k
+    idsets = [[], [1], [256], [0x01000000], [2, 3], [2, 0x100], [70000], [1], []]
+    off, ids = [0], []
+    for s_ in range(S):
+        ids.extend(idsets[s_])
+        off.append(len(ids))
+    flat = hip.FlatDfa.from_dense(nt, 0, [0] + [1] * (S - 1))
+    flat.endid_off, flat.endids = np.array(off, np.uint32), np.array(ids, np.uint32)
+    dfa = hip.HipDfa(flat)
+    sets = [tuple(int(x) for x in s) for s in dfa.ret_sets()]
+    key = lambda t: (len(t), np.array(t, "<u4").tobytes())
+    want = sorted(set(tuple(x) for x in idsets[1:]), key=key)
+    assert sets == want
+    assert sets.index((256,)) < sets.index((1,)) and sets.index((0x01000000,)) < sets.index((1,))   # not numeric
+    rows = np.zeros((S - 1, 16), np.uint8)
+    lens = np.ones(S - 1, np.uint32)
+    rows[:, 0] = np.arange(S - 1) + ord("a")
+    r = dfa.exec_batch_ids(rows, 2, lens)
+    for k in range(1, S):
+        assert sets[int(r[k - 1])] == tuple(idsets[k])
+    e = dfa.exec_batch_ids(rows, 1, lens)
+    assert list(e) == [(min(s) if s else 0xFFFFFFFE) for s in idsets[1:]]
+    assert dfa.ids_conflict() == 4                      # lowest end state with two ids
+    with pytest.raises(OSError):
+        dfa.exec_batch_ids(rows, 3, lens)
+    dfa.close()
+    # without a conflict AMBIG_ERROR is AMBIG_EARLIEST
+    flat2 = hip.FlatDfa.from_dense(nt, 0, [0] + [1] * (S - 1))
+    flat2.endid_off = np.array([0] + list(range(0, S)), np.uint32)        # state 0: none; states 1..S-1: one id each
+    flat2.endids = np.array([300 - k for k in range(S - 1)], np.uint32)
+    d2 = hip.HipDfa(flat2)
+    assert d2.ids_conflict() is None
+    assert np.array_equal(d2.exec_batch_ids(rows, 3, lens), d2.exec_batch_ids(rows, 1, lens))
+    assert list(d2.exec_batch_ids(rows, 3, lens)) == [300 - k for k in range(S - 1)]
+    d2.close()
+
+
+# ---------------------------------------------------------------------------
+# streaming file front, threads
+# ---------------------------------------------------------------------------
+
+def test_match_file_in_chunks(hip, tmp_path):
+    """fsm_hip_match_file carries the state across 64 KiB chunks (fsm_vm_match_file's loop, vm.c:188-216):
+    files below, at and far above the chunk size, the match straddling a chunk boundary, the empty file; an
+    anchored DFA that dies on the first byte stops reading at once."""
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    o = Oracle(g.flat)
+    dfa = hip.HipDfa(g.flat)
+    rng = np.random.RandomState(6)
+    cases = [b"", b"Libfsm", b"x" * 65536, b"x" * 65533 + b"Libfsm" + b"y" * 10, b"x" * 200_000 + b"libffsm",
+             bytes(rng.randint(0, 256, 300_000).astype(np.uint8)), b"q" * 131072, b"Libf" + b"x" * 70000]
+    for k, data in enumerate(cases):
+        p = tmp_path / f"f{k}.bin"
+        p.write_bytes(data)
+        ret, _ = o.exec_one(data)
+        assert dfa.match_file(str(p)) == ret == dfa.match_buffer(data), k
+    assert dfa.state_is_absorbing(hip.STATE_DEAD) and not dfa.state_is_absorbing(hip.STATE_START)
+    dfa.close()
+    g3 = Golden(os.path.join(GOLDEN, "c3.npz"))
+    d3 = hip.HipDfa(g3.flat)
+    p = tmp_path / "big.bin"
+    p.write_bytes(b"#" + b"0" * 3_000_000)               # '#' has no edge from the start state: DEAD after one byte
+    assert d3.match_file(str(p)) == 0
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    good = pats[5][1:pats[5].index(b"[")] + b"7" * 150_000 + b"x"
+    p.write_bytes(good)
+    assert d3.match_file(str(p)) == 1 == Oracle(g3.flat).exec_one(good)[0]
+    d3.close()
+
+
+def test_two_host_threads_share_one_dfa(hip):
+    """The per-dfa mutex: two threads hammering the host-pointer front of ONE dfa (ctypes drops the GIL) get the
+    right answers; a third uses the device front on its own stream meanwhile."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g.flat)
+    dfa = hip.HipDfa(g.flat)
+    rng = np.random.RandomState(11)
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    jobs = []
+    for t in range(2):
+        rows = a[rng.randint(0, len(a), (3000 + 500 * t, 96))]
+        lens = rng.randint(0, 97, len(rows)).astype(np.uint32)
+        jobs.append((rows, lens, o.exec_stride(rows, lens)[1]))
+    drows = torch.from_numpy(g.rows).cuda()
+    dend = torch.empty(len(g.rows), dtype=torch.int32, device="cuda")
+    errors = []
+
+    def host(rows, lens, want):
+        try:
+            for _ in range(60):
+                end, _bm = dfa.exec_batch(rows, lens)
+                if not np.array_equal(end, want):
+                    errors.append("host mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def device():
+        try:
+            s = torch.cuda.Stream()
+            for _ in range(60):
+                dfa.exec_batch_device(drows.data_ptr(), drows.shape[1], len(g.rows), dend.data_ptr(), 0, stream=s.cuda_stream)
+                s.synchronize()
+                if not np.array_equal(dend.cpu().numpy().view(np.uint32), g.end):
+                    errors.append("device mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=host, args=j) for j in jobs] + [threading.Thread(target=device)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    dfa.close()
+
+
+# ---------------------------------------------------------------------------
+# retest -l hip: the reference's own retest(1) with IMPL_HIP in its runner
+# ---------------------------------------------------------------------------
+
+def test_retest_l_hip(hip, tmp_path):
+    """integration/retest: the reference's retest main.c + runner.c with the IMPL_HIP patch applied
+    (integration/retest/impl_hip.patch; built by integration/retest/build.sh against the reference archive).
+    `retest -l hip` over the reference's tests/retest cases (37 regexps / 115 +/- lines, re-emitted in .tst
+    format from the frozen goldens): one fsm_hip_compile per regexp -- in the forked child, so the HIP context
+    is created after the fork -- and one fsm_hip_match_buffer launch per test line.  0 errors; the same file
+    through `-l vm` (the reference's own interpreter) agrees; a flipped expectation is reported by both."""
+    from common import retest_tst_lines
+    exe = os.path.join(ROOT, "integration", "_build", "retest")
+    if not os.path.exists(exe):
+        sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
+        if not os.path.exists(exe):
+            pytest.skip("integration/_build/retest not built (needs /root/reference at build time): " + sh.stderr[-300:])
+    lines, flip = retest_tst_lines()
+    tst = tmp_path / "all.tst"
+    tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for impl in ("hip", "vm"):
+        out = subprocess.run([exe, "-l", impl, str(tst)], capture_output=True, text=True, env=env, timeout=600)
+        tail = out.stdout.strip().splitlines()[-2:]
+        assert out.returncode == 0, (impl, out.stdout[-1500:], out.stderr[-1500:])
+        assert tail[0].endswith("37 regexps, 115 test cases") and tail[1].endswith("0 re errors, 0 errors"), (impl, tail)
+        assert out.stdout.count("[OK    ]") == 115 and "[NOT OK]" not in out.stdout
+    lines[flip] = "-" + lines[flip][1:]
+    bad = tmp_path / "bad.tst"
+    bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    for impl in ("hip", "vm"):
+        out = subprocess.run([exe, "-l", impl, str(bad)], capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 1 and out.stdout.count("[NOT OK]") == 1, (impl, out.stdout[-800:])
+        assert out.stdout.strip().splitlines()[-1].endswith("0 re errors, 1 errors")
