@@ -1,27 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path (batched DFA walk) on N GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c5] [--n INPUTS_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5] [--n INPUTS_PER_GPU] [--subs auto|none]
+                    [--scaling weak|strong] [--full-parity]
 
-A "step" is one pass of the walk kernel over one batch of synthetic inputs that
-is already resident in HBM (generated on the device, so nothing crosses PCIe),
-followed -- for N > 1 -- by the RCCL all-gather of the accept bitmap (asynchronous: it
-overlaps the next step's kernel; all K gathers finish inside the timed region).  Inputs are
-sharded by contiguous global index range, one shard per rank (weak scaling:
-per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the walk kernel over one batch of synthetic inputs that is already resident in
+HBM (generated on the device, so nothing crosses PCIe), followed -- for N > 1 -- by the RCCL all-gather of
+the accept bitmap (asynchronous: it overlaps the next step's kernel; all K gathers finish inside the timed
+region).  Inputs are sharded by contiguous global index range, one shard per rank.  Rank 0 prints ONE JSON
+line.
 
-Workloads (BASELINE.json configs):
-  c2  configs[1]: PCRE [Ll]ibf+(sm)* DFA (5 states) over 1e8 x 1 KiB random
-      inputs per GPU, "Libfsm" planted in every 8th input.        (default)
-  c3  configs[2]: 1 024 anchored PCRE unioned into a ~4 096-state DFA, half the
-      inputs derived from a pattern (prefix + digits + suffix), half random.
-  c5  configs[4]: Aho-Corasick DFA of 1e5 literals (8-16 characters over 64
-      symbols, ~1e6 states, right-anchored, end-id = literal), built by the
-      library's own fsm_hip_strings_* builder; 1e7 x 1 KiB inputs over the same
-      alphabet, every 8th ending with a literal.  The table does not fit LDS: this
-      walk is bound by L2 gather requests, not by HBM.
-The c2/c3 DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real
-reference by tests/golden/make_golden.py); /root/reference is not needed.
+Workloads (BASELINE.json configs; SURVEY.md section 8(d)):
+  c3  configs[2], the north star's target config: 1 024 anchored PCRE unioned into one ~4 096-state DFA,
+      1e8 x 1 KiB inputs per GPU, half derived from a pattern (prefix + digits + suffix), half random. (default)
+  c2  configs[1]: PCRE [Ll]ibf+(sm)* DFA (5 states), 1e8 x 1 KiB random inputs, "Libfsm" planted in every 8th.
+  c5  configs[4]: Aho-Corasick DFA of 1e5 literals (8-16 characters over 64 symbols, ~1e6 states,
+      right-anchored, end-id = literal), built by the library's own fsm_hip_strings_* builder; 1e7 x 1 KiB
+      inputs over the same alphabet, every 8th ending with a literal.  Table > LDS: bound by L2 gather
+      requests, not by HBM.
+At N = 1 the line carries the other configs as `sub_results` (each with its own roofline, cpu_baseline and
+parity): c3 with the chunk skip disabled (every byte pays its lookup test: the transition-dense bound of
+the same table), c2, c5.  N > 1 defaults to configs[3]'s shard, 1.25e8 inputs per GPU.
+The c2/c3 DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real reference by
+tests/golden/make_golden.py); /root/reference is not needed at run time.
 """
 import argparse
 import json
@@ -37,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 SEED = 0x5EEDF5A1
 ALNUM = b"abcdefghijklmnopqrstuvwxyz0123456789"
+KNOB_NOSKIP = 13
 
 
 def parse():
@@ -44,14 +46,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
-    ap.add_argument("--n", "--inputs", dest="n", type=int, default=0, help="inputs per GPU (default 1e8; c5: 1e7)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--subs", default="auto", choices=["auto", "none"],
+                    help="auto: at N = 1 also measure the other configs and report them as sub_results")
+    ap.add_argument("--n", "--inputs", dest="n", type=int, default=0,
+                    help="inputs per GPU (weak) / in all (strong); default 1e8 (N > 1: configs[3]'s 1.25e8 per GPU; c5: 1e7)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--c5-words", type=int, default=100_000, help="c5: number of literals")
     ap.add_argument("--len", type=int, default=1024, help="bytes per input")
     ap.add_argument("--input-mode", type=int, default=-1)
     ap.add_argument("--nb", type=int, default=0)
-    ap.add_argument("--rows", type=int, default=0)
-    ap.add_argument("--mask", type=int, default=-1)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0)
@@ -59,6 +63,8 @@ def parse():
     ap.add_argument("--no-early-retire", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="inputs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-parity", action="store_true",
+                    help="after timing, stream ALL inputs back and compare every end state with the threaded CPU table walker")
     return ap.parse_args()
 
 
@@ -131,66 +137,130 @@ def generate_host(hip, workload, n, L, first, words=None):
     return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
 
 
-def cpu_baseline(hip, workload, flat, L, sample, gpu_end_sample, words=None):
-    """Time the reference's CPU path on a bounded sample of the same inputs (rank 0, N=1 only)
-    and check the GPU's answers on that sample against it, bit for bit."""
+def host_cores():
+    """(threads to use, cgroup cpu quota or None): a container may be throttled far below the visible cores."""
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    if quota:
+        ncores = max(1, min(ncores, int(quota + 0.5)))
+    return ncores, quota
+
+
+def sample_indices(n, sample):
+    """A seeded spread over the WHOLE index range [0, n) -- not a prefix: one random phase, a constant stride,
+    plus the first and last 64 rows (the last tile may be partial) and the rows either side of byte offset 2^32."""
+    sample = max(1, min(sample, n))
+    stride = max(1, n // sample)
+    phase = int(np.random.RandomState(SEED & 0x7FFFFFFF).randint(stride))
+    idx = [phase + np.arange(sample, dtype=np.int64) * stride, np.arange(min(64, n)), np.arange(max(0, n - 64), n)]
+    if n > (1 << 22) + 64:
+        idx.append(np.arange((1 << 22) - 32, (1 << 22) + 32))
+    idx = np.unique(np.concatenate(idx))
+    return idx[idx < n]
+
+
+def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
+    """Time the reference's CPU paths on the sampled rows (the very bytes the GPU walked, copied back from the
+    device; rank 0, N = 1 only) and check the GPU's answers on them against it, bit for bit.
+    SURVEY.md 8(d)'s four CPU lines: (1) literal fsm_exec, (2) fsm_exec with the per-call isdfa sweep hoisted
+    (derived, non-reference), (3) VM v2 on 1 thread and on every granted core, (4) the gcc-compiled matcher
+    `retest -l vmc` generates."""
     from oracle import pyoracle
-    rows = generate_host(hip, workload, sample, L, 0, words)
     out = {"cores": 1, "unit": "GB/s"}
     gb = rows.size / 1e9
-    if workload == "c5":
-        # the reference needs ~1 min and 7.5 GB for re_strings on 1e5 literals, 3.7 s per fsm_exec call
-        # (fsm_all(isdfa) over 1e6 states, exec.c:106) and 7 min to compile its VM (measured in the build
-        # container, DESIGN.md): the CPU leg of this workload is the oracle's table walker
+    nrows = len(rows)
+    if workload == "c5" or not pyoracle.have_ref():
         o = pyoracle.Oracle(flat)
         want = o.table_walk(rows)
         out.update(kind="port", value=round(gb / o.last_seconds, 5),
-                   sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, first {sample} inputs x {L} B")
+                   sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, {nrows} inputs x {L} B spread over the whole batch")
+        if workload == "c5":
+            out["why_not_reference"] = ("at this size the reference's fsm_exec takes 3.7 s per 1 KiB input (fsm_all(fsm_isdfa) over ~1e6 states on "
+                                        "every call, exec.c:106), re_strings 59 s + 7.5 GB to build the DFA and fsm_vm_compile 7 min + 15 GB "
+                                        "(measured in the build container, DESIGN.md section 3); the reference is compared at 3e5 states in "
+                                        "tests/test_gpu_parity.py::test_config5_aho_corasick_100k_literals")
         return out, bool(np.array_equal(gpu_end_sample, want))
-    if pyoracle.have_ref():
-        # the real reference, rebuilt as a struct fsm from its own regex sources
-        if workload == "c2":
-            f = pyoracle.RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
-            nfe = sample
-        else:
-            pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
-            f = pyoracle.RefFsm.union_res("pcre", pats, 0)
-            nfe = min(sample, 1500)  # fsm_exec re-runs fsm_all(isdfa) per call: ~9 ms/call on 4k states
-        ret, end = f.exec_stride(rows[:nfe])
-        t_exec = f.last_seconds
-        vm = f.vm_match_stride(rows, 2)
-        t_vm = f.last_seconds
-        want = pyoracle.Oracle(flat).table_walk(rows)
-        assert np.array_equal(end, want[:nfe]), "oracle != reference fsm_exec"
-        assert np.array_equal(vm == 1, want != 0xFFFFFFFF), "reference VM != fsm_exec"
-        # all host cores: the reference itself is single-threaded, so its fastest matcher (VM v2) is run
-        # on one thread per core over slices of the sample, repeated to ~1-2 s of wall time
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        quota = None
-        try:  # a container may be CPU-throttled far below the visible core count
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            quota = None if q == "max" else round(int(q) / int(per), 2)
-        except Exception:
-            pass
-        if quota:
-            ncores = max(1, min(ncores, int(quota + 0.5)))          # threads = cores the cgroup really grants
-        f.match_threads(rows, ncores, 1, 2)                         # untimed pass (burst credit, page faults)
-        probe, _ = f.match_threads(rows, ncores, 2, 2)              # sizes the timed run (~2 s)
-        reps = max(1, min(2000, int(2.0 * probe / gb)))
-        allc, acc = f.match_threads(rows, ncores, reps, 2)
-        assert acc == int((want != 0xFFFFFFFF).sum()), "threaded VM run disagrees"
-        out.update(kind="reference", value=round(nfe * L / 1e9 / t_exec, 5),
-                   sample=f"reference fsm_exec (src/libfsm/exec.c) with a (ptr,len) getc, 1 thread, first {nfe} inputs x {L} B of the same generator stream",
-                   vm_v2_value=round(gb / t_vm, 5), vm_v2_sample=f"reference fsm_vm_match_buffer v2, 1 thread, {sample} inputs",
-                   vm_v2_allcores_value=round(allc, 3), vm_v2_allcores_cores=ncores, vm_v2_allcores_cgroup_cpu_quota=quota,
-                   vm_v2_allcores_sample=f"same VM shared read-only by {ncores} threads, each walking its slice of the {sample}-input sample {reps}x")
+    # the real reference, rebuilt as a struct fsm from its own regex sources
+    if workload == "c2":
+        f = pyoracle.RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
+        nfe, nho = nrows, nrows
     else:
-        o = pyoracle.Oracle(flat)
-        want = o.table_walk(rows)
-        out.update(kind="port", value=round(gb / o.last_seconds, 5),
-                   sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, first {sample} inputs x {L} B")
+        pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
+        f = pyoracle.RefFsm.union_res("pcre", pats, 0)
+        nfe, nho = min(nrows, 1500), min(nrows, 40000)  # fsm_exec re-runs fsm_all(isdfa) per call: ~9 ms/call on 4k states
+    fe_idx = np.linspace(0, nrows - 1, nfe).astype(np.int64)      # the fsm_exec subset is spread over the sample too
+    ret, end = f.exec_stride(rows[fe_idx])
+    t_exec = f.last_seconds
+    ho_idx = np.linspace(0, nrows - 1, nho).astype(np.int64)
+    hret, hend = f.exec_hoisted_stride(rows[ho_idx])
+    t_hoist = f.last_seconds
+    vm = f.vm_match_stride(rows, 2)
+    t_vm = f.last_seconds
+    want = pyoracle.Oracle(flat).table_walk(rows)
+    assert np.array_equal(end, want[fe_idx]), "oracle != reference fsm_exec"
+    assert np.array_equal(hend, want[ho_idx]), "hoisted fsm_exec != fsm_exec"
+    assert np.array_equal(vm == 1, want != 0xFFFFFFFF), "reference VM != fsm_exec"
+    # all host cores: the reference itself is single-threaded, so its fastest in-process matcher (VM v2) is run
+    # on one thread per core over slices of the sample, repeated to ~1-2 s of wall time
+    ncores, quota = host_cores()
+    f.match_threads(rows, ncores, 1, 2)                         # untimed pass (burst credit, page faults)
+    probe, _ = f.match_threads(rows, ncores, 2, 2)              # sizes the timed run (~2 s)
+    reps = max(1, min(2000, int(2.0 * probe / gb)))
+    allc, acc = f.match_threads(rows, ncores, reps, 2)
+    assert acc == int((want != 0xFFFFFFFF).sum()), "threaded VM run disagrees"
+    out.update(kind="reference", value=round(nfe * L / 1e9 / t_exec, 5),
+               sample=f"reference fsm_exec (src/libfsm/exec.c) with a (ptr,len) getc, 1 thread, {nfe} inputs x {L} B spread over the whole batch",
+               fsm_exec_hoisted_value=round(nho * L / 1e9 / t_hoist, 5),
+               fsm_exec_hoisted_sample=f"fsm_exec with the per-call fsm_all(fsm_isdfa) sweep of exec.c:106-109 removed (derived from exec.c by oracle/build_ref.sh: NOT the reference), 1 thread, {nho} inputs",
+               vm_v2_value=round(gb / t_vm, 5), vm_v2_sample=f"reference fsm_vm_match_buffer v2, 1 thread, {nrows} inputs",
+               vm_v2_allcores_value=round(allc, 3), vm_v2_allcores_cores=ncores, vm_v2_allcores_cgroup_cpu_quota=quota,
+               vm_v2_allcores_sample=f"same VM shared read-only by {ncores} threads, each walking its slice of the {nrows}-input sample {reps}x")
+    # (4) what `retest -l vmc` runs: fsm_print(FSM_PRINT_VMC) -> cc -> dlopen -> fsm_main(b, e) per input
+    try:
+        m = f.codegen_match_stride(rows, "vmc", ("-O3",) if flat.nstates < 1000 else ("-O1",), timeout=90.0)
+        if m is not None:
+            assert np.array_equal(m == 1, want != 0xFFFFFFFF), "generated matcher != fsm_exec"
+            out.update(codegen_vmc_value=round(gb / f.last_seconds, 5),
+                       codegen_vmc_sample=f"the matcher `retest -l vmc` builds (fsm_print FSM_PRINT_VMC, io = pair, gcc {'-O3' if flat.nstates < 1000 else '-O1'}: "
+                                          f"{f.last_compile_seconds:.1f} s to print + compile), 1 thread, {nrows} inputs")
+    except AssertionError:
+        raise
+    except Exception as e:  # no C compiler on the box, ...: the optional line is left out
+        out["codegen_vmc_error"] = repr(e)[:200]
     parity = bool(np.array_equal(gpu_end_sample, want))
     return out, parity
+
+
+def full_parity(torch, flat, buf, end, n, L):
+    """'full N compare GPU vs CPU table-walker'.  Every input is streamed back from the device
+    in 2 GiB slices and walked by the oracle's dense-table walker (itself pinned to fsm_exec on every golden
+    fixture) on all granted host cores; every end state must agree."""
+    from oracle import pyoracle
+    o = pyoracle.Oracle(flat)
+    ncores, _ = host_cores()
+    step = max(1, (2 << 30) // L)
+    bad, t0, t_cpu = 0, time.perf_counter(), 0.0
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rows = buf[lo:hi].cpu().numpy()
+        want = o.table_walk_mt(rows, ncores)
+        t_cpu += o.last_seconds
+        got = end[lo:hi].cpu().numpy().view(np.uint32)
+        bad += int((got != want).sum())
+    return {"rows": n, "mismatches": bad, "cpu_threads": ncores, "seconds": round(time.perf_counter() - t0, 1),
+            "cpu_walk_GBps": round(n * L / 1e9 / t_cpu, 2), "checker": "oracle dense-table walker (oracle/dfa_oracle.c), all inputs"}
+
+
+WORKLOAD_TEXT = {
+    "c2": "c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), ",
+    "c3": "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, ",
+    "c5": "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), ",
+}
 
 
 def main():
@@ -222,160 +292,221 @@ def main():
         dist.barrier()
     import libfsm_amd as hip
     hip.load_library()
-
-    words = None
-    if a.workload == "c5":
-        words = c5_words(a.c5_words)
-        # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
-        flat = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
-    else:
-        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if a.workload == "c2" else "c3.npz"))
-    flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
-    dfa = hip.HipDfa(flat, flags)
-    for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_ROWS, a.rows),
-                    (hip.KNOB_WAVES, a.waves), (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu), (hip.KNOB_MASK, a.mask)):
-        if v > 0 or (knob in (hip.KNOB_INPUT_MODE, hip.KNOB_MASK) and v >= 0):
-            dfa.tune(knob, v)
-    for kv in a.knob:
-        k, v = kv.split("=")
-        dfa.tune(int(k), int(v))
-    info = dfa.info()
+    from libfsm_amd.shard import shard_range
 
     L = a.len
-    n = a.n if a.n > 0 else (10_000_000 if a.workload == "c5" else 100_000_000)
-    requested = n
-    free, total = torch.cuda.mem_get_info()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- sizes: per-GPU inputs of the main workload; one resident buffer serves every workload -------------
+    def default_n(wl):
+        if wl == "c5":
+            return 10_000_000
+        return 125_000_000 if world > 1 else 100_000_000   # N > 1: configs[3] = 1e9 inputs over 8 GPUs
+
+    requested = a.n if a.n > 0 else default_n(a.workload)
+    n_total = requested if a.scaling == "strong" else requested * world
+    n_total = n_total // (64 * world) * (64 * world) if world > 1 else n_total   # equal shards of whole bitmap words
+    first, n = shard_range(n_total, rank, world)
+    free, _total = torch.cuda.mem_get_info()
     need = n * (L + 4) + n // 8 + (1 << 30)
+    shrunk = False
     if need > free * 0.92:  # shrink rather than risk an OOM strike; reported in config
         n = int((free * 0.92 - (1 << 30)) // (L + 5)) // 64 * 64
-    from libfsm_amd.shard import shard_range
-    first, cnt = shard_range(n * world, rank, world)  # weak scaling: the global batch is world x n inputs
-    assert cnt == n or n % 64 != 0
-    n = cnt
-    buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
-    end = torch.empty(n, dtype=torch.int32, device="cuda")
-    nwords = (n + 63) // 64
-    bm = torch.zeros(nwords, dtype=torch.int64, device="cuda")
-    gathered = torch.empty(nwords * world, dtype=torch.int64, device="cuda") if world > 1 else None
-    generate(hip, a.workload, buf.data_ptr(), n, L, first, words, buf)
-    torch.cuda.synchronize()
+        shrunk = True
+        assert world == 1, "the shard does not fit this GPU"
+    buf_all = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+    end_all = torch.empty(n, dtype=torch.int32, device="cuda")
 
-    stream = torch.cuda.current_stream().cuda_stream
-    kernel_ms = []
+    def run(wl, variant=None, n_wl=None, first_wl=0, with_cpu=True):
+        """Generate the workload's inputs in the resident buffer, time a.steps walks, return the result dict."""
+        n_ = n if n_wl is None else min(n_wl, n)
+        buf, end = buf_all[:n_], end_all[:n_]
+        words = None
+        if wl == "c5":
+            words = c5_words(a.c5_words)
+            # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
+            flat = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
+        else:
+            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
+        flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
+        dfa = hip.HipDfa(flat, flags)
+        for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_WAVES, a.waves),
+                        (hip.KNOB_BLOCKS_PER_CU, a.blocks_per_cu)):
+            if v > 0 or (knob == hip.KNOB_INPUT_MODE and v >= 0):
+                dfa.tune(knob, v)
+        for kv in a.knob:
+            k, v = kv.split("=")
+            dfa.tune(int(k), int(v))
+        if variant == "noskip":
+            dfa.tune(KNOB_NOSKIP, 1)
+        info = dfa.info()
+        nwords = (n_ + 63) // 64
+        bm = torch.zeros(nwords, dtype=torch.int64, device="cuda")
+        generate(hip, wl, buf.data_ptr(), n_, L, first_wl, words, buf)
+        torch.cuda.synchronize()
 
-    # N > 1: the all-gather of step k's bitmap runs on RCCL's stream while step k+1's walk kernel runs
-    # (two bitmap / gather buffers); every gather is waited for before the timed region ends.
-    bms = [bm, torch.zeros_like(bm)] if world > 1 else [bm]
-    gats = [gathered, torch.empty_like(gathered)] if world > 1 else [None]
-    pending = [None, None]
-    tick = [0]
+        # N > 1: the all-gather of step k's bitmap runs on RCCL's stream while step k+1's walk kernel runs
+        # (two bitmap / gather buffers); every gather is waited for before the timed region ends.
+        bms = [bm, torch.zeros_like(bm)] if world > 1 else [bm]
+        gats = [torch.empty(nwords * world, dtype=torch.int64, device="cuda") for _ in range(2)] if world > 1 else [None]
+        pending = [None, None]
+        tick = [0]
+        kernel_ms = []
 
-    def step(record):
-        k = tick[0] % len(bms)
-        tick[0] += 1
-        if world > 1 and pending[k] is not None:
-            pending[k].wait()      # stream-level: the gather that last read this bitmap buffer is done
-            pending[k] = None
-        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bms[k].data_ptr(), stream=stream)
-        if record:
-            kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
-        if world > 1:
-            # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
-            pending[k] = dist.all_gather_into_tensor(gats[k], bms[k], async_op=True)
-
-    def drain():
-        for k in range(len(pending)):
-            if pending[k] is not None:
-                pending[k].wait()
+        def step(record):
+            k = tick[0] % len(bms)
+            tick[0] += 1
+            if world > 1 and pending[k] is not None:
+                pending[k].wait()      # stream-level: the gather that last read this bitmap buffer is done
                 pending[k] = None
+            dfa.exec_batch_device(buf.data_ptr(), L, n_, end.data_ptr(), bms[k].data_ptr(), stream=stream)
+            if record:
+                kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
+            if world > 1:
+                # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
+                pending[k] = dist.all_gather_into_tensor(gats[k], bms[k], async_op=True)
 
-    for _ in range(4):  # setup, untimed: the first launches after a long generator kernel run at ramping clocks
-        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr(), stream=stream)
-    for _ in range(a.warmup):
-        step(False)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+        def drain():
+            for k in range(len(pending)):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
 
-    accepts = int((end != -1).sum().item())
-    acc_t = torch.tensor([accepts], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(acc_t)
+        for _ in range(4):  # setup, untimed: the first launches after a long generator kernel run at ramping clocks
+            dfa.exec_batch_device(buf.data_ptr(), L, n_, end.data_ptr(), bm.data_ptr(), stream=stream)
+        for _ in range(a.warmup):
+            step(False)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(True)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+        acc_t = (end != -1).sum().to(torch.int64).reshape(1)
+        if world > 1:
+            dist.all_reduce(acc_t)
+        if rank != 0:
+            dfa.close()
+            return None
+
+        ms_step = elapsed / a.steps * 1e3
+        value = float(n_) * L * world / (elapsed / a.steps) / 1e9
+        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = float(n_) * (L + 4)  # SURVEY.md 8(d): L bytes read + 4 B end state written per input
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 passes (tools/profile.sh),
+        # never inside this run -- quoted only when the recorded launch is the same workload, size and kernel
+        traffic, traffic_source = None, None
+        pj = os.path.join(ROOT, "profiles", f"pmc_{wl}.json")
+        if variant is None and os.path.exists(pj):
+            try:
+                t = json.load(open(pj))
+                if int(t.get("n", 0)) == n_ and int(t.get("len", 0)) == L:
+                    traffic = t.get("hbm_bytes_per_launch")
+                    traffic_source = (f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over this "
+                                      f"workload at this size (kernel {str(t.get('kernel'))[:60]}); recorded, not measured in this run")
+            except Exception:
+                traffic = None
+        text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl == "c3" else (len(words), flat.nstates) if wl == "c5" else ())
+        if variant == "noskip":
+            text += "chunk skip disabled (every byte pays its self-loop test: the transition-dense bound of this table), "
+        res = {
+            "value": round(value, 2), "ms_per_step": round(ms_step, 4),
+            "config": {
+                "workload": text + f"{n_} x {L} B synthetic inputs per GPU resident in HBM, 64 inputs/wavefront",
+                "inputs_per_gpu": n_, "input_len": L, "dfa_states": flat.nstates, "byte_classes": info["nclasses"],
+                "table_layout": info["layout_name"], "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"],
+                "waves_per_block": info["waves_per_block"],
+                "sharding": (f"{world} contiguous index ranges ({a.scaling} scaling); RCCL all-gather of each step's accept bitmap, overlapped with the next step's walk"
+                             if world > 1 else "single GPU"),
+                "accepted_inputs": int(acc_t.item()),
+            },
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if wl == "c5":
+            res["roofline"]["note"] = ("this walk is bound by dependent L2 gathers, not by HBM (DESIGN.md section 3; profiles/r02*_c5_*): "
+                                       "the fraction of HBM peak is reported for uniformity only")
+        if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
+            sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if wl == "c2" else 100_000)
+            idx = sample_indices(n_, sample)
+            tidx = torch.from_numpy(idx).cuda()
+            rows = buf[tidx].cpu().numpy()                              # the bytes the GPU walked
+            cb, parity = cpu_baseline(hip, wl, flat, L, rows, end[tidx].cpu().numpy().view(np.uint32), words)
+            # the device rows are what the host generator produces for the same indices (spot check on a run)
+            lo = int(idx[len(idx) // 2])
+            cnt = min(256, n_ - lo)
+            twin = bool(np.array_equal(buf[lo:lo + cnt].cpu().numpy(), generate_host(hip, wl, cnt, L, first_wl + lo, words)))
+            res["cpu_baseline"] = cb
+            res["parity_vs_cpu_sample"] = "bit-exact" if parity and twin else "MISMATCH"
+            res["parity_sample"] = f"{len(idx)} inputs: seeded stride over [0, {n_}) + first/last 64 rows" + (" + rows around byte offset 2^32" if n_ > (1 << 22) + 64 else "")
+            if not (parity and twin):
+                res["value"] = None  # a fast wrong answer is not a result
+        if a.full_parity and world == 1 and wl != "c5":
+            res["full_parity"] = full_parity(torch, flat, buf, end, n_, L)
+            if res["full_parity"]["mismatches"]:
+                res["value"] = None
+        res["_buf"] = (buf, bm)
+        dfa.close()
+        return res
+
+    main_res = run(a.workload)
+    subs = []
+    if world == 1 and a.subs == "auto" and a.n == 0 and not shrunk:
+        plan = []
+        if a.workload == "c3":
+            plan.append(("c3", "noskip", None))
+        for wl in ("c3", "c2", "c5"):
+            if wl != a.workload:
+                plan.append((wl, None, default_n(wl)))
+        for wl, variant, n_wl in plan:
+            r = run(wl, variant, n_wl, with_cpu=(variant is None))
+            r.pop("_buf", None)
+            r["workload"] = wl + ("_" + variant if variant else "")
+            subs.append(r)
+        # leave the main workload's inputs in the buffer for the stream probe below
     if rank != 0:
         if world > 1:
             dist.barrier()   # leave together with rank 0, which still probes the stream rate and prints
             dist.destroy_process_group()
         return
 
+    buf, bm = main_res.pop("_buf")
     stream_gbps = None
-    try:  # what a trivially coalesced read-only kernel sustains over the same resident buffer
-        stream_gbps = hip.stream_read_probe_gbps(buf.data_ptr(), n * L, bm.data_ptr(), 3, stream)
+    try:  # what a read-only kernel sustains over the same resident bytes (three access patterns, the fastest)
+        stream_gbps = hip.stream_read_probe_gbps(buf.data_ptr(), buf.numel(), bm.data_ptr(), 3, stream)
     except Exception:
         pass
-    ms_step = elapsed / a.steps * 1e3
-    total_bytes = float(n) * L * world
-    value = total_bytes / (elapsed / a.steps) / 1e9
-    k_ms = float(np.mean(kernel_ms))
-    alg_bytes = float(n) * (L + 4)  # L bytes read + 4 B end state written per input
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", f"pmc_{a.workload}.json")
-    if os.path.exists(pj):
-        try:
-            t = json.load(open(pj))
-            if int(t.get("n", 0)) == n and int(t.get("len", 0)) == L:
-                traffic = t.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
     res = {
-        "metric": "input GB/s matched (whole node)", "value": round(value, 2), "unit": "GB/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {
-            "workload": ("c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), "
-                         if a.workload == "c2" else
-                         "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, " % flat.nstates
-                         if a.workload == "c3" else
-                         "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), " % (len(words), flat.nstates))
-                        + f"{n} x {L} B synthetic inputs per GPU resident in HBM, 64 inputs/wavefront",
-            "inputs_per_gpu": n, "input_len": L, "dfa_states": flat.nstates, "byte_classes": info["nclasses"],
-            "table_layout": info["layout_name"], "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"],
-            "waves_per_block": info["waves_per_block"], "sharding": f"{world} contiguous index ranges; RCCL all-gather of each step's accept bitmap, overlapped with the next step's walk" if world > 1 else "single GPU",
-            "accepted_inputs": int(acc_t.item()), "requested_inputs_per_gpu": requested,
-        },
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "measured_read_stream_GBps": None if stream_gbps is None else round(stream_gbps, 1),
-                     "frac_of_measured_stream": None if not stream_gbps else round(achieved / stream_gbps, 4),
-                     "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
-                     "algorithmic_bytes_per_launch": alg_bytes},
+        "metric": "input GB/s matched (whole node)", "value": main_res["value"], "unit": "GB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": dict(main_res["config"], requested_inputs_per_gpu=requested if a.scaling == "weak" else requested // world),
+        "roofline": dict(main_res["roofline"],
+                         measured_read_stream_GBps=None if stream_gbps is None else round(stream_gbps, 1),
+                         frac_of_measured_stream=None if not stream_gbps else round(main_res["roofline"]["achieved"] / stream_gbps, 4)),
     }
-    if a.workload == "c5":
-        res["roofline"]["note"] = ("this walk is bound by L2 gather requests, not by HBM: profiles/r01g_c5_rocprof_summary.json "
-                                   "(TCC_REQ 6.96e9 per 1e7 x 1 KiB launch = 205 G requests/s, 96.5 % hits; a 4-byte gather test peaks "
-                                   "at ~265 G/s, profiles/r01_c5_global_hot.txt); HBM traffic is 3.0x the input bytes")
-    if world == 1 and not a.no_cpu_baseline and a.cpu_sample != 0:
-        sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if a.workload == "c2" else 100_000)
-        sample = min(sample, n)
-        cb, parity = cpu_baseline(hip, a.workload, flat, L, sample, end[:sample].cpu().numpy().view(np.uint32), words)
-        res["cpu_baseline"] = cb
-        res["parity_vs_cpu_sample"] = "bit-exact" if parity else "MISMATCH"
-        if not parity:
-            res["value"] = None  # a fast wrong answer is not a result
+    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity"):
+        if k in main_res:
+            res[k] = main_res[k]
+    if subs:
+        res["sub_results"] = subs
+        if any(s.get("parity_vs_cpu_sample") == "MISMATCH" for s in subs):
+            res["value"] = None
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -28,7 +28,8 @@ enum {
 	FSM_HIP_KNOB_HOT_BYTES     = 8,  /* global layout: bytes of the table head mirrored in LDS        */
 	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */
 	FSM_HIP_KNOB_PREFETCH      = 10, /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
-	FSM_HIP_KNOB_NT            = 11  /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
+	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
+	FSM_HIP_KNOB_NOSKIP        = 13  /* 1: self-loop layouts never skip a whole chunk (measurement aid: every byte pays its test) */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);

@@ -68,6 +68,7 @@ struct fsm_hip_dfa {
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
+	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
 	unsigned flags = 0;
 };
 
@@ -491,6 +492,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
+	if (d->knob_noskip > 0) a.early |= 4u;
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events are per dfa */
 	hipError_t e = hipSuccess;
@@ -770,6 +772,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_WAVES: d->knob_waves = value; break;
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
+	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
 	default: errno = EINVAL; return -1;
 	}
 	return 0;

@@ -72,7 +72,8 @@ struct WalkArgs {
 	uint32_t        abs_min;  /* encoded states >= abs_min are absorbing              */
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
 	uint32_t        early;    /* bit 0: retire a wavefront once every lane is absorbing;
-	                           * bit 1: absorbing lanes stop loading their input        */
+	                           * bit 1: absorbing lanes stop loading their input;
+	                           * bit 2: never skip a chunk (skip16 off: measurement aid) */
 	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
 	const uint32_t *fin2;     /* optional second per-state table (end-id / ret index) */
 	uint32_t       *out2;     /* n entries, written from fin2, or NULL                */
@@ -270,6 +271,7 @@ struct LdsSelfPol {
 	const uint8_t *bp;
 	const unsigned char *tab;
 	uint32_t smoff;   /* offset of the mask inside a row */
+	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
@@ -278,6 +280,7 @@ struct LdsSelfPol {
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		tab = lds + FSMHIP_BTAB_BYTES;
 		smoff = a.fin_div - 4u;   /* fin_div = row bytes */
+		skip_on = !(a.early & 4u);
 	}
 	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, mask_of(code) }; return s; }
@@ -289,7 +292,7 @@ struct LdsSelfPol {
 		uint32_t m = 0;
 #pragma unroll
 		for (int k = 0; k < 16; k++) m |= 1u << c[k];
-		return __all((m & ~s.sm) == 0u);
+		return skip_on && __all((m & ~s.sm) == 0u);
 	}
 	__device__ __forceinline__ S next(S s, P c) const
 	{
@@ -374,6 +377,7 @@ struct CombSelfPol {
 	const uint2 *dsm;       /* LDS [32]: {row offset, self-loop mask} of each class's default state */
 	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
 	uint32_t start, start_sm;
+	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
@@ -386,6 +390,7 @@ struct CombSelfPol {
 		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
 		start = a.start;
 		start_sm = smask0[a.start];
+		skip_on = !(a.early & 4u);
 	}
 	/* every input starts from the start state unless it is resumed: its mask is fetched once per
 	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
@@ -404,7 +409,7 @@ struct CombSelfPol {
 		uint32_t m = 0;
 #pragma unroll
 		for (int k = 0; k < 16; k++) m |= 1u << c[k];
-		return __all((m & ~s.sm) == 0u);
+		return skip_on && __all((m & ~s.sm) == 0u);
 	}
 	__device__ __forceinline__ S next(S s, P c) const
 	{

@@ -61,7 +61,16 @@ ar rcs "$OUT/libfsmre.a" "$OUT"/obj/*.o
 # -Bsymbolic: libfsm's re_comp() would otherwise be interposed by glibc's BSD
 # re_comp() once loaded into a process such as python.
 gcc -std=c99 -O2 -fPIC -D_POSIX_C_SOURCE=200809L -I$R/include -c "$HERE/ref_helper.c" -o "$OUT/ref_helper.o"
-gcc -shared -Wl,-Bsymbolic -o "$OUT/libfsm_ref.so" -Wl,--whole-archive "$OUT/libfsmre.a" -Wl,--no-whole-archive "$OUT/ref_helper.o" -lpthread
+# fsm_exec_hoisted(): NOT the reference -- fsm_exec (src/libfsm/exec.c:85-167) with the per-call
+# `fsm_all(fsm, fsm_isdfa)` block of :106-109 removed, derived here from a scratch copy so that nothing of
+# the reference is stored in the repository.  One of bench.py's CPU baseline lines (SURVEY.md 8(d) line 2).
+mkdir -p "$OUT/aux"
+sed -e 's/^fsm_exec(/fsm_exec_hoisted(/' \
+    -e '/if (!fsm_all(fsm, fsm_isdfa)) {/,/^\t}$/d' "$R/src/libfsm/exec.c" > "$OUT/aux/exec_hoisted.c"
+grep -q 'fsm_exec_hoisted(' "$OUT/aux/exec_hoisted.c" && ! grep -q 'fsm_isdfa' "$OUT/aux/exec_hoisted.c"
+gcc $CF -c "$OUT/aux/exec_hoisted.c" -o "$OUT/aux/exec_hoisted.o"
+rm -f "$OUT/aux/exec_hoisted.c"
+gcc -shared -Wl,-Bsymbolic -o "$OUT/libfsm_ref.so" -Wl,--whole-archive "$OUT/libfsmre.a" -Wl,--no-whole-archive "$OUT/ref_helper.o" "$OUT/aux/exec_hoisted.o" -lpthread
 gcc $CF -D_XOPEN_SOURCE=700 $R/src/re/main.c "$OUT/libfsmre.a" -o "$OUT/re"
 gcc -std=gnu99 -O2 -DNDEBUG -I$R/include -I$R/src $R/src/retest/main.c $R/src/retest/runner.c "$OUT/libfsmre.a" -ldl -o "$OUT/retest"
 echo "built: $(ls "$OUT"/obj/*.o | wc -l) objects -> $OUT/libfsmre.a, libfsm_ref.so, re, retest"

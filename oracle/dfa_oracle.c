@@ -26,6 +26,7 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include <errno.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -290,6 +291,79 @@ oracle_table_walk_stride(struct oracle_dfa *d, const unsigned char *base, size_t
 	}
 	return now_s() - t0;
 }
+
+/*
+ * The same dense-table walk on `nthreads` host threads over contiguous slices of the rows: the checker of
+ * bench.py's --full-parity leg ("full N compare GPU vs CPU table-walker"), where all N
+ * inputs are streamed back from the device and walked here.  The table walker is itself proven equal to
+ * the edge-group restatement (and so to fsm_exec) by tests/test_oracle.py.  Returns wall seconds.
+ */
+struct walk_job {
+	const struct oracle_dfa *d;
+	const unsigned char *base;
+	size_t stride, first, count;
+	uint32_t *end;
+};
+
+static void *
+walk_worker(void *opaque)
+{
+	struct walk_job *j = opaque;
+	const struct oracle_dfa *d = j->d;
+	const uint32_t S = d->statecount;
+	size_t i, t;
+	for (i = j->first; i < j->first + j->count; i++) {
+		const unsigned char *p = j->base + i * j->stride;
+		uint32_t st = d->start;
+		for (t = 0; t < j->stride; t++) {
+			st = d->dense[(size_t) st * 256 + p[t]];
+		}
+		j->end[i] = (st < S && d->states[st].end) ? st : 0xFFFFFFFFu;
+	}
+	return NULL;
+}
+
+double
+oracle_table_walk_stride_mt(struct oracle_dfa *d, const unsigned char *base, size_t stride, size_t n, uint32_t *end, int nthreads)
+{
+	pthread_t th[256];
+	struct walk_job jobs[256];
+	double t0;
+	int t, started = 0;
+
+	if (!d->hasstart || !build_dense(d)) {
+		return -1.0;
+	}
+	if (nthreads < 1) {
+		nthreads = 1;
+	}
+	if (nthreads > 256) {
+		nthreads = 256;
+	}
+	t0 = now_s();
+	for (t = 0; t < nthreads; t++) {
+		jobs[t].d = d;
+		jobs[t].base = base;
+		jobs[t].stride = stride;
+		jobs[t].first = n * (size_t) t / (size_t) nthreads;
+		jobs[t].count = n * (size_t) (t + 1) / (size_t) nthreads - jobs[t].first;
+		jobs[t].end = end;
+		if (pthread_create(&th[t], NULL, walk_worker, &jobs[t]) != 0) {
+			walk_worker(&jobs[t]);   /* no thread to be had: walk the slice here */
+			th[t] = (pthread_t) 0;
+			continue;
+		}
+		started |= 1;
+	}
+	for (t = 0; t < nthreads; t++) {
+		if (th[t] != (pthread_t) 0) {
+			pthread_join(th[t], NULL);
+		}
+	}
+	(void) started;
+	return now_s() - t0;
+}
+
 
 size_t
 oracle_endid_count(const struct oracle_dfa *d, uint32_t state)

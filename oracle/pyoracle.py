@@ -29,7 +29,7 @@ RE_STRINGS_ANCHOR_LEFT, RE_STRINGS_ANCHOR_RIGHT = 1, 2
 def build_oracle(force: bool = False) -> str:
     src = os.path.join(HERE, "dfa_oracle.c")
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", ORACLE_SO])
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", ORACLE_SO, "-lpthread"])
     return ORACLE_SO
 
 
@@ -129,6 +129,19 @@ class Oracle:
         self.last_seconds = self.lib().oracle_table_walk_stride(self._h, _p(data), stride, _p(lens), n, _p(end))
         if self.last_seconds < 0:
             raise RuntimeError("oracle_table_walk_stride")
+        return end
+
+    def table_walk_mt(self, data: np.ndarray, nthreads: int) -> np.ndarray:
+        """table_walk on nthreads host threads (contiguous slices); uniform rows only."""
+        lib = self.lib()
+        lib.oracle_table_walk_stride_mt.restype = C.c_double
+        lib.oracle_table_walk_stride_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        end = np.zeros(n, np.uint32)
+        self.last_seconds = lib.oracle_table_walk_stride_mt(self._h, _p(data), stride, n, _p(end), int(nthreads))
+        if self.last_seconds < 0:
+            raise RuntimeError("oracle_table_walk_stride_mt")
         return end
 
     def state_walk(self, data: np.ndarray, state_io: np.ndarray, lens=None) -> np.ndarray:
@@ -347,6 +360,47 @@ class RefFsm:
         ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
         self.last_seconds = Ref.libs()[1].rh_exec_batch_stride(self.ptr, _p(data), stride, n, _p(ret), _p(end))
         return ret, end
+
+    def exec_hoisted_stride(self, data: np.ndarray):
+        """fsm_exec with its per-call fsm_all(fsm_isdfa) check removed (NOT the reference: derived from
+        exec.c by oracle/build_ref.sh; SURVEY.md 8(d) CPU line 2)."""
+        _, H = Ref.libs()
+        H.rh_exec_hoisted_batch_stride.restype = C.c_double
+        H.rh_exec_hoisted_batch_stride.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
+        self.last_seconds = H.rh_exec_hoisted_batch_stride(self.ptr, _p(data), stride, n, _p(ret), _p(end))
+        return ret, end
+
+    def codegen_match_stride(self, data: np.ndarray, lang: str = "vmc", cflags=("-O3",), timeout: float = 120.0, comments: bool = False):
+        """What `retest -l vmc|c` runs (src/retest/runner.c:290-404): fsm_print() the DFA as C, compile it with
+        the host C compiler into a shared object, dlopen it and call fsm_main(b, e) per input.  Returns the 0/1
+        array (or None if printing / compiling failed or timed out); last_seconds = time inside the loop,
+        last_compile_seconds = fsm_print + cc."""
+        import tempfile
+        import time as _t
+        _, H = Ref.libs()
+        H.rh_print_matcher.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        H.rh_codegen_match_batch_stride.restype = C.c_double
+        H.rh_codegen_match_batch_stride.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        d = tempfile.mkdtemp(prefix="fsmcodegen")
+        src, so = os.path.join(d, "m.c"), os.path.join(d, "m.so")
+        t0 = _t.perf_counter()
+        if H.rh_print_matcher(self.ptr, 0 if lang == "vmc" else 1, int(comments), src.encode()) != 0:
+            return None
+        try:
+            subprocess.check_call([os.environ.get("CC", "gcc"), *cflags, "-shared", "-fPIC", "-w", src, "-o", so], timeout=timeout)
+        except (subprocess.SubprocessError, OSError):
+            return None
+        self.last_compile_seconds = _t.perf_counter() - t0
+        lib = C.CDLL(so)
+        fn = C.cast(lib.fsm_main, C.c_void_p)
+        data = np.ascontiguousarray(data, np.uint8)
+        n, stride = data.shape
+        ret = np.zeros(n, np.int8)
+        self.last_seconds = H.rh_codegen_match_batch_stride(fn, _p(data), stride, n, _p(ret))
+        return ret
 
     def endids(self, state: int) -> np.ndarray:
         _, H = Ref.libs()

@@ -22,6 +22,7 @@
 #include <fsm/fsm.h>
 #include <fsm/bool.h>
 #include <fsm/options.h>
+#include <fsm/print.h>
 #include <fsm/vm.h>
 #include <re/re.h>
 #include <re/strings.h>
@@ -525,5 +526,94 @@ rh_match_threads(const struct fsm_dfavm *vm, const struct fsm *fsm, const unsign
 	}
 	free(th);
 	free(jobs);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+
+/* ---- CPU baseline lines SURVEY.md section 8(d) asks for beside the literal fsm_exec ---------------- */
+
+/*
+ * (2) fsm_exec with its per-call precondition hoisted.  NOT the reference: build_ref.sh derives
+ * fsm_exec_hoisted() from the reference's src/libfsm/exec.c at build time (a sed of a scratch copy under
+ * oracle/_ref/obj/: the function renamed, the `if (!fsm_all(fsm, fsm_isdfa))` block of exec.c:106-109
+ * removed), so that the loop itself -- indirect getc, edge_set_find's linear scan -- is timed without the
+ * O(states) sweep that dominates big DFAs.  Same signature and results as fsm_exec on a DFA.
+ */
+int fsm_exec_hoisted(const struct fsm *fsm, int (*fsm_getc)(void *opaque), void *opaque,
+	fsm_state_t *end, struct fsm_capture *captures);
+
+double
+rh_exec_hoisted_batch_stride(const struct fsm *fsm, const unsigned char *base, size_t stride, size_t n,
+	int8_t *ret, uint32_t *end)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		struct span s;
+		fsm_state_t st = 0;
+		int r;
+		s.p = base + i * stride;
+		s.e = s.p + stride;
+		r = fsm_exec_hoisted(fsm, span_getc, &s, &st, NULL);
+		if (ret != NULL) {
+			ret[i] = (int8_t) r;
+		}
+		if (end != NULL) {
+			end[i] = r == 1 ? st : 0xFFFFFFFFu;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+/*
+ * (4) the generated matcher `retest -l vmc|c` compiles and dlopens (src/retest/runner.c:63-135, :290-404):
+ * fsm_print() with retest's own options (anonymous states, consolidated edges, comments, io = PAIR,
+ * src/retest/main.c:1225-1229) writes `int fsm_main(const char *b, const char *e)` to `path`; the
+ * caller compiles it with the C compiler and hands the dlsym'd function to rh_codegen_match_batch_stride.
+ * lang: 0 = FSM_PRINT_VMC, 1 = FSM_PRINT_C; comments: retest's opt.comments (example strings in the
+ * generated code; no effect on the matcher).  Returns 0, or -1 + errno.
+ */
+int
+rh_print_matcher(const struct fsm *fsm, int lang, int comments, const char *path)
+{
+	struct fsm_options opt;
+	FILE *f;
+	int e;
+
+	memset(&opt, 0, sizeof opt);
+	opt.anonymous_states = 1;
+	opt.consolidate_edges = 1;
+	opt.comments = comments != 0;   /* retest sets 1; the per-state example strings take minutes on a 4k-state DFA */
+	opt.io = FSM_IO_PAIR;
+	f = fopen(path, "w");
+	if (f == NULL) {
+		return -1;
+	}
+	if (lang == 0) {
+		fprintf(f, "#include <string.h>\n\n");   /* the vmc codegen may emit memcmp/strncmp (runner.c:81-84) */
+	}
+	e = fsm_print(f, fsm, &opt, NULL, lang == 0 ? FSM_PRINT_VMC : FSM_PRINT_C);
+	if (fclose(f) == EOF || e == -1) {
+		return -1;
+	}
+	return 0;
+}
+
+double
+rh_codegen_match_batch_stride(int (*fsm_main)(const char *, const char *), const unsigned char *base, size_t stride, size_t n,
+	int8_t *ret)
+{
+	struct timespec t0, t1;
+	size_t i;
+
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (i = 0; i < n; i++) {
+		const char *b = (const char *) base + i * stride;
+		ret[i] = (int8_t) (fsm_main(b, b + stride) != 0);
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
 	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
 }

@@ -833,7 +833,8 @@ def test_bench_two_ranks_share_one_gpu(hip):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--inputs", "262144"]
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2",
+           "--inputs", "262144"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -843,7 +844,15 @@ def test_bench_two_ranks_share_one_gpu(hip):
     assert r["config"]["inputs_per_gpu"] == 262144
     # every 8th input of the 2 x 262144 carries the planted match (plus chance matches)
     assert abs(r["config"]["accepted_inputs"] - 2 * 262144 // 8) < 64
-    assert "cpu_baseline" not in r
+    assert "cpu_baseline" not in r and "sub_results" not in r
+    # strong scaling: the same total split over the ranks; an --n that is not a multiple of 64 x ranks is rounded down
+    cmd[cmd.index("--master-port") + 1] = "29534"
+    cmd[-1] = "262200"
+    out = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["scaling"] == "strong" and r["config"]["inputs_per_gpu"] == 262144 // 2
+    assert abs(r["config"]["accepted_inputs"] - 262144 // 8) < 64
 
 
 def test_retest_style_c_driver(hip, tmp_path):

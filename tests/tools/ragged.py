@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tests/tools/ragged.py -- throughput of the ragged / packed front (walk_generic) on device-resident
-inputs: fixed stride with per-input lengths, and inputs packed back to back with an offsets array.
-Results are checked against the oracle on a sample."""
+"""tests/tools/ragged.py -- throughput of the ragged / packed front on device-resident inputs: fixed stride
+with per-input lengths, and inputs packed back to back with an offsets array; the coalesced lane-refilling
+kernel (walk_ragged, mode 3) next to per-lane loads (walk_generic, mode 2), at several workgroup sizes.
+Results are checked against the oracle on a sample and kernel against kernel on every input."""
 import os
 import sys
 
@@ -18,7 +19,7 @@ def main():
     from oracle.pyoracle import Oracle
     hip.load_library()
     torch.cuda.set_device(0)
-    n, L = 2_000_000, 1024
+    n, L = int(os.environ.get("RAGGED_N", 2_000_000)), 1024
     buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
     end = torch.empty(n, dtype=torch.int32, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -40,8 +41,11 @@ def main():
             idx = np.random.RandomState(0).randint(0, n, 1024)
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
-            for front, queue in (("stride+len", 1), ("stride+len", 0), ("packed", 1), ("packed", 0)):
-                dfa.tune(hip.KNOB_QUEUE, queue)
+            ref = None
+            for front, mode, waves in (("packed", 3, 0), ("packed", 3, 8), ("packed", 3, 6), ("packed", 3, 4), ("packed", 2, 0),
+                                       ("stride+len", 3, 0), ("stride+len", 2, 0)):
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, waves)
                 ms = []
                 for r in range(4):
                     if front == "packed":
@@ -53,7 +57,10 @@ def main():
                         ms.append(t)
                 torch.cuda.synchronize()
                 ok = np.array_equal(end.cpu().numpy().view(np.uint32)[idx], want)
-                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} queue={queue} ms={min(ms):8.3f} "
+                if ref is None:
+                    ref = end.clone()
+                ok = ok and bool(torch.equal(ref, end))
+                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode} waves={waves:2d} ms={min(ms):8.3f} "
                       f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
             dfa.close()
 

@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/gpu_session.sh -- one gpurun call's worth of work (run on the GPU box from the repo root):
+#   tools/gpu_session.sh <tag> [steps...]     steps: test bench ragged c5 eager
+# Every step runs under its own timeout and writes to gpurun_out/<tag>_*.
+TAG=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for step in "$@"; do
+	case $step in
+	test)   timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
+	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
+	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
+	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
+	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
+	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
+	esac
+done
