@@ -152,12 +152,15 @@ def host_cores():
 
 
 def sample_indices(n, sample):
-    """A seeded spread over the WHOLE index range [0, n) -- not a prefix: one random phase, a constant stride,
-    plus the first and last 64 rows (the last tile may be partial) and the rows either side of byte offset 2^32."""
+    """A seeded STRATIFIED sample over the whole index range [0, n) -- not a prefix, and not a constant stride
+    either (the generators are periodic in the index: every 2nd / 8th row is special): one uniformly random row
+    out of each of `sample` equal strata, plus the first and last 64 rows (the last tile may be partial) and the
+    rows either side of byte offset 2^32."""
     sample = max(1, min(sample, n))
-    stride = max(1, n // sample)
-    phase = int(np.random.RandomState(SEED & 0x7FFFFFFF).randint(stride))
-    idx = [phase + np.arange(sample, dtype=np.int64) * stride, np.arange(min(64, n)), np.arange(max(0, n - 64), n)]
+    rng = np.random.RandomState(SEED & 0x7FFFFFFF)
+    edges = np.linspace(0, n, sample + 1).astype(np.int64)
+    width = np.maximum(1, edges[1:] - edges[:-1])
+    idx = [edges[:-1] + (rng.randint(0, 1 << 62, sample, dtype=np.int64) % width), np.arange(min(64, n)), np.arange(max(0, n - 64), n)]
     if n > (1 << 22) + 64:
         idx.append(np.arange((1 << 22) - 32, (1 << 22) + 32))
     idx = np.unique(np.concatenate(idx))
@@ -453,7 +456,7 @@ def main():
             twin = bool(np.array_equal(buf[lo:lo + cnt].cpu().numpy(), generate_host(hip, wl, cnt, L, first_wl + lo, words)))
             res["cpu_baseline"] = cb
             res["parity_vs_cpu_sample"] = "bit-exact" if parity and twin else "MISMATCH"
-            res["parity_sample"] = f"{len(idx)} inputs: seeded stride over [0, {n_}) + first/last 64 rows" + (" + rows around byte offset 2^32" if n_ > (1 << 22) + 64 else "")
+            res["parity_sample"] = f"{len(idx)} inputs: seeded stratified sample of [0, {n_}) + first/last 64 rows" + (" + rows around byte offset 2^32" if n_ > (1 << 22) + 64 else "")
             if not (parity and twin):
                 res["value"] = None  # a fast wrong answer is not a result
         if a.full_parity and world == 1 and wl != "c5":

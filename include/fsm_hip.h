@@ -323,6 +323,54 @@ size_t fsm_hip_eager_words(const struct fsm_hip_dfa *dfa);   /* ceil(id_count / 
 uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *dfa, unsigned bit);
 
 /* ------------------------------------------------------------------ */
+/* multi-device front: one table replica per GPU of the node           */
+/* ------------------------------------------------------------------ */
+
+/* The path shards by input: inputs are independent and the table is small enough
+ * to replicate, so a node handle = one struct fsm_hip_dfa per device, and a batch of n inputs is split into
+ * contiguous index shards of whole bitmap words -- shard k = inputs [k*per, min(n, (k+1)*per)) with
+ * per = 64 * ceil(ceil(n/64) / ndev) -- each driven by its own host thread on its own device and stream.
+ * This is what lets a C host (rx, retest, re(1)) use all 8 GPUs without torch.distributed.
+ *
+ * devices == NULL or ndev == 0: every device of the node.  The list may repeat a device (several replicas on
+ * one GPU: a test rig).  NULL + errno as fsm_hip_dfa_create / fsm_hip_compile. */
+struct fsm_hip_node;
+
+struct fsm_hip_node *fsm_hip_node_create(const struct fsm_hip_dfa_desc *desc, unsigned flags, const int *devices, int ndev);
+struct fsm_hip_node *fsm_hip_node_compile(const struct fsm *fsm, unsigned flags, const int *devices, int ndev);
+void fsm_hip_node_free(struct fsm_hip_node *node);
+int fsm_hip_node_ndev(const struct fsm_hip_node *node);
+/* the k-th replica (borrowed: end-ids, ret sets, knobs, info are per replica and identical) */
+struct fsm_hip_dfa *fsm_hip_node_dfa(struct fsm_hip_node *node, int k);
+/* shard k of a batch of n inputs */
+void fsm_hip_node_shard(const struct fsm_hip_node *node, size_t n, int k, size_t *first, size_t *count);
+/* 1 if the device-resident exchange below runs over RCCL (distinct devices, librccl present), 0 if it is done
+ * with peer-to-peer copies */
+int fsm_hip_node_uses_rccl(const struct fsm_hip_node *node);
+
+/* fsm_hip_exec_batch / _offsets over the whole node: same arguments, same results.  Every device stages its
+ * own slice from the caller's pages and copies its results straight into the caller's arrays at the shard's
+ * offset -- no collective is needed for host-side results. */
+int fsm_hip_node_exec_batch(struct fsm_hip_node *node,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+int fsm_hip_node_exec_batch_offsets(struct fsm_hip_node *node,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+
+/* Device-resident shards (inputs generated or loaded on the GPUs): d_base[k] = shard k's rows on device k,
+ * uniform `stride`-byte inputs, 16-byte aligned.  d_end_out[k] (optional array, optional entries) receives
+ * shard k's end states on device k.  d_bitmap_all[k] (optional) is a buffer of
+ * fsm_hip_node_bitmap_words(node, n) words on device k: device k writes its slice at word k * (words / ndev)
+ * and ONE in-place ncclAllGather over RCCL/xGMI (the path's only collective) leaves the whole batch's accept
+ * bitmap on every device; *match_count (optional, needs d_bitmap_all) = accepted inputs of the whole batch,
+ * one ncclAllReduce of a u64.  Returns after every device has finished. */
+size_t fsm_hip_node_bitmap_words(const struct fsm_hip_node *node, size_t n);
+int fsm_hip_node_exec_batch_device(struct fsm_hip_node *node,
+	const void *const *d_base, size_t stride, size_t n,
+	uint32_t *const *d_end_out, uint64_t *const *d_bitmap_all, uint64_t *match_count);
+
+/* ------------------------------------------------------------------ */
 /* synthetic input generator (benchmarks and parity tests)            */
 /* ------------------------------------------------------------------ */
 

@@ -25,10 +25,12 @@ mkdir -p "$OUT/src/retest"
 cp "$R/src/retest/runner.c" "$R/src/retest/runner.h" "$R/src/retest/main.c" "$OUT/src/retest/"
 (cd "$OUT" && patch -p1 -s < "$HERE/impl_hip.patch")
 gcc -std=gnu99 -O2 -DNDEBUG -I"$R/include" -I"$R/src" -I"$ROOT/include" \
-	"$OUT/src/retest/main.c" "$OUT/src/retest/runner.c" "$ROOT/oracle/_ref/libfsmre.a" \
+	"$OUT/src/retest/main.c" "$OUT/src/retest/runner.c" \
+	-Wl,--whole-archive "$ROOT/oracle/_ref/libfsmre.a" -Wl,--no-whole-archive \
 	-rdynamic -L"$ROOT/libfsm_amd" -lfsm_hip -Wl,-rpath,'$ORIGIN/../../libfsm_amd' -Wl,-rpath-link,/opt/rocm/lib -ldl \
 	-o "$OUT/retest"
-# -rdynamic: libfsm is linked statically here, and libfsm_hip.so's shim finds libfsm's public functions
-# with dlsym(RTLD_DEFAULT, ...): the executable has to export them.
+# --whole-archive + -rdynamic: libfsm is linked statically here, and libfsm_hip.so's shim finds libfsm's
+# public functions with dlsym(RTLD_DEFAULT, ...): the executable has to contain and export all of them
+# (a plain static link drops the ones retest itself never calls, e.g. fsm_walk_edges).
 rm -rf "$OUT/src"   # the patched copies were only needed for the compile
 echo "built $OUT/retest"

@@ -556,6 +556,90 @@ class HipDfa:
         return buf[:n]
 
 
+class HipNode:
+    """struct fsm_hip_node *: one table replica per device, a batch sharded over them (include/fsm_hip.h)."""
+
+    def __init__(self, flat: FlatDfa, devices: Optional[Sequence[int]] = None, flags: int = 0):
+        self._lib = load_library()
+        lib = self._lib
+        lib.fsm_hip_node_create.restype = C.c_void_p
+        lib.fsm_hip_node_dfa.restype = C.c_void_p
+        lib.fsm_hip_node_bitmap_words.restype = C.c_size_t
+        d = flat.desc()
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        C.set_errno(0)
+        self._h = lib.fsm_hip_node_create(C.byref(d), C.c_uint(flags), devs, C.c_int(len(devices) if devices else 0))
+        if not self._h:
+            raise _oserr("fsm_hip_node_create")
+        self.ndev = int(lib.fsm_hip_node_ndev(C.c_void_p(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fsm_hip_node_free(C.c_void_p(self._h))
+            self._h = None
+
+    __del__ = close
+
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.fsm_hip_node_uses_rccl(C.c_void_p(self._h)))
+
+    def replica(self, k: int) -> "HipDfa":
+        """Borrowed view of the k-th replica (do not close it)."""
+        h = self._lib.fsm_hip_node_dfa(C.c_void_p(self._h), C.c_int(k))
+        if not h:
+            raise _oserr("fsm_hip_node_dfa")
+        r = HipDfa(handle=h)
+        r.close = lambda: None
+        r.__class__ = type("BorrowedHipDfa", (HipDfa,), {"__del__": lambda self: None})
+        return r
+
+    def shard(self, n: int, k: int):
+        f, c = C.c_size_t(), C.c_size_t()
+        self._lib.fsm_hip_node_shard(C.c_void_p(self._h), C.c_size_t(n), C.c_int(k), C.byref(f), C.byref(c))
+        return int(f.value), int(c.value)
+
+    def bitmap_words(self, n: int) -> int:
+        return int(self._lib.fsm_hip_node_bitmap_words(C.c_void_p(self._h), C.c_size_t(n)))
+
+    def exec_batch(self, data: np.ndarray, lens: Optional[np.ndarray] = None):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, stride = data.shape
+        end = np.empty(n, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_node_exec_batch(C.c_void_p(self._h), _ptr(data), C.c_size_t(stride), _ptr(lens), C.c_size_t(n), _ptr(end), _ptr(bm)) != 0:
+            raise _oserr("fsm_hip_node_exec_batch")
+        return end, bm
+
+    def exec_strings(self, strings: Sequence[bytes]):
+        off = np.zeros(len(strings) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in strings])
+        base = np.frombuffer(b"".join(strings) or b"\0", dtype=np.uint8)
+        n = len(strings)
+        end = np.empty(n, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64)
+        C.set_errno(0)
+        if self._lib.fsm_hip_node_exec_batch_offsets(C.c_void_p(self._h), _ptr(base), _ptr(off), C.c_size_t(n), _ptr(end), _ptr(bm)) != 0:
+            raise _oserr("fsm_hip_node_exec_batch_offsets")
+        return end, bm
+
+    def exec_batch_device(self, d_base: Sequence[int], stride: int, n: int, d_end: Optional[Sequence[int]] = None,
+                          d_bitmap_all: Optional[Sequence[int]] = None, want_count: bool = False):
+        g = self.ndev
+        vp = C.c_void_p * g
+        base = vp(*[C.c_void_p(x) for x in d_base])
+        ends = vp(*[C.c_void_p(x or None) for x in d_end]) if d_end is not None else None
+        bms = vp(*[C.c_void_p(x) for x in d_bitmap_all]) if d_bitmap_all is not None else None
+        cnt = C.c_uint64(0)
+        C.set_errno(0)
+        if self._lib.fsm_hip_node_exec_batch_device(C.c_void_p(self._h), base, C.c_size_t(stride), C.c_size_t(n), ends, bms,
+                                                    C.byref(cnt) if want_count else None) != 0:
+            raise _oserr("fsm_hip_node_exec_batch_device")
+        return int(cnt.value) if want_count else None
+
+
 def _gen_args(alphabet, plant):
     a = np.frombuffer(bytes(alphabet), dtype=np.uint8).copy() if alphabet else None
     p = np.frombuffer(bytes(plant), dtype=np.uint8).copy() if plant else None

@@ -459,12 +459,13 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
 	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
-	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12,
-	 * eager ragged / generic 8. */
+	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12 for the
+	 * two-word-state policies (launch.h eager_dma_threads), eager ragged / generic 8. */
 	int wmax = 16;
 	if (mode == IN_RAGGED) wmax = eager ? 8 : 12;
 	else if (eager && mode == IN_GENERIC) wmax = 8;
-	else if (eager && mode == IN_LDSDMA) wmax = 12;
+	else if (eager && mode == IN_LDSDMA)
+		wmax = (layout == FSM_HIP_LAYOUT_TINY && d->plan.tiny5_col.empty()) || layout == FSM_HIP_LAYOUT_LDSSELF || layout == FSM_HIP_LAYOUT_COMBSELF ? 12 : 16;
 	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16) waves = d->knob_waves;

@@ -66,9 +66,15 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	return launch_fn(k, c, a, grid, block, s);
 }
 
-/* eager-output walks: the policy wrapped; the register-set form also behind LDS-DMA (128-byte
- * segments, 12 waves at most so that the set and the tile fit the register file without spills) */
-template <class EP, bool DMA>
+/* thread cap of the eager LDS-DMA kernel: 16 waves (<= 128 VGPRs) unless the policy carries two words of
+ * state or 64-bit lookups next to the 64-bit id set -- those spilled 2-8 VGPRs at 128 and get 12 waves */
+template <class Pol> struct eager_dma_threads { static constexpr int value = 1024; };
+template <> struct eager_dma_threads<TinyPol<uint64_t>> { static constexpr int value = 768; };
+template <> struct eager_dma_threads<LdsSelfPol> { static constexpr int value = 768; };
+template <> struct eager_dma_threads<CombSelfPol> { static constexpr int value = 768; };
+
+/* eager-output walks: the policy wrapped; the register-set form also behind LDS-DMA (128-byte segments) */
+template <class EP, bool DMA, int DMAT>
 static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	walk_fn k = nullptr;
@@ -76,7 +82,7 @@ static hipError_t launch_eager_pol(const LaunchCfg &c, const WalkArgs &a, dim3 g
 	case IN_RAGGED:  k = walk_ragged<EP, 512>; break;
 	case IN_GENERIC: k = walk_generic<EP, 512>; break;
 	case IN_LDSDMA:
-		if (DMA) { k = walk_ldsdma<EP, 128, 2, 768>; break; }
+		if constexpr (DMA) { k = walk_ldsdma<EP, 128, 2, DMAT>; break; }   /* wide sets: per-lane loads (pick_cfg never asks) */
 		/* fallthrough */
 	default: k = walk_direct<EP, 4, 1>; break;
 	}
@@ -87,8 +93,8 @@ template <class Pol>
 static hipError_t launch_family(int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	if (eager == 0) return launch_pol<Pol>(c, a, grid, block, s);
-	if (eager == 1) return launch_eager_pol<EagerPol<Pol>, true>(c, a, grid, block, s);
-	return launch_eager_pol<EagerWidePol<Pol>, false>(c, a, grid, block, s);
+	if (eager == 1) return launch_eager_pol<EagerPol<Pol>, true, eager_dma_threads<Pol>::value>(c, a, grid, block, s);
+	return launch_eager_pol<EagerWidePol<Pol>, false, 1024>(c, a, grid, block, s);
 }
 
 } // namespace fsmhip

@@ -437,6 +437,17 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		return k;
 	};
 	const uint32_t thr = C / 2u;
+	auto consec_vs = [&](uint32_t a, uint32_t b) {
+		const uint32_t *ra = row(a), *rb = row(b);
+		uint32_t first = NONE, k = 0;
+		for (uint32_t c = 0; c < C; c++) {
+			if (ra[c] == rb[c]) continue;
+			if (first == NONE) first = ra[c];
+			if (ra[c] != first + k) return false;
+			k++;
+		}
+		return k != 0;
+	};
 	for (uint32_t n : order) {
 		done[n] = 1;
 		if (n == p.start || parent[n] == NONE || p.start >= N) continue;
@@ -446,8 +457,12 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		vb[n] = cand;
 		if (chain[cand] >= 6) cand = p.start;
 		uint32_t k = diff(n, cand);
-		if (k > thr && cand != p.start) { cand = p.start; k = diff(n, cand); }
-		if (k > thr) continue;
+		/* a row that differs from its base on many classes still makes a 16-byte record when the
+		 * differing targets are consecutive ids (CONSEC, below): a trie node with all 64 children costs
+		 * a record, not a 260-byte dense row -- which is what lets every depth-2 record of the 1e5-literal
+		 * automaton stay in LDS */
+		if (k > thr && !consec_vs(n, cand) && cand != p.start) { cand = p.start; k = diff(n, cand); }
+		if (k > thr && !consec_vs(n, cand)) continue;
 		base[n] = cand;
 		nexc[n] = k;
 		chain[n] = (uint8_t)(chain[cand] + 1);

@@ -309,6 +309,24 @@ fsm_hip_compile(const struct fsm *fsm, unsigned flags)
 	return dfa;
 }
 
+struct fsm_hip_node *
+fsm_hip_node_compile(const struct fsm *fsm, unsigned flags, const int *devices, int ndev)
+{
+	struct fsm_hip_dfa_desc *desc;
+	struct fsm_hip_node *node;
+	int e;
+
+	desc = fsm_hip_flatten(fsm);
+	if (desc == NULL) {
+		return NULL;
+	}
+	node = fsm_hip_node_create(desc, flags, devices, ndev);
+	e = errno;
+	fsm_hip_desc_free(desc);
+	errno = e;
+	return node;
+}
+
 /* ---- single-input fronts (batch of one on the GPU) ------------------ */
 
 int

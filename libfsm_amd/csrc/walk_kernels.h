@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 {
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
-		const typename Pol::S nx = pol.next(st, pol.pre(byte_of(w, k)));
+		const typename Pol::S nx = pol.next(st, pre_of(pol, w, k, 0));
 		st = pick(((uint32_t)k - lo) < cnt, nx, st); /* k < lo wraps: fails the test */
 	}
 }
@@ -1209,25 +1209,35 @@ walk_ragged(const WalkArgs a)
 			spend = (uint32_t)c;
 		}
 
-		/* walk the segment in hand */
+		/* walk the segment in hand.  Only the first chunk of an input (its bytes start `head` bytes into
+		 * an aligned chunk) and its last one can be partial: those two take one predicated step each per
+		 * segment -- before and after the loop over the full chunks, for all lanes at once -- instead of
+		 * predicating every byte of every chunk (with 64 ragged lanes some lane is nearly always in a
+		 * partial chunk: the first version of this kernel spent 7 VALU operations per byte on that). */
 		if (tile && have) {
+			const uint32_t c_lo = head != 0u ? 1u : 0u;      /* first full chunk of the input */
+			const uint32_t c_hi = (uint32_t)(span >> 4);     /* one past its last full chunk = index of the tail */
+			if (kpos == 0u && head != 0u)
+				step16_part(pol, st, w[0], head, (span < 16u ? (uint32_t)span : 16u) - head);
+			u32x4 tw = w[0];
 #pragma unroll
 			for (uint32_t p = 0; p < 8; p++) {
 				const uint32_t k = kpos + p;
-				if (k < nch) {
-					const uint32_t lo = k == 0 ? head : 0u;
-					const uint64_t left = span - (uint64_t)k * 16u;
-					const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
-					if (__all(lo == 0u && hi == 16u)) {
-						typename Pol::S s1[1] = { st };
-						const u32x4 w1[1] = { w[p] };
-						step16<Pol, 1>(pol, s1, w1);
-						st = s1[0];
-					} else {
-						step16_part(pol, st, w[p], lo, hi - lo);
-					}
+				if (k >= c_lo && k < c_hi) {
+					typename Pol::S s1[1] = { st };
+					const u32x4 w1[1] = { w[p] };
+					step16<Pol, 1>(pol, s1, w1);
+					st = s1[0];
+				}
+				if (p != 0u) {
+					const bool is_tail = k == c_hi;
+					tw.x = is_tail ? w[p].x : tw.x; tw.y = is_tail ? w[p].y : tw.y;
+					tw.z = is_tail ? w[p].z : tw.z; tw.w = is_tail ? w[p].w : tw.w;
 				}
 			}
+			const uint32_t tail = (uint32_t)span & 15u;
+			if (tail != 0u && c_hi >= c_lo && c_hi >= kpos && c_hi < kpos + 8u)
+				step16_part(pol, st, tw, 0u, tail);
 		}
 		if (fin) {
 			write_result_lane(a, ci, Pol::code(st));

@@ -112,8 +112,29 @@ main(void)
 	}
 	assert(npass >= 6);
 
+	/* the node front: one replica per listed device (this rig lists its one GPU twice), the batch sharded
+	 * over them, results in the caller's arrays: identical to the single-dfa batch */
+	{
+		static const int devs[2] = { 0, 0 };
+		struct fsm_hip_node *node = fsm_hip_node_compile(fsm, 0, devs, 2);
+		uint32_t end2[NI];
+		uint64_t bitmap2[(NI + 63) / 64];
+		size_t first, count;
+		fsm_state_t conflict = 0;
+		assert(node != NULL && fsm_hip_node_ndev(node) == 2);
+		fsm_hip_node_shard(node, NI, 0, &first, &count);
+		assert(first == 0 && count == NI);           /* fewer than 64 inputs: one shard holds them all */
+		assert(fsm_hip_node_exec_batch_offsets(node, buf, off, NI, end2, bitmap2) == 0);
+		assert(memcmp(end, end2, sizeof end) == 0 && bitmap[0] == bitmap2[0]);
+		/* AMBIG_ERROR: "abc" is accepted by ^abc$, ^ab*c$ and ^a.c$ -- an end state with three ids */
+		assert(fsm_hip_ids_conflict(fsm_hip_node_dfa(node, 1), &conflict) == 1);
+		assert(fsm_hip_endid_count(dfa, conflict) > 1);
+		fsm_hip_node_free(node);
+	}
+
 	fsm_free(fsm); /* the device table is self-contained (retest frees the fsm early, main.c:1056-1058) */
 	assert(fsm_hip_match_buffer(dfa, "abc", 3) == 1);
+	assert(fsm_hip_state_is_absorbing(dfa, FSM_HIP_STATE_DEAD) == 1);
 	fsm_hip_dfa_free(dfa);
 	printf("PASS %d/%d inputs matched, fsm_exec == fsm_hip on all\n", npass, (int) NI);
 	return EXIT_SUCCESS;

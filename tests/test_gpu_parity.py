@@ -465,8 +465,8 @@ def test_device_side_endids(hip):
             e1 = dfa.exec_batch_ids(rows, 1, lens)
             e2 = dfa.exec_batch_ids(rows, 2, lens)
             sets = dfa.ret_sets()
-            # retlist order: by count, then lexicographic; unique
-            keys = [(len(s), tuple(int(x) for x in s)) for s in sets]
+            # retlist order (cmp_ret, src/libfsm/vm/retlist.c:63-79): by count, then memcmp of the uint32 ids; unique
+            keys = [(len(s), np.asarray(s, "<u4").tobytes()) for s in sets]
             assert keys == sorted(set(keys))
             for i in range(len(rows)):
                 want = g.ids_of(i)

@@ -57,7 +57,7 @@ def test_eager_outputs_fast_kernels_golden_dfas(hip):
     and the ragged and generic ones on the same rows: ids and end states against the oracle."""
     from oracle.pyoracle import Oracle
     rng = np.random.RandomState(77)
-    n_checked = 0
+    n_checked = n_fired = 0
     for path in eager_golden_paths():
         g = Golden(path)
         pats = [p.encode("latin1").strip(b"^$") for p in g.meta["patterns"]]
@@ -69,7 +69,7 @@ def test_eager_outputs_fast_kernels_golden_dfas(hip):
                 at = rng.randint(0, 256 - len(p))
                 rows[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
         wret, wend, wsets = Oracle(g.flat).exec_eager(rows)
-        assert sum(len(s) for s in wsets) > 0
+        n_fired += sum(len(s) for s in wsets)
         for lname in EAGER_LAYOUTS:
             try:
                 dfa = hip.HipDfa(g.flat, getattr(hip, "LAYOUT_" + lname))
@@ -84,7 +84,7 @@ def test_eager_outputs_fast_kernels_golden_dfas(hip):
                     assert np.array_equal(sets[i], wsets[i]), (g.meta["source"], lname, mode, waves, i)
                 n_checked += len(rows)
             dfa.close()
-    assert n_checked > 100000
+    assert n_checked > 100000 and n_fired > 2000
 
 
 @pytest.mark.parametrize("nids", [40, 64, 65, 300])
@@ -123,13 +123,15 @@ def test_eager_outputs_fast_kernels_random_dfas(hip, nids):
 
 
 def test_eager_union_in_a_comb_layout_live_reference(hip):
-    """An anchored eager union built by the reference (fsm_union_repeated_pattern_group) that lands in a comb
-    layout: before round 2 the planner sent every eager DFA that was not tiny/lds to `global`."""
+    """A start-anchored eager union built by the reference (fsm_union_repeated_pattern_group) that lands in a
+    comb layout (AUTO picks combself for it): before round 2 the planner sent every eager DFA that was not
+    tiny/lds to `global`."""
     _need_ref()
     from oracle.pyoracle import RefFsm
     rng = np.random.RandomState(4)
     alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
-    pats = sorted(set(b"^" + bytes(alpha[rng.randint(0, 26, 3)]) + b"[0-9]+(x|yz)$" for _ in range(48)))[:40]
+    # anchored at the start only: a pattern anchored at both ends yields an end-id, not an eager output
+    pats = sorted(set(b"^" + bytes(alpha[rng.randint(0, 26, 3)]) + b"[0-9]+(x|yz)" for _ in range(48)))[:40]
     f = RefFsm.union_repeated("pcre", pats, 1, False)
     strings = []
     for i in range(900):
@@ -481,7 +483,7 @@ def test_retest_l_hip(hip, tmp_path):
     tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     for impl in ("hip", "vm"):
-        out = subprocess.run([exe, "-l", impl, str(tst)], capture_output=True, text=True, env=env, timeout=600)
+        out = subprocess.run([exe, "-l", impl, str(tst)], capture_output=True, text=True, errors="replace", env=env, timeout=600)
         tail = out.stdout.strip().splitlines()[-2:]
         assert out.returncode == 0, (impl, out.stdout[-1500:], out.stderr[-1500:])
         assert tail[0].endswith("37 regexps, 115 test cases") and tail[1].endswith("0 re errors, 0 errors"), (impl, tail)
@@ -490,6 +492,77 @@ def test_retest_l_hip(hip, tmp_path):
     bad = tmp_path / "bad.tst"
     bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
     for impl in ("hip", "vm"):
-        out = subprocess.run([exe, "-l", impl, str(bad)], capture_output=True, text=True, env=env, timeout=600)
+        out = subprocess.run([exe, "-l", impl, str(bad)], capture_output=True, text=True, errors="replace", env=env, timeout=600)
         assert out.returncode == 1 and out.stdout.count("[NOT OK]") == 1, (impl, out.stdout[-800:])
         assert out.stdout.strip().splitlines()[-1].endswith("0 re errors, 1 errors")
+
+
+# ---------------------------------------------------------------------------
+# multi-device front (C ABI): one replica per device, one host thread per device
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_node_front_shards_and_gathers(hip, devices):
+    """fsm_hip_node_*: the batch is split into contiguous shards of whole bitmap words, one per replica, each
+    driven by its own host thread.  This box has one GPU, so [0] exercises the RCCL path (a communicator of one:
+    ncclAllGather / ncclAllReduce are really called) and [0, 0] / [0, 0, 0] put several replicas on it and take
+    the peer-copy exchange.  Host-pointer fronts (stride + lengths, packed) and the device-resident front with
+    the whole-batch bitmap and match count on every replica: all against the oracle."""
+    import torch
+    import bench
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g.flat)
+    node = hip.HipNode(g.flat, devices)
+    assert node.ndev == len(devices)
+    assert node.uses_rccl() == (len(devices) == 1)
+    rng = np.random.RandomState(len(devices))
+    # shards: contiguous, whole words, cover [0, n)
+    for n in (1, 63, 64, 65, 1000, 100_003):
+        cover = 0
+        for k in range(node.ndev):
+            f, c = node.shard(n, k)
+            assert f == cover and (f % 64 == 0)
+            cover += c
+        assert cover == n
+    # host pointers, ragged rows
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    rows = a[rng.randint(0, len(a), (10_007, 80))]
+    lens = rng.randint(0, 81, len(rows)).astype(np.uint32)
+    ret, want = o.exec_stride(rows, lens)
+    end, bm = node.exec_batch(rows, lens)
+    assert np.array_equal(end, want) and np.array_equal(bits(bm, len(rows)), ret == 1)
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    strings = [(pats[rng.randint(len(pats))][1:4] + b"123yz") if i % 3 == 0 else bytes(a[rng.randint(0, len(a), rng.randint(0, 50))]) for i in range(5003)]
+    ret, want = o.exec_strings(strings)
+    end, bm = node.exec_strings(strings)
+    assert np.array_equal(end, want) and np.array_equal(bits(bm, len(strings)), ret == 1)
+    assert (ret == 1).sum() > 1000
+    # device-resident shards: each replica generates its own rows by global index, walks them; every replica
+    # ends up with the whole bitmap; the count is the batch's
+    n, L = 300_037, 1024
+    bufs, ends, bms = [], [], []
+    W = node.bitmap_words(n)
+    for k in range(node.ndev):
+        f, c = node.shard(n, k)
+        b = torch.empty((max(c, 1), L), dtype=torch.uint8, device="cuda")
+        if c:
+            bench.generate(hip, "c3", b.data_ptr(), c, L, f)
+        bufs.append(b)
+        ends.append(torch.full((max(c, 1),), -2, dtype=torch.int32, device="cuda"))
+        bms.append(torch.full((W,), -1, dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
+    cnt = node.exec_batch_device([b.data_ptr() for b in bufs], L, n, [e.data_ptr() for e in ends], [m.data_ptr() for m in bms], want_count=True)
+    host = bench.generate_host(hip, "c3", n, L, 0)
+    want = o.table_walk(host)
+    got = np.concatenate([ends[k][:node.shard(n, k)[1]].cpu().numpy().view(np.uint32) for k in range(node.ndev)])
+    assert np.array_equal(got, want)
+    assert cnt == int((want != NO).sum()) > n // 3
+    for k in range(node.ndev):
+        assert np.array_equal(bits(bms[k].cpu().numpy(), n), want != NO), k            # the whole bitmap on every replica
+        assert not bits(bms[k].cpu().numpy(), W * 64)[n:].any()
+    # replicas answer end-id queries like a single dfa
+    r0 = node.replica(0)
+    e = int(want[want != NO][0])
+    assert np.array_equal(r0.endids(e), o.endids(e))
+    node.close()

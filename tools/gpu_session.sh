@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 for step in "$@"; do
 	case $step in
-	test)   timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
+	test)   timeout 1000 python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
 	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
 	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
