@@ -69,6 +69,7 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
+	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes */
 	unsigned flags = 0;
 };
 
@@ -426,7 +427,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* ragged / packed / unaligned inputs: the coalesced, lane-refilling kernel whenever at least four
 	 * waves' tiles and rings fit next to the table, else per-lane loads (walk_generic) */
 	const bool ragged_fits = d->table_lds + 4u * FSMHIP_RAGGED_WAVE_LDS <= d->lds_limit;
-	int mode = ragged_fits ? IN_RAGGED : IN_GENERIC;
+	/* (the refill works in 128-byte segments: inputs much shorter than that leave most of every tile unused,
+	 * and per-lane loads win -- measured 1.5 vs 0.8 TB/s at 8-64 bytes; the host fronts know the average) */
+	int mode = ragged_fits && !d->hint_short ? IN_RAGGED : IN_GENERIC;
 	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits)) mode = d->knob_input_mode;
 	else if (fast_ok) {
 		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging (8 KiB tile per wave) is the better input
@@ -459,13 +462,12 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
 	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
-	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12 for the
-	 * two-word-state policies (launch.h eager_dma_threads), eager ragged / generic 8. */
+	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12
+	 * (launch.h eager_dma_threads), eager ragged / generic 8. */
 	int wmax = 16;
 	if (mode == IN_RAGGED) wmax = eager ? 8 : 12;
 	else if (eager && mode == IN_GENERIC) wmax = 8;
-	else if (eager && mode == IN_LDSDMA)
-		wmax = (layout == FSM_HIP_LAYOUT_TINY && d->plan.tiny5_col.empty()) || layout == FSM_HIP_LAYOUT_LDSSELF || layout == FSM_HIP_LAYOUT_COMBSELF ? 12 : 16;
+	else if (eager && mode == IN_LDSDMA) wmax = 12;
 	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16) waves = d->knob_waves;
@@ -692,6 +694,11 @@ static int exec_host(const struct fsm_hip_dfa *d,
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	const int p_bm = hc.add(HostCall::OUT, nullptr, accept_bitmap, ((n + 63) / 64) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
+	struct Hint {   /* under the dfa's lock, which hc holds */
+		fsm_hip_dfa *d;
+		Hint(fsm_hip_dfa *d_, bool v) : d(d_) { d->hint_short = v; }
+		~Hint() { d->hint_short = false; }
+	} hint(hc.d, (len != nullptr || off != nullptr) && in_bytes / n < 96u);
 	if (off) {
 		if (fsm_hip_exec_batch_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
 		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;

@@ -66,12 +66,10 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	return launch_fn(k, c, a, grid, block, s);
 }
 
-/* thread cap of the eager LDS-DMA kernel: 16 waves (<= 128 VGPRs) unless the policy carries two words of
- * state or 64-bit lookups next to the 64-bit id set -- those spilled 2-8 VGPRs at 128 and get 12 waves */
-template <class Pol> struct eager_dma_threads { static constexpr int value = 1024; };
-template <> struct eager_dma_threads<TinyPol<uint64_t>> { static constexpr int value = 768; };
-template <> struct eager_dma_threads<LdsSelfPol> { static constexpr int value = 768; };
-template <> struct eager_dma_threads<CombSelfPol> { static constexpr int value = 768; };
+/* thread cap of the eager LDS-DMA kernel: 12 waves (<= 170 VGPRs): the chunk-level eager walk (EagerPol::walk16)
+ * keeps the 16 lookups of a chunk live across its two passes next to the tile and the 64-bit id set, which
+ * spilled 2-44 VGPRs under the 128 of a 16-wave workgroup */
+template <class Pol> struct eager_dma_threads { static constexpr int value = 768; };
 
 /* eager-output walks: the policy wrapped; the register-set form also behind LDS-DMA (128-byte segments) */
 template <class EP, bool DMA, int DMAT>

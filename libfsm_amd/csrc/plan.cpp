@@ -397,7 +397,7 @@ try {
  * state's) on more than half the classes stays dense, so the form is never much larger than the
  * table and the result is the same for any choice.
  *
- * Records are 16 bytes {bits lo, bits hi, base | DENSE | CONSEC, offset}; those of the states nearest the
+ * Records are 16 bytes {bits lo, bits hi, base | DENSE | CONSEC | FULLBASE, offset}; those of the states nearest the
  * start state, and the dense rows among them, are mirrored in LDS (breadth-first numbering puts
  * the states a walk visits most first), the rest stays in HBM/L2.
  *
@@ -481,7 +481,11 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		std::vector<uint32_t> byc(C);
 		for (uint32_t c = 0; c < C; c++) byc[c] = c;
 		std::stable_sort(byc.begin(), byc.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
-		std::vector<uint32_t> pick(byc.begin(), byc.begin() + (C < 64u ? C : 64u));
+		/* only classes that are excepted somewhere need a bit: a class on which every row equals its
+		 * base row (bytes outside a literal set's alphabet, say) is answered by the chain's dense end */
+		uint32_t npick = 0;
+		while (npick < C && npick < 64u && cnt[byc[npick]] != 0) npick++;
+		std::vector<uint32_t> pick(byc.begin(), byc.begin() + npick);
 		std::sort(pick.begin(), pick.end());
 		for (size_t k = 0; k < pick.size(); k++) bit_of[pick[k]] = (uint8_t)k;
 		if (C > 64u) {
@@ -499,8 +503,8 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	 * Breadth-first numbering hands the children of a trie node consecutive ids, so on an Aho-Corasick
 	 * DFA every record with at least one exception qualifies: the walk then computes the next state as
 	 * first + rank(bit) and the exception list -- one dependent gather per hit -- is not stored at all. */
-	const uint32_t CONSEC = 0x40000000u;
-	if (N >= CONSEC) return ENOTSUP;
+	const uint32_t CONSEC = 0x40000000u, FULLBASE = 0x20000000u;
+	if (N >= FULLBASE) return ENOTSUP;
 	std::vector<uint8_t> consec(N, 0);
 	for (uint32_t n = 0; n < N; n++) {
 		if (base[n] == NONE || nexc[n] == 0) continue;
@@ -547,7 +551,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		uint16_t *pm = reinterpret_cast<uint16_t *>(&img[16]);
 		for (unsigned b = 0; b < 256; b++) pm[b] = (uint16_t)(p.cls[b] | (bit_of[p.cls[b]] << 8));
 	}
-	uint32_t drow = 0, eoff = 0, maxchain = 0, nconsec = 0;
+	uint32_t drow = 0, eoff = 0, maxchain = 0, nconsec = 0, nfullbase = 0;
 	for (uint32_t n = 0; n < N; n++) {
 		uint32_t *r = &img[grec_w + (size_t)n * 4u];
 		if (base[n] == NONE) {
@@ -575,8 +579,23 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 			nconsec += consec[n];
 			if (chain[n] > maxchain) maxchain = chain[n];
 		}
-		if (n < H) memcpy(&img[lds_rec_w + (size_t)n * 4u], r, 16);
 	}
+	/* FULLBASE: the base is an LDS-resident CONSEC record with a bit set for EVERY class that owns a bit
+	 * (a trie node with all children, e.g. every depth-1 node of a literal set over its whole alphabet).
+	 * A miss on such a record's child need not visit the base: the answer is first(base) + bit(class),
+	 * one 4-byte LDS read instead of a whole chain step. */
+	{
+		uint32_t nbits = 0;
+		for (uint32_t c = 0; c < C; c++) nbits += bit_of[c] != 0xff;
+		const uint64_t all = nbits >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << nbits) - 1u);
+		for (uint32_t n = 0; n < N; n++) {
+			uint32_t *r = &img[grec_w + (size_t)n * 4u];
+			if (base[n] == NONE || base[n] >= H || !consec[base[n]]) continue;
+			const uint32_t *rb = &img[grec_w + (size_t)base[n] * 4u];
+			if ((rb[0] | ((uint64_t)rb[1] << 32)) == all) { r[2] |= FULLBASE; nfullbase++; }
+		}
+	}
+	for (uint32_t n = 0; n < H; n++) memcpy(&img[lds_rec_w + (size_t)n * 4u], &img[grec_w + (size_t)n * 4u], 16);
 	img[0] = 0x31525053u;   /* "SPR1" */
 	img[1] = H;
 	img[2] = HD * C;
@@ -591,6 +610,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	img[11] = (uint32_t)ntot_exc;
 	img[12] = maxchain;
 	img[13] = nconsec;
+	img[14] = nfullbase;
 	p.sparse_lds_bytes = lds_words * 4u;
 	p.layout = FSM_HIP_LAYOUT_SPARSE;
 	return 0;

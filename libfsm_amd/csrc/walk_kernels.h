@@ -53,6 +53,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fsmhip {
 
@@ -127,6 +128,7 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 
 template <class W>
 struct TinyPol {
+	static constexpr bool heavy_next = false;
 	static_assert(sizeof(W) == 8, "16 states x 4 bits per column");
 	typedef W P;
 	typedef uint32_t S;   /* carried unmasked: only bits 3:0 are the state (see next) */
@@ -199,6 +201,7 @@ __device__ __forceinline__ void copy_table(unsigned char *dst, const WalkArgs &a
  *    is carried as 5 * s: the dependent chain is ONE v_bfe_u32 per byte.
  */
 struct Tiny5Pol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -230,6 +233,7 @@ struct Tiny5Pol {
 };
 
 struct LdsPol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -266,6 +270,7 @@ struct LdsSelfState {
 };
 
 struct LdsSelfPol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef LdsSelfState S;
 	const uint8_t *bp;
@@ -305,6 +310,7 @@ struct LdsSelfPol {
 };
 
 struct CombPol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -333,6 +339,7 @@ struct CombPol {
 };
 
 struct Comb256Pol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -369,6 +376,7 @@ struct Comb256Pol {
 struct CombSelfState { uint32_t st, sm; };
 
 struct CombSelfPol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef CombSelfState S;
 	const uint8_t *bp;      /* LDS byte -> class map                                    */
@@ -430,6 +438,7 @@ struct CombSelfPol {
 };
 
 struct GlobPol {
+	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -461,13 +470,14 @@ struct GlobPol {
 
 /*
  * SparsePol: base-row records (plan.cpp build_sparse).  A state is its renumbered id; its 16-byte
- * record {bits lo, bits hi, base | DENSE | CONSEC, offset} comes from LDS for the H states nearest the
+ * record {bits lo, bits hi, base | DENSE | CONSEC | FULLBASE, offset} comes from LDS for the H states nearest the
  * start state and from HBM/L2 for the rest.  A lane follows base links until a record has the class's
  * bit set -- next state = offset + rank of the bit when the record's targets are consecutive ids
  * (CONSEC: pure arithmetic), else one gather from the exception list -- or is dense (next state from
  * the dense row, LDS for the first rows).  The loop is lane-divergent; chains are bounded by the planner.
  */
 struct SparsePol {
+	static constexpr bool heavy_next = true;   /* next() is a divergent loop: EagerPol keeps its per-byte form */
 	typedef uint32_t P;   /* class | bit << 8 */
 	typedef uint32_t S;
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
@@ -499,30 +509,33 @@ struct SparsePol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
 	{
-		const uint32_t cls = p & 0xffu, bit = p >> 8;
-		const uint32_t lowmask_lo = bit < 32u ? (1u << bit) - 1u : 0xFFFFFFFFu;
-		const uint32_t lowmask_hi = bit < 32u ? 0u : bit < 64u ? (1u << (bit - 32u)) - 1u : 0u;
+		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit (only when C > 64) */
+		const bool hasbit = bit < 64u;
+		const uint64_t below = hasbit ? ((uint64_t)1 << bit) - 1u : 0u;
 		uint32_t res = st;
 		bool live = st < abs_min;
 		while (live) {
 			u32x4 r;
 			if (st < H) r = lrec[st]; else r = grec[st];
-			if (r.z & 0x80000000u) {
+			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
+			if (hasbit && ((bits >> bit) & 1u)) {
+				const uint32_t k = r.w + (uint32_t)__popcll(bits & below);
+				/* CONSEC: the exception targets are consecutive ids in bit order (breadth-first
+				 * numbering gives every trie node's children such ids), so the k-th one is
+				 * first + k: no gather at all */
+				res = (r.z & 0x40000000u) ? k : exc[k];
+				live = false;
+			} else if (r.z & 0x80000000u) {                      /* dense row (a dense record has no bits) */
 				const uint32_t o = r.w + cls;
 				if (o < HDE) res = ldense[o]; else res = gdense[o];
 				live = false;
+			} else if (hasbit && (r.z & 0x20000000u)) {
+				/* FULLBASE: the base is an LDS-resident record with every bit set: its answer is
+				 * first(base) + bit, one 4-byte read instead of another turn of the loop */
+				res = lrec[r.z & 0x1FFFFFFFu].w + bit;
+				live = false;
 			} else {
-				const uint32_t sel = bit < 32u ? (r.x >> bit) & 1u : bit < 64u ? (r.y >> (bit - 32u)) & 1u : 0u;
-				if (sel) {
-					const uint32_t k = r.w + __popc(r.x & lowmask_lo) + __popc(r.y & lowmask_hi);
-					/* CONSEC: the exception targets are consecutive ids in bit order (breadth-first
-					 * numbering gives every trie node's children such ids), so the k-th one is
-					 * first + k: no gather at all */
-					res = (r.z & 0x40000000u) ? k : exc[k];
-					live = false;
-				} else {
-					st = r.z & 0x3FFFFFFFu;
-				}
+				st = r.z & 0x1FFFFFFFu;
 			}
 		}
 		return res;
@@ -546,11 +559,12 @@ struct EagerPol : Pol {
 	typedef EagerState<Pol> S;
 	typedef typename Pol::P P;
 	const uint64_t *emask;
-	uint32_t lo_end, hi_begin, span, fin_div;
+	uint32_t lo_end, hi_begin, span, fin_div, abs_min_code;
 
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		Pol::setup(lds, a);
+		abs_min_code = a.abs_min;
 		emask = a.emask;
 		lo_end = a.eager_lo_end;
 		hi_begin = a.eager_hi_begin;
@@ -587,6 +601,32 @@ struct EagerPol : Pol {
 		/* outside [lo_end, hi_begin) in one unsigned compare */
 		if (c != before && (c - lo_end) >= span) st.acc |= emask[c / fin_div];
 		return st;
+	}
+	/* A whole 16-byte chunk at once.  Entering a state with outputs is rare (a pattern has just completed),
+	 * so the chunk is first walked as a plain chunk while one running maximum of (state - lo_end) notes
+	 * whether ANY of the 16 states entered lies outside [lo_end, hi_begin): 2 operations per byte instead
+	 * of the 4 + branch of next().  Only the lanes that did enter one re-walk the chunk byte by byte from
+	 * its first state with the exact per-byte rule.  A lane that starts the chunk in an absorbing state
+	 * cannot enter anything: its outputs were collected when it got there. */
+	template <class Q = Pol, class = typename std::enable_if<!Q::heavy_next>::type>
+	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
+	{
+		typename Pol::S s = st.s;
+		uint32_t m = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			s = Pol::next(s, pre[k]);
+			const uint32_t d = Pol::code(s) - lo_end;
+			m = d > m ? d : m;
+		}
+		if (m >= span && Pol::code(st.s) < abs_min_code) {
+			S t = st;
+#pragma unroll
+			for (int k = 0; k < 16; k++) t = next(t, pre[k]);
+			st = t;
+		} else {
+			st.s = s;
+		}
 	}
 	__device__ __forceinline__ static void finish(const WalkArgs &a, uint64_t i, bool valid, const S &st)
 	{
@@ -752,6 +792,20 @@ __device__ __forceinline__ bool skip_chunk(const Pol &, const typename Pol::S &,
 	return false;
 }
 
+/* a policy may walk a whole chunk itself (walk16: EagerPol's rare-event form) */
+template <class Pol>
+__device__ __forceinline__ auto walk_chunk(const Pol &pol, typename Pol::S &st, const typename Pol::P (&pre)[16], int)
+	-> decltype(pol.walk16(st, pre))
+{
+	pol.walk16(st, pre);
+}
+template <class Pol>
+__device__ __forceinline__ void walk_chunk(const Pol &pol, typename Pol::S &st, const typename Pol::P (&pre)[16], long)
+{
+#pragma unroll
+	for (int k = 0; k < 16; k++) st = pol.next(st, pre[k]);
+}
+
 template <class Pol, int ROWS>
 __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
@@ -760,7 +814,11 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 	for (int r = 0; r < ROWS; r++)
 #pragma unroll
 		for (int k = 0; k < 16; k++) pre[r][k] = pre_of(pol, w[r], k, 0);
-	if (ROWS == 1 && skip_chunk(pol, st[0], pre[0], 0)) return;
+	if (ROWS == 1) {
+		if (skip_chunk(pol, st[0], pre[0], 0)) return;
+		walk_chunk(pol, st[0], pre[0], 0);
+		return;
+	}
 #pragma unroll
 	for (int k = 0; k < 16; k++)
 #pragma unroll

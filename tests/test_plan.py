@@ -62,9 +62,14 @@ def decode_sparse(p, S1, lds_limit=160 * 1024):
             pop = np.array([bin(int(x)).count("1") for x in low], np.int64)
             consec = (rec[:, 2] & 0x40000000) != 0                      # targets = first + rank: no list stored
             eval_ = np.where(consec, rec[:, 3] + pop, img[np.minimum(exo // 4 + rec[:, 3] + pop, len(img) - 1)])
-            fin_now = dense | sel
-            res[idx[fin_now]] = np.where(dense, dval, eval_)[fin_now]
-            st[idx[~fin_now]] = rec[~fin_now, 2] & 0x3FFFFFFF
+            # FULLBASE: a miss resolves as first(base) + bit when the (LDS-resident, all-bits-set) base says so
+            bid = rec[:, 2] & 0x1FFFFFFF
+            fullbase = ((rec[:, 2] & 0x20000000) != 0) & ~dense & ~sel & (b < 64)
+            assert (bid[fullbase] < H).all()
+            fval = lds[np.minimum(lro // 4 + bid * 4 + 3, len(lds) - 1)] + b
+            fin_now = dense | sel | fullbase
+            res[idx[fin_now]] = np.where(sel, eval_, np.where(dense, dval, fval))[fin_now]
+            st[idx[~fin_now]] = bid[~fin_now]
             live[idx[fin_now]] = False
             hops += 1
             assert hops <= maxchain + 1
@@ -225,6 +230,20 @@ def test_auto_layout_choices(built):
     assert int(img[13]) > 0.9 * (int(img[8]) - int(img[10])) * 0.5 and int(img[11]) < 0.05 * pa.S1
     want = decode_want(ac, pa)
     assert np.array_equal(decode_sparse(pa, pa.S1), want)
+
+
+def test_sparse_fullbase_shortcut(built):
+    """A literal set over a small alphabet in which every 2-gram occurs: the depth-1 nodes own all children
+    (records with every bit set) and their children are flagged FULLBASE -- a miss resolves as first(base) + bit
+    without visiting the base.  The decoder above follows that shortcut; delta must still be exact."""
+    rng = np.random.RandomState(17)
+    alpha = np.frombuffer(b"abcd", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 4, rng.randint(3, 9))]) for _ in range(400)))
+    ac = FlatDfa.from_strings(words, 2, list(range(len(words))))
+    pa = Plan(ac, LAYOUT_SPARSE)
+    img = pa.get("sparse")
+    assert int(img[14]) >= 16 and int(img[13]) > 0 and int(img[11]) == 0     # FULLBASE records, CONSEC records, no lists
+    assert np.array_equal(decode_sparse(pa, pa.S1), decode_want(ac, pa))
 
 
 def test_wide_eager_sets(built):
