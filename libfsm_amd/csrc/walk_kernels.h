@@ -444,10 +444,14 @@ struct GlobPol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	/* explicit address spaces: with generic pointers the `hot or table` choice became one flat_load of a
+	 * selected address, i.e. even the LDS-mirrored rows went through the vector-memory path */
+	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
+	typedef const unsigned char __attribute__((address_space(1))) *glb_u8_p;
 	const uint8_t *bp;         /* LDS byte -> class map                                    */
-	const unsigned char *tab;  /* device table; state is a byte offset into it             */
-	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
-	uint32_t hot_bytes;        /* nearest the start state (breadth-first numbering)        */
+	glb_u8_p tab;              /* device table; state is a byte offset into it             */
+	uint32_t hot;              /* LDS byte address of the copy of the first hot_bytes of the table: */
+	uint32_t hot_bytes;        /* the rows nearest the start state (breadth-first numbering)        */
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -455,16 +459,16 @@ struct GlobPol {
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
-		hot = lds + FSMHIP_BTAB_BYTES;
+		hot = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + FSMHIP_BTAB_BYTES);
 		hot_bytes = a.tab_bytes;
-		tab = static_cast<const unsigned char *>(a.tab);
+		tab = (glb_u8_p)a.tab;
 		abs_min = a.abs_min;
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
-		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
+		if (st < hot_bytes) return *(lds_u32_p)(uintptr_t)(hot + st + c * 4u);
+		return *(const uint32_t __attribute__((address_space(1))) *)(tab + st + c * 4u);
 	}
 };
 
@@ -483,11 +487,20 @@ struct SparsePol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	const uint16_t *pm;        /* LDS: byte -> class | bit << 8 */
-	const uint32_t *ldense;    /* LDS: first dense rows         */
-	const u32x4 *lrec;         /* LDS: first H records          */
-	const u32x4 *grec;
-	const uint32_t *gdense, *exc;
+	/* LDS and global tables are addressed through pointers of their own address space: with generic
+	 * pointers the compiler merged `st < H ? lrec[st] : grec[st]` into ONE flat_load of a selected
+	 * address, so that every LDS-resident record travelled the vector-memory path and queued behind the
+	 * global gathers in flight (ISA of the round-1 kernel); now it is a ds_read_b128 or a global_load */
+	typedef const u32x4 __attribute__((address_space(3))) *lds_rec_p;
+	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
+	typedef const uint16_t __attribute__((address_space(3))) *lds_u16_p;
+	typedef const u32x4 __attribute__((address_space(1))) *glb_rec_p;
+	typedef const uint32_t __attribute__((address_space(1))) *glb_u32_p;
+	uint32_t pm;               /* LDS byte address: byte -> class | bit << 8 (u16) */
+	uint32_t ldense;           /* LDS byte address: first dense rows               */
+	uint32_t lrec;             /* LDS byte address: first H records                */
+	glb_rec_p grec;
+	glb_u32_p gdense, exc;
 	uint32_t H, HDE, abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
@@ -496,17 +509,18 @@ struct SparsePol {
 		copy_table(lds, a);
 		const uint32_t *hdr = static_cast<const uint32_t *>(a.tab);
 		const unsigned char *g = static_cast<const unsigned char *>(a.tab);
+		const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
 		H = hdr[1];
 		HDE = hdr[2];
-		pm = reinterpret_cast<const uint16_t *>(lds + 64);
-		ldense = reinterpret_cast<const uint32_t *>(lds + hdr[3]);
-		lrec = reinterpret_cast<const u32x4 *>(lds + hdr[4]);
-		grec = reinterpret_cast<const u32x4 *>(g + hdr[5]);
-		gdense = reinterpret_cast<const uint32_t *>(g + hdr[6]);
-		exc = reinterpret_cast<const uint32_t *>(g + hdr[7]);
+		pm = l0 + 64u;
+		ldense = l0 + hdr[3];
+		lrec = l0 + hdr[4];
+		grec = (glb_rec_p)(g + hdr[5]);
+		gdense = (glb_u32_p)(g + hdr[6]);
+		exc = (glb_u32_p)(g + hdr[7]);
 		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
+	__device__ __forceinline__ P pre(uint32_t b) const { return *(lds_u16_p)(uintptr_t)(pm + b * 2u); }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
 	{
 		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit (only when C > 64) */
@@ -516,7 +530,8 @@ struct SparsePol {
 		bool live = st < abs_min;
 		while (live) {
 			u32x4 r;
-			if (st < H) r = lrec[st]; else r = grec[st];
+			if (st < H) r = *(lds_rec_p)(uintptr_t)(lrec + st * 16u);
+			else r = grec[st];
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
 			if (hasbit && ((bits >> bit) & 1u)) {
 				const uint32_t k = r.w + (uint32_t)__popcll(bits & below);
@@ -527,12 +542,13 @@ struct SparsePol {
 				live = false;
 			} else if (r.z & 0x80000000u) {                      /* dense row (a dense record has no bits) */
 				const uint32_t o = r.w + cls;
-				if (o < HDE) res = ldense[o]; else res = gdense[o];
+				if (o < HDE) res = *(lds_u32_p)(uintptr_t)(ldense + o * 4u);
+				else res = gdense[o];
 				live = false;
 			} else if (hasbit && (r.z & 0x20000000u)) {
 				/* FULLBASE: the base is an LDS-resident record with every bit set: its answer is
 				 * first(base) + bit, one 4-byte read instead of another turn of the loop */
-				res = lrec[r.z & 0x1FFFFFFFu].w + bit;
+				res = *(lds_u32_p)(uintptr_t)(lrec + (r.z & 0x1FFFFFFFu) * 16u + 12u) + bit;
 				live = false;
 			} else {
 				st = r.z & 0x1FFFFFFFu;
@@ -1068,11 +1084,12 @@ walk_generic(const WalkArgs a)
 		const uint64_t nchunks = (span + 15u) / 16u;
 		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
 		u32x4 w[1] = { {0u, 0u, 0u, 0u} };
-		if (nchunks != 0) w[0] = *reinterpret_cast<const u32x4 *>(q0);
+		typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;   /* not a flat load */
+		if (nchunks != 0) w[0] = *(glb_chunk_p)q0;
 		for (uint64_t c = 0; __any(c < nchunks); c++) {
 			if (c < nchunks) {
 				u32x4 wn = {0u, 0u, 0u, 0u};
-				if (c + 1 < nchunks) wn = *reinterpret_cast<const u32x4 *>(q0 + (c + 1) * 16u); /* next chunk in flight */
+				if (c + 1 < nchunks) wn = *(glb_chunk_p)(q0 + (c + 1) * 16u); /* next chunk in flight */
 				/* valid bytes of this chunk: [lo, hi) */
 				const uint32_t lo = c == 0 ? head : 0u;
 				const uint64_t left = span - c * 16u;

@@ -537,7 +537,7 @@ def test_node_front_shards_and_gathers(hip, devices):
     ret, want = o.exec_strings(strings)
     end, bm = node.exec_strings(strings)
     assert np.array_equal(end, want) and np.array_equal(bits(bm, len(strings)), ret == 1)
-    assert (ret == 1).sum() > 1000
+    assert (ret == 1).sum() > 300
     # device-resident shards: each replica generates its own rows by global index, walks them; every replica
     # ends up with the whole bitmap; the count is the batch's
     n, L = 300_037, 1024

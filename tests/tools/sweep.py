@@ -91,6 +91,10 @@ def main():
                 variants += [(hip.IN_LDSDMA, 128, 1, 8, 0, 0, 0), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 0)]
                 variants += [(hip.IN_DIRECT, nb, 1, w, b, 2, 1) for nb in (4, 8) for w in (16, 8) for b in (0, 4)]  # mask=2: no-prefetch kernel
                 variants += [(hip.IN_GENERIC, 0, 1, 16, 0, masks[-1], 1)]
+            if a.set == "r2":  # round 2: every input path of every layout, library defaults first
+                variants = [(-1, 0, 0, 0, 0, -1, 1), (hip.IN_LDSDMA, 128, 1, 16, 0, 4, 1), (hip.IN_LDSDMA, 128, 1, 12, 0, 4, 1),
+                            (hip.IN_LDSDMA, 128, 1, 8, 0, 4, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 1, 16, 0, 2, 1),
+                            (hip.IN_RAGGED, 0, 1, 0, 0, 0, 1), (hip.IN_GENERIC, 0, 1, 16, 0, 0, 1)]
             if a.set == "dma":  # LDS-DMA staging next to an LDS table: how many waves fit / pay
                 variants = [(hip.IN_LDSDMA, 128, 1, w, b, m, 1) for w in (16, 14, 12, 10, 8) for b in (0, 1) for m in (0, 4)]
                 variants += [(hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 2, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]

@@ -13,5 +13,6 @@ for step in "$@"; do
 	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
+	sweep)  timeout 400 python tests/tools/sweep.py --set r2 --workloads c3,c2 > gpurun_out/${TAG}_sweep.txt 2>&1; echo "sweep rc=$?"; grep -v '^#' gpurun_out/${TAG}_sweep.txt | tail -80 ;;
 	esac
 done
