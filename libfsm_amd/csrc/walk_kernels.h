@@ -444,14 +444,10 @@ struct GlobPol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	/* explicit address spaces: with generic pointers the `hot or table` choice became one flat_load of a
-	 * selected address, i.e. even the LDS-mirrored rows went through the vector-memory path */
-	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
-	typedef const unsigned char __attribute__((address_space(1))) *glb_u8_p;
 	const uint8_t *bp;         /* LDS byte -> class map                                    */
-	glb_u8_p tab;              /* device table; state is a byte offset into it             */
-	uint32_t hot;              /* LDS byte address of the copy of the first hot_bytes of the table: */
-	uint32_t hot_bytes;        /* the rows nearest the start state (breadth-first numbering)        */
+	const unsigned char *tab;  /* device table; state is a byte offset into it             */
+	const unsigned char *hot;  /* LDS copy of the first hot_bytes of the table: the rows   */
+	uint32_t hot_bytes;        /* nearest the start state (breadth-first numbering)        */
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -459,16 +455,16 @@ struct GlobPol {
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
-		hot = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + FSMHIP_BTAB_BYTES);
+		hot = lds + FSMHIP_BTAB_BYTES;
 		hot_bytes = a.tab_bytes;
-		tab = (glb_u8_p)a.tab;
+		tab = static_cast<const unsigned char *>(a.tab);
 		abs_min = a.abs_min;
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (st < hot_bytes) return *(lds_u32_p)(uintptr_t)(hot + st + c * 4u);
-		return *(const uint32_t __attribute__((address_space(1))) *)(tab + st + c * 4u);
+		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
+		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
 	}
 };
 
@@ -479,6 +475,11 @@ struct GlobPol {
  * bit set -- next state = offset + rank of the bit when the record's targets are consecutive ids
  * (CONSEC: pure arithmetic), else one gather from the exception list -- or is dense (next state from
  * the dense row, LDS for the first rows).  The loop is lane-divergent; chains are bounded by the planner.
+ * The LDS / global choice of a record is left to generic pointers on purpose: the compiler turns
+ * `st < H ? lrec[st] : grec[st]` into ONE flat_load of a selected address, and one load instruction per
+ * turn of the loop measured faster than a ds_read + a global_load under complementary exec masks
+ * (422 vs 385 GB/s, profiles/r02_c5_steps.txt): the walk is bound by instructions per turn, every path
+ * being live in some lane of a 64-lane wave.
  */
 struct SparsePol {
 	static constexpr bool heavy_next = true;   /* next() is a divergent loop: EagerPol keeps its per-byte form */
@@ -487,20 +488,11 @@ struct SparsePol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	/* LDS and global tables are addressed through pointers of their own address space: with generic
-	 * pointers the compiler merged `st < H ? lrec[st] : grec[st]` into ONE flat_load of a selected
-	 * address, so that every LDS-resident record travelled the vector-memory path and queued behind the
-	 * global gathers in flight (ISA of the round-1 kernel); now it is a ds_read_b128 or a global_load */
-	typedef const u32x4 __attribute__((address_space(3))) *lds_rec_p;
-	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
-	typedef const uint16_t __attribute__((address_space(3))) *lds_u16_p;
-	typedef const u32x4 __attribute__((address_space(1))) *glb_rec_p;
-	typedef const uint32_t __attribute__((address_space(1))) *glb_u32_p;
-	uint32_t pm;               /* LDS byte address: byte -> class | bit << 8 (u16) */
-	uint32_t ldense;           /* LDS byte address: first dense rows               */
-	uint32_t lrec;             /* LDS byte address: first H records                */
-	glb_rec_p grec;
-	glb_u32_p gdense, exc;
+	const uint16_t *pm;        /* LDS: byte -> class | bit << 8 */
+	const uint32_t *ldense;    /* LDS: first dense rows         */
+	const u32x4 *lrec;         /* LDS: first H records          */
+	const u32x4 *grec;
+	const uint32_t *gdense, *exc;
 	uint32_t H, HDE, abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
@@ -509,18 +501,17 @@ struct SparsePol {
 		copy_table(lds, a);
 		const uint32_t *hdr = static_cast<const uint32_t *>(a.tab);
 		const unsigned char *g = static_cast<const unsigned char *>(a.tab);
-		const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
 		H = hdr[1];
 		HDE = hdr[2];
-		pm = l0 + 64u;
-		ldense = l0 + hdr[3];
-		lrec = l0 + hdr[4];
-		grec = (glb_rec_p)(g + hdr[5]);
-		gdense = (glb_u32_p)(g + hdr[6]);
-		exc = (glb_u32_p)(g + hdr[7]);
+		pm = reinterpret_cast<const uint16_t *>(lds + 64);
+		ldense = reinterpret_cast<const uint32_t *>(lds + hdr[3]);
+		lrec = reinterpret_cast<const u32x4 *>(lds + hdr[4]);
+		grec = reinterpret_cast<const u32x4 *>(g + hdr[5]);
+		gdense = reinterpret_cast<const uint32_t *>(g + hdr[6]);
+		exc = reinterpret_cast<const uint32_t *>(g + hdr[7]);
 		abs_min = a.abs_min;
 	}
-	__device__ __forceinline__ P pre(uint32_t b) const { return *(lds_u16_p)(uintptr_t)(pm + b * 2u); }
+	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
 	{
 		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit (only when C > 64) */
@@ -530,8 +521,7 @@ struct SparsePol {
 		bool live = st < abs_min;
 		while (live) {
 			u32x4 r;
-			if (st < H) r = *(lds_rec_p)(uintptr_t)(lrec + st * 16u);
-			else r = grec[st];
+			if (st < H) r = lrec[st]; else r = grec[st];
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
 			if (hasbit && ((bits >> bit) & 1u)) {
 				const uint32_t k = r.w + (uint32_t)__popcll(bits & below);
@@ -542,13 +532,12 @@ struct SparsePol {
 				live = false;
 			} else if (r.z & 0x80000000u) {                      /* dense row (a dense record has no bits) */
 				const uint32_t o = r.w + cls;
-				if (o < HDE) res = *(lds_u32_p)(uintptr_t)(ldense + o * 4u);
-				else res = gdense[o];
+				if (o < HDE) res = ldense[o]; else res = gdense[o];
 				live = false;
 			} else if (hasbit && (r.z & 0x20000000u)) {
 				/* FULLBASE: the base is an LDS-resident record with every bit set: its answer is
 				 * first(base) + bit, one 4-byte read instead of another turn of the loop */
-				res = *(lds_u32_p)(uintptr_t)(lrec + (r.z & 0x1FFFFFFFu) * 16u + 12u) + bit;
+				res = lrec[r.z & 0x1FFFFFFFu].w + bit;
 				live = false;
 			} else {
 				st = r.z & 0x1FFFFFFFu;

@@ -522,7 +522,7 @@ def test_node_front_shards_and_gathers(hip, devices):
         cover = 0
         for k in range(node.ndev):
             f, c = node.shard(n, k)
-            assert f == cover and (f % 64 == 0)
+            assert f == cover and (f % 64 == 0 or c == 0)
             cover += c
         assert cover == n
     # host pointers, ragged rows

@@ -14,5 +14,13 @@ for step in "$@"; do
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
 	sweep)  timeout 400 python tests/tools/sweep.py --set r2 --workloads c3,c2 > gpurun_out/${TAG}_sweep.txt 2>&1; echo "sweep rc=$?"; grep -v '^#' gpurun_out/${TAG}_sweep.txt | tail -80 ;;
+	prof)   for wl in c3 c2 c5; do
+	            L2=""; [ $wl = c5 ] && L2="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"
+	            L2_PMC="$L2" timeout 500 bash tools/profile.sh $wl $PWD/gpurun_out/${TAG}_prof_$wl > gpurun_out/${TAG}_prof_$wl.log 2>&1
+	            python tools/rocpd_summary.py gpurun_out/${TAG}_prof_$wl $wl gpurun_out/${TAG}_$wl >> gpurun_out/${TAG}_prof_$wl.log 2>&1
+	            tail -2 gpurun_out/${TAG}_prof_$wl.log
+	            rm -rf gpurun_out/${TAG}_prof_$wl/*/*.db gpurun_out/${TAG}_prof_$wl/*/*/*.db 2>/dev/null
+	        done ;;
+	node)   timeout 300 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "node or retest" > gpurun_out/${TAG}_node.log 2>&1; tail -5 gpurun_out/${TAG}_node.log ;;
 	esac
 done

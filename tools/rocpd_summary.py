@@ -39,7 +39,7 @@ def main():
     hbm = fetch_kib * 1024 * 2 + write_kib * 1024
     alg = n * (L + 4)
     summary = {
-        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline  (then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
+        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline --subs none  (then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
         "bench_line_under_trace": bench,
         "kernel_stats_top": [{"name": t["name"][:120], "calls": t["total_calls"], "avg_us": round(t["average"], 1), "pct": round(t["percentage"], 2)} for t in top[:4]],
         "walk_kernel": {"name": walk["name"], "calls": walk["total_calls"], "avg_ms": round(walk["average"] / 1e3, 4),
