@@ -77,6 +77,12 @@ int fsm_hip_plan_get(const struct fsm_hip_plan *plan, int what, const void **dat
  * d_scratch4 = 4 writable device bytes.  <0 on error. */
 double fsm_hip_stream_read_probe_ms(const void *d_base, size_t bytes, void *d_scratch4, int reps, void *hip_stream);
 
+/* Counter calibration aid: one launch of `ngathers` independent vec_bytes-byte (4 or 16) loads at pseudo-random
+ * aligned offsets of the `bytes`-byte device buffer at d_base (make it far larger than the caches).  Returns the
+ * kernel's milliseconds (< 0 on error).  tools/fetch_calib.py runs it under rocprofv3 --pmc to see what
+ * FETCH_SIZE tallies per gather. */
+double fsm_hip_gather_probe_ms(const void *d_base, size_t bytes, size_t ngathers, int vec_bytes, void *d_scratch4, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1062,6 +1062,35 @@ fail:
 	return (double)ms;
 }
 
+extern "C" double fsm_hip_gather_probe_ms(const void *d_base, size_t bytes, size_t ngathers, int vec_bytes, void *d_scratch4, void *hip_stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	float ms = -1.f;
+	if (d_base == nullptr || d_scratch4 == nullptr || (vec_bytes != 4 && vec_bytes != 16) || bytes < 16 || ngathers == 0 ||
+	    (reinterpret_cast<uintptr_t>(d_base) % 16u) != 0) { errno = EINVAL; return -1.0; }
+	int dev = 0, ncu = 256;
+	(void)hipGetDevice(&dev);
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, s));
+	if (vec_bytes == 16)
+		hipLaunchKernelGGL(gather_probe_kernel<16>, dim3((unsigned)ncu * 8u), dim3(256), 0, s, static_cast<const unsigned char *>(d_base),
+		                   (uint64_t)(bytes / 16u), (uint64_t)ngathers, static_cast<uint32_t *>(d_scratch4));
+	else
+		hipLaunchKernelGGL(gather_probe_kernel<4>, dim3((unsigned)ncu * 8u), dim3(256), 0, s, static_cast<const unsigned char *>(d_base),
+		                   (uint64_t)(bytes / 4u), (uint64_t)ngathers, static_cast<uint32_t *>(d_scratch4));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e1, s));
+	HIP_TRY(hipEventSynchronize(e1));
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+fail:
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return (double)ms;
+}
+
 /* ------------------------------------------------------------------ */
 /* end-ids delivered by the device                                    */
 /* ------------------------------------------------------------------ */

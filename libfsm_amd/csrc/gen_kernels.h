@@ -172,6 +172,28 @@ dma_stream_kernel(const uint8_t *base, uint64_t nrows, uint64_t stride, uint32_t
 	if (acc == 0x9E3779B9u) out[0] = acc;
 }
 
+/* Calibration aid for the PMC counters: `ngathers` independent VEC-byte loads at pseudo-random, VEC-aligned
+ * offsets of a buffer far larger than L2 + MALL, 64 different lines per wave instruction -- the access shape of
+ * the record / table gathers of the sparse and global layouts.  Run under rocprofv3 --pmc FETCH_SIZE (and
+ * TCC_EA0_RDREQ_sum / TCC_EA0_RDREQ_32B_sum) to see how many bytes the counter tallies per such gather
+ * (tools/fetch_calib.py), before quoting an HBM-traffic figure for a gather-bound walk. */
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gather_probe_kernel(const unsigned char *base, uint64_t nvec, uint64_t ngathers, uint32_t *out)
+{
+	uint32_t acc = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngathers; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t v = mix64(i * 0x9E3779B97F4A7C15ull + 12345u) % nvec;
+		if (VEC == 16) {
+			const u32x4 x = *reinterpret_cast<const u32x4 *>(base + v * 16u);
+			acc ^= x.x ^ x.y ^ x.z ^ x.w;
+		} else {
+			acc ^= *reinterpret_cast<const uint32_t *>(base + v * 4u);
+		}
+	}
+	if (acc == 0x9E3779B9u) out[0] = acc;
+}
+
 } // namespace fsmhip
 
 #endif

@@ -10,6 +10,7 @@ for step in "$@"; do
 	test)   timeout 1000 python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
 	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
+	fullpar) timeout 900 python bench.py --steps 5 --warmup 2 --subs none --full-parity > gpurun_out/${TAG}_bench_fullparity.json 2> gpurun_out/${TAG}_bench_fullparity.err; echo "fullparity rc=$?"; python -c "import json,sys; r=json.loads(open('gpurun_out/${TAG}_bench_fullparity.json').read().strip().splitlines()[-1]); print(r['value'], r.get('full_parity'))" ;;
 	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
@@ -21,6 +22,10 @@ for step in "$@"; do
 	            tail -2 gpurun_out/${TAG}_prof_$wl.log
 	            rm -rf gpurun_out/${TAG}_prof_$wl/*/*.db gpurun_out/${TAG}_prof_$wl/*/*/*.db 2>/dev/null
 	        done ;;
+	calib)  cd /tmp; rocprofv3 --pmc FETCH_SIZE -d $OLDPWD/gpurun_out/${TAG}_calib/fetch -o f -- python $OLDPWD/tools/fetch_calib.py > $OLDPWD/gpurun_out/${TAG}_calib_run.txt 2>&1
+	        rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OLDPWD/gpurun_out/${TAG}_calib/req -o r -- python $OLDPWD/tools/fetch_calib.py >> $OLDPWD/gpurun_out/${TAG}_calib_run.txt 2>&1
+	        cd $OLDPWD; python tools/fetch_calib.py --read gpurun_out/${TAG}_calib/fetch gpurun_out/${TAG}_calib/req > gpurun_out/${TAG}_fetch_calib.json 2>&1; cat gpurun_out/${TAG}_fetch_calib.json | tail -12
+	        rm -rf gpurun_out/${TAG}_calib ;;
 	node)   timeout 300 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "node or retest" > gpurun_out/${TAG}_node.log 2>&1; tail -5 gpurun_out/${TAG}_node.log ;;
 	esac
 done
