@@ -36,7 +36,14 @@ def main():
     n, L = bench["config"]["inputs_per_gpu"], bench["config"]["input_len"]
     fetch_kib = sum(pmc["FETCH_SIZE"]) / len(pmc["FETCH_SIZE"])
     write_kib = sum(pmc["WRITE_SIZE"]) / len(pmc["WRITE_SIZE"])
-    hbm = fetch_kib * 1024 * 2 + write_kib * 1024
+    # Read side.  gfx950 tallies a 128-byte request of a 16-byte-per-lane coalesced stream as 64 bytes
+    # (MI355X_MICROARCH.md section HBM): the streamed input, n * L bytes, shows up as n * L / 2.  A gather that
+    # misses is ONE 64-byte request tallied as 64 bytes (tools/fetch_calib.py, profiles/r02e_fetch_calib.json:
+    # 63.99 bytes and 1.000 TCC_EA0_RDREQ per 4- or 16-byte gather), so whatever FETCH_SIZE reports beyond the
+    # input's n * L / 2 is table traffic at face value.
+    raw = fetch_kib * 1024
+    stream_raw = min(raw, n * L / 2)
+    hbm = stream_raw * 2 + (raw - stream_raw) + write_kib * 1024
     alg = n * (L + 4)
     summary = {
         "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline --subs none  (then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
@@ -46,7 +53,7 @@ def main():
                         "algorithmic_GBps": round(alg / (walk["average"] * 1e-6) / 1e9, 1)},
         "pmc": {"FETCH_SIZE_KiB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": pmc["WRITE_SIZE"],
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
-                "note": "read side = FETCH_SIZE KiB x 1024 x 2 (gfx950: 128-B requests tallied as 64 B for 16-B/lane streams); write side as reported"},
+                "note": "read side = 2 x the input stream's share of FETCH_SIZE (gfx950 tallies 128-B requests of 16-B/lane streams as 64 B) + the rest of FETCH_SIZE at face value (gather misses are 64-B requests tallied as 64 B: profiles/r02e_fetch_calib.json); write side as reported"},
     }
     l2db = glob.glob(os.path.join(prof, "l2", "*.db"))
     if l2db:  # optional pass: L2 (TCC) request / hit / miss counts per walk launch
