@@ -69,6 +69,7 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
+	int knob_ragged_align = -1;  /* ragged kernel: 1 = 128-byte-aligned segments, 0 = 16-byte-aligned, -1 default */
 	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes */
 	unsigned flags = 0;
 };
@@ -496,6 +497,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	if (d->knob_noskip > 0) a.early |= 4u;
+	if (d->knob_ragged_align > 0) a.early |= 8u;
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events are per dfa */
 	hipError_t e = hipSuccess;
@@ -781,6 +783,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
+	case FSM_HIP_KNOB_RAGGED_ALIGN: d->knob_ragged_align = value; break;
 	default: errno = EINVAL; return -1;
 	}
 	return 0;

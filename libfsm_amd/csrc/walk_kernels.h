@@ -514,34 +514,38 @@ struct SparsePol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
 	{
-		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit (only when C > 64) */
+		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit */
 		const bool hasbit = bit < 64u;
-		const uint64_t below = hasbit ? ((uint64_t)1 << bit) - 1u : 0u;
+		const uint64_t sel = hasbit ? (uint64_t)1 << bit : 0u, below = hasbit ? sel - 1u : 0u;
 		uint32_t res = st;
 		bool live = st < abs_min;
+		/* One turn per record of the chain.  The common outcomes -- a hit on a CONSEC record (first + rank,
+		 * pure arithmetic), a miss on a FULLBASE record (first(base) + bit, one 4-byte LDS read), a miss
+		 * that moves on to the base -- are computed straight-line and selected; only the rare ones (a
+		 * dense row, a hit on a record that still owns an exception list) branch.  The walk is bound by
+		 * the instructions of this loop: every path is live in some lane of a 64-lane wave. */
 		while (live) {
 			u32x4 r;
 			if (st < H) r = lrec[st]; else r = grec[st];
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
-			if (hasbit && ((bits >> bit) & 1u)) {
-				const uint32_t k = r.w + (uint32_t)__popcll(bits & below);
-				/* CONSEC: the exception targets are consecutive ids in bit order (breadth-first
-				 * numbering gives every trie node's children such ids), so the k-th one is
-				 * first + k: no gather at all */
-				res = (r.z & 0x40000000u) ? k : exc[k];
-				live = false;
-			} else if (r.z & 0x80000000u) {                      /* dense row (a dense record has no bits) */
-				const uint32_t o = r.w + cls;
-				if (o < HDE) res = ldense[o]; else res = gdense[o];
-				live = false;
-			} else if (hasbit && (r.z & 0x20000000u)) {
-				/* FULLBASE: the base is an LDS-resident record with every bit set: its answer is
-				 * first(base) + bit, one 4-byte read instead of another turn of the loop */
-				res = lrec[r.z & 0x1FFFFFFFu].w + bit;
-				live = false;
-			} else {
-				st = r.z & 0x1FFFFFFFu;
+			const bool hit = (bits & sel) != 0u;
+			const uint32_t id = r.z & 0x1FFFFFFFu;
+			const bool dense = (r.z & 0x80000000u) != 0u;            /* a dense record has no bits */
+			const bool fb = !hit && hasbit && (r.z & 0x20000000u) != 0u;
+			uint32_t v = r.w + (uint32_t)__popcll(bits & below);
+			if (fb) v = lrec[id].w + bit;
+			if (dense || (hit && !(r.z & 0x40000000u))) {
+				if (dense) {
+					const uint32_t o = r.w + cls;
+					if (o < HDE) v = ldense[o]; else v = gdense[o];
+				} else {
+					v = exc[v];
+				}
 			}
+			const bool done = hit || fb || dense;
+			res = done ? v : res;
+			st = id;
+			live = !done;
 		}
 		return res;
 	}
@@ -658,11 +662,12 @@ struct EagerWidePol : Pol {
 	typedef typename Pol::P P;
 	const uint32_t *ew_off, *ew_word;
 	const uint64_t *ew_mask;
-	uint32_t lo_end, hi_begin, fin_div;
+	uint32_t lo_end, hi_begin, fin_div, abs_min_code;
 
 	__device__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		Pol::setup(lds, a);
+		abs_min_code = a.abs_min;
 		ew_off = a.ew_off;
 		ew_word = a.ew_word;
 		ew_mask = a.ew_mask;
@@ -706,6 +711,31 @@ struct EagerWidePol : Pol {
 		 * idempotent, so re-entering the same state need not write again */
 		st.pend = (c != before && emits(c)) ? c : 0xFFFFFFFFu;
 		return st;
+	}
+	/* chunk-level form, as EagerPol::walk16: the chunk is walked as a plain chunk unless a running maximum
+	 * says that some state entered in it emits; the pending outputs of the state the chunk starts in are
+	 * written first (that state is committed) */
+	template <class Q = Pol, class = typename std::enable_if<!Q::heavy_next>::type>
+	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
+	{
+		typename Pol::S s = st.s;
+		uint32_t m = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			s = Pol::next(s, pre[k]);
+			const uint32_t d = Pol::code(s) - lo_end;
+			m = d > m ? d : m;
+		}
+		if (m >= hi_begin - lo_end && Pol::code(st.s) < abs_min_code) {
+			S t = st;
+#pragma unroll
+			for (int k = 0; k < 16; k++) t = next(t, pre[k]);
+			st = t;
+		} else {
+			emit(st.pend, st.row);
+			st.pend = 0xFFFFFFFFu;
+			st.s = s;
+		}
 	}
 	__device__ __forceinline__ void finish_at(const S &st) const { emit(st.pend, st.row); }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
@@ -1202,10 +1232,19 @@ walk_ragged(const WalkArgs a)
 			staged += spend;
 			spend = 0;
 		}
+		/* the first and the last chunk of an input may be partial: they are fetched once more, by their
+		 * (lane-varying) index, for the two predicated steps below */
+		u32x4 hw = {0u, 0u, 0u, 0u}, tw = {0u, 0u, 0u, 0u};
+		const uint32_t c_lo = (head + 15u) >> 4;                   /* first full chunk of the input */
+		const uint32_t c_hi = (uint32_t)(span >> 4);               /* one past its last full chunk = index of the tail */
 		if (tile) {
 #pragma unroll
 			for (uint32_t p = 0; p < 8; p++)
 				w[p] = *reinterpret_cast<const u32x4 *>(rd + ((p + rot) & 7u) * 16u);
+			const uint32_t hidx = kpos == 0u ? (head >> 4) & 7u : 0u;
+			const uint32_t tidx = (c_hi - kpos) & 7u;
+			hw = *reinterpret_cast<const u32x4 *>(rd + ((hidx + rot) & 7u) * 16u);
+			tw = *reinterpret_cast<const u32x4 *>(rd + ((tidx + rot) & 7u) * 16u);
 		}
 		__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile in registers (slot reusable), ring written */
 		__asm__ volatile("" ::: "memory");
@@ -1227,7 +1266,9 @@ walk_ragged(const WalkArgs a)
 			if (take) {
 				const uint64_t beg = ring[(idx & (RING - 1u)) * 2u], len = ring[(idx & (RING - 1u)) * 2u + 1u];
 				const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
-				nq0 = p0 & ~(uint64_t)15;
+				/* segments start at a 16-byte boundary, or (early bit 3) at a 128-byte one: every DMA row is then
+				 * exactly one cache line, at the price of up to 7 empty chunks in the input's first segment */
+				nq0 = p0 & ~(uint64_t)((a.early & 8u) ? 127 : 15);
 				nhead = (uint32_t)(p0 - nq0);
 				nspan = len ? nhead + len : 0;
 				nnch = (uint32_t)((nspan + 15u) / 16u);
@@ -1279,11 +1320,11 @@ walk_ragged(const WalkArgs a)
 		 * predicating every byte of every chunk (with 64 ragged lanes some lane is nearly always in a
 		 * partial chunk: the first version of this kernel spent 7 VALU operations per byte on that). */
 		if (tile && have) {
-			const uint32_t c_lo = head != 0u ? 1u : 0u;      /* first full chunk of the input */
-			const uint32_t c_hi = (uint32_t)(span >> 4);     /* one past its last full chunk = index of the tail */
-			if (kpos == 0u && head != 0u)
-				step16_part(pol, st, w[0], head, (span < 16u ? (uint32_t)span : 16u) - head);
-			u32x4 tw = w[0];
+			const uint32_t hc = head >> 4, hlo = head & 15u;     /* chunk and offset of the first byte */
+			if (kpos == 0u && hlo != 0u) {
+				const uint64_t hend = span - (uint64_t)hc * 16u;  /* bytes from that chunk's start to the input's end */
+				step16_part(pol, st, hw, hlo, (hend < 16u ? (uint32_t)hend : 16u) - hlo);
+			}
 #pragma unroll
 			for (uint32_t p = 0; p < 8; p++) {
 				const uint32_t k = kpos + p;
@@ -1293,13 +1334,9 @@ walk_ragged(const WalkArgs a)
 					step16<Pol, 1>(pol, s1, w1);
 					st = s1[0];
 				}
-				if (p != 0u) {
-					const bool is_tail = k == c_hi;
-					tw.x = is_tail ? w[p].x : tw.x; tw.y = is_tail ? w[p].y : tw.y;
-					tw.z = is_tail ? w[p].z : tw.z; tw.w = is_tail ? w[p].w : tw.w;
-				}
 			}
 			const uint32_t tail = (uint32_t)span & 15u;
+			/* the tail chunk, unless it is the head chunk (an input that ends inside its first chunk) */
 			if (tail != 0u && c_hi >= c_lo && c_hi >= kpos && c_hi < kpos + 8u)
 				step16_part(pol, st, tw, 0u, tail);
 		}

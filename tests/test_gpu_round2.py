@@ -271,14 +271,15 @@ def test_ragged_kernel_length_distributions(hip, name, alpha):
                 dfa = hip.HipDfa(g.flat, L)
             except OSError:
                 continue
-            for mode, waves in ((hip.IN_RAGGED, 0), (hip.IN_RAGGED, 1), (hip.IN_RAGGED, 7), (hip.IN_GENERIC, 0)):
+            for mode, waves, align in ((hip.IN_RAGGED, 0, 0), (hip.IN_RAGGED, 1, 1), (hip.IN_RAGGED, 7, 0), (hip.IN_RAGGED, 0, 1), (hip.IN_GENERIC, 0, 0)):
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_RAGGED_ALIGN, align)      # an input's segments start at a 16- or a 128-byte boundary
                 for early in (1, 0):
                     dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                     end, bm = dfa.exec_batch_offsets(base, off)
-                    assert np.array_equal(end, want), (name, cname, L, mode, waves, early)
-                    assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, early)
+                    assert np.array_equal(end, want), (name, cname, L, mode, waves, align, early)
+                    assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, align, early)
             dfa.close()
     # stride + lengths through the ragged kernel, with the id and resume fronts
     rows = a[rng.randint(0, len(a), (4000, 272))]

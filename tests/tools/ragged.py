@@ -42,10 +42,11 @@ def main():
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
             ref = None
-            for front, mode, waves in (("packed", 3, 0), ("packed", 3, 8), ("packed", 3, 6), ("packed", 3, 4), ("packed", 2, 0),
-                                       ("stride+len", 3, 0), ("stride+len", 2, 0)):
+            for front, mode, waves, align in (("packed", 3, 0, 0), ("packed", 3, 0, 1), ("packed", 3, 6, 0), ("packed", 2, 0, 0),
+                                              ("stride+len", 3, 0, 0), ("stride+len", 3, 0, 1), ("stride+len", 2, 0, 0)):
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_RAGGED_ALIGN, align)
                 ms = []
                 for r in range(4):
                     if front == "packed":
@@ -60,7 +61,7 @@ def main():
                 if ref is None:
                     ref = end.clone()
                 ok = ok and bool(torch.equal(ref, end))
-                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode} waves={waves:2d} ms={min(ms):8.3f} "
+                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode} waves={waves:2d} align128={align} ms={min(ms):8.3f} "
                       f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
             dfa.close()
 
