@@ -18,9 +18,10 @@ Workloads (BASELINE.json configs):
       right-anchored, end-id = literal), built by the library's own fsm_hip_strings_* builder; 1e7 x 1 KiB
       inputs over the same alphabet, every 8th ending with a literal.  Table > LDS: bound by L2 gather
       requests, not by HBM.
+  c3t the transition-dense twin of c3 (not a BASELINE config): 1 024 patterns ^<pfx>([0-9][a-f])+(x|yz)$, half the
+      rows alternating digit / letter, so a live row changes state on every byte and no chunk can be skipped.
 At N = 1 the line carries the other configs as `sub_results` (each with its own roofline, cpu_baseline and
-parity): c3 with the chunk skip disabled (every byte pays its lookup test: the transition-dense bound of
-the same table), c2, c5.  N > 1 defaults to configs[3]'s shard, 1.25e8 inputs per GPU.
+parity): c3 with the chunk skip disabled (every byte pays its lookup test), c3t, c2, c5.  N > 1 defaults to configs[3]'s shard, 1.25e8 inputs per GPU.
 The c2/c3 DFA tables come from tests/golden/{c1,c3}.npz (flattened from the real reference by
 tests/golden/make_golden.py); /root/reference is not needed at run time.
 """
@@ -46,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5"])
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
     ap.add_argument("--n", "--inputs", dest="n", type=int, default=0,
@@ -68,9 +69,9 @@ def parse():
     return ap.parse_args()
 
 
-def c3_affixes():
-    pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
-    return [p[1:p.index(b"[")] for p in pats], [b"x", b"yz"]
+def c3_affixes(which="c3"):
+    pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", which + ".npz"))["patterns"]).split(b"\n")
+    return [p[1:p.index(b"[" if which == "c3" else b"(")] for p in pats], [b"x", b"yz"]
 
 
 ALPHA64 = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-"
@@ -121,6 +122,9 @@ def generate(hip, workload, d_ptr, n, L, first, words=None, buf=None):
         return
     if workload == "c2":
         hip.gen_inputs_device(d_ptr, n, L, first, SEED, None, b"Libfsm", 8)
+    elif workload == "c3t":   # pattern rows alternate digit / [a-f] after the prefix: a state change on every byte
+        pf, sf = c3_affixes("c3t")
+        hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
     else:
         pf, sf = c3_affixes()
         hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
@@ -133,6 +137,9 @@ def generate_host(hip, workload, n, L, first, words=None):
         return rows
     if workload == "c2":
         return hip.gen_inputs_host(n, L, first, SEED, None, b"Libfsm", 8)
+    if workload == "c3t":
+        pf, sf = c3_affixes("c3t")
+        return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
     pf, sf = c3_affixes()
     return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
 
@@ -193,7 +200,7 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
         f = pyoracle.RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
         nfe, nho = nrows, nrows
     else:
-        pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", "c3.npz"))["patterns"]).split(b"\n")
+        pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", workload + ".npz"))["patterns"]).split(b"\n")
         f = pyoracle.RefFsm.union_res("pcre", pats, 0)
         nfe, nho = min(nrows, 1500), min(nrows, 40000)  # fsm_exec re-runs fsm_all(isdfa) per call: ~9 ms/call on 4k states
     fe_idx = np.linspace(0, nrows - 1, nfe).astype(np.int64)      # the fsm_exec subset is spread over the sample too
@@ -262,6 +269,8 @@ def full_parity(torch, flat, buf, end, n, L):
 WORKLOAD_TEXT = {
     "c2": "c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), ",
     "c3": "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, ",
+    "c3t": ("c3t: the transition-dense twin of configs[2] -- 1024 patterns ^<pfx>([0-9][a-f])+(x|yz)$ unioned into one %d-state DFA, "
+            "half the rows alternating digit / letter so that a live row changes state on EVERY byte, "),
     "c5": "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), ",
 }
 
@@ -330,7 +339,7 @@ def main():
             # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
             flat = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
         else:
-            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
+            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
         flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
         dfa = hip.HipDfa(flat, flags)
         for knob, v in ((hip.KNOB_INPUT_MODE, a.input_mode), (hip.KNOB_NB, a.nb), (hip.KNOB_WAVES, a.waves),
@@ -422,7 +431,7 @@ def main():
                                       f"workload at this size (kernel {str(t.get('kernel'))[:60]}); recorded, not measured in this run")
             except Exception:
                 traffic = None
-        text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl == "c3" else (len(words), flat.nstates) if wl == "c5" else ())
+        text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl in ("c3", "c3t") else (len(words), flat.nstates) if wl == "c5" else ())
         if variant == "noskip":
             text += "chunk skip disabled (every byte pays its self-loop test: the transition-dense bound of this table), "
         res = {
@@ -474,7 +483,7 @@ def main():
         plan = []
         if a.workload == "c3":
             plan.append(("c3", "noskip", None))
-        for wl in ("c3", "c2", "c5"):
+        for wl in ("c3", "c3t", "c2", "c5"):
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
         for wl, variant, n_wl in plan:

@@ -416,6 +416,27 @@ void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
 	const unsigned char *suffixes, unsigned nsfx,
 	unsigned every);
 
+/* The same with an ALTERNATING body: positions after the prefix take bytes of `body` and `body2` in turn
+ * (a transition-dense stream for patterns like ^ab([0-9][a-f])+(x|yz)$: every byte changes the state), and the
+ * suffix is the first one, from the hashed choice on, that leaves a whole number of pairs.  nbody2 <= 64. */
+int fsm_hip_gen_affix2_inputs_device(void *d_base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *body2, unsigned nbody2,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every, void *hip_stream);
+
+void fsm_hip_gen_affix2_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *body2, unsigned nbody2,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every);
+
 /* ------------------------------------------------------------------ */
 /* literal sets: the Aho-Corasick caller of the path                   */
 /* ------------------------------------------------------------------ */

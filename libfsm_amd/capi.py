@@ -678,30 +678,34 @@ def pack_affixes(items: Sequence[bytes]) -> np.ndarray:
 
 
 def gen_affix_inputs_host(n: int, stride: int, first_index: int, seed: int, alphabet: bytes, body: bytes,
-                          prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2) -> np.ndarray:
+                          prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2, body2: Optional[bytes] = None) -> np.ndarray:
+    """body2: alternate body / body2 byte by byte after the prefix (fsm_hip_gen_affix2_inputs_host)."""
     lib = load_library()
-    lib.fsm_hip_gen_affix_inputs_host.restype = None
+    lib.fsm_hip_gen_affix2_inputs_host.restype = None
     out = np.empty((n, stride), dtype=np.uint8)
     a, b = _gen_args(alphabet, body)
+    b2 = np.frombuffer(bytes(body2), dtype=np.uint8).copy() if body2 else None
     p, s = pack_affixes(prefixes), pack_affixes(suffixes)
-    lib.fsm_hip_gen_affix_inputs_host(_ptr(out), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index), C.c_uint64(seed),
-                                      _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)), _ptr(p), C.c_uint(len(p)),
-                                      _ptr(s), C.c_uint(len(s)), C.c_uint(every))
+    lib.fsm_hip_gen_affix2_inputs_host(_ptr(out), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index), C.c_uint64(seed),
+                                       _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)), _ptr(b2), C.c_uint(len(b2) if b2 is not None else 0),
+                                       _ptr(p), C.c_uint(len(p)), _ptr(s), C.c_uint(len(s)), C.c_uint(every))
     return out
 
 
 def gen_affix_inputs_device(d_base: int, n: int, stride: int, first_index: int, seed: int, alphabet: bytes, body: bytes,
-                            prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2, stream: int = 0):
+                            prefixes: Sequence[bytes], suffixes: Sequence[bytes], every: int = 2, stream: int = 0, body2: Optional[bytes] = None):
     lib = load_library()
     a, b = _gen_args(alphabet, body)
+    b2 = np.frombuffer(bytes(body2), dtype=np.uint8).copy() if body2 else None
     p, s = pack_affixes(prefixes), pack_affixes(suffixes)
     C.set_errno(0)
-    r = lib.fsm_hip_gen_affix_inputs_device(C.c_void_p(d_base), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index),
-                                            C.c_uint64(seed), _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)),
-                                            _ptr(p), C.c_uint(len(p)), _ptr(s), C.c_uint(len(s)), C.c_uint(every),
-                                            C.c_void_p(stream or None))
+    r = lib.fsm_hip_gen_affix2_inputs_device(C.c_void_p(d_base), C.c_size_t(stride), C.c_size_t(n), C.c_uint64(first_index),
+                                             C.c_uint64(seed), _ptr(a), C.c_uint(len(a)), _ptr(b), C.c_uint(len(b)),
+                                             _ptr(b2), C.c_uint(len(b2) if b2 is not None else 0),
+                                             _ptr(p), C.c_uint(len(p)), _ptr(s), C.c_uint(len(s)), C.c_uint(every),
+                                             C.c_void_p(stream or None))
     if r != 0:
-        raise _oserr("fsm_hip_gen_affix_inputs_device")
+        raise _oserr("fsm_hip_gen_affix2_inputs_device")
 
 
 def stream_read_probe_gbps(d_base: int, nbytes: int, d_scratch4: int, reps: int = 3, stream: int = 0) -> float:

@@ -925,12 +925,15 @@ extern "C" void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size
 
 /* ---- affix generator (see walk_kernels.h) ---- */
 
-static int fill_affix(AffixArgs &x, const unsigned char *body, unsigned nbody, unsigned npfx, unsigned nsfx, unsigned every)
+static int fill_affix(AffixArgs &x, const unsigned char *body, unsigned nbody, const unsigned char *body2, unsigned nbody2,
+	unsigned npfx, unsigned nsfx, unsigned every)
 {
 	memset(&x, 0, sizeof x);
-	if (body == nullptr || nbody == 0 || nbody > 256 || npfx == 0 || nsfx == 0 || every == 0) return -1;
-	x.npfx = npfx; x.nsfx = nsfx; x.every = every; x.nbody = nbody;
+	if (body == nullptr || nbody == 0 || nbody > 256 || npfx == 0 || nsfx == 0 || every == 0 ||
+	    nbody2 > sizeof x.body2 || (nbody2 != 0 && body2 == nullptr)) return -1;
+	x.npfx = npfx; x.nsfx = nsfx; x.every = every; x.nbody = nbody; x.nbody2 = nbody2;
 	memcpy(x.body, body, nbody);
+	if (nbody2) memcpy(x.body2, body2, nbody2);
 	return 0;
 }
 
@@ -941,10 +944,11 @@ static int check_affixes(const unsigned char *t, unsigned n, size_t stride)
 	return 0;
 }
 
-extern "C" int fsm_hip_gen_affix_inputs_device(void *d_base, size_t stride, size_t n,
+extern "C" int fsm_hip_gen_affix2_inputs_device(void *d_base, size_t stride, size_t n,
 	uint64_t first_index, uint64_t seed,
 	const unsigned char *alphabet, unsigned nalpha,
 	const unsigned char *body, unsigned nbody,
+	const unsigned char *body2, unsigned nbody2,
 	const unsigned char *prefixes, unsigned npfx,
 	const unsigned char *suffixes, unsigned nsfx,
 	unsigned every, void *hip_stream)
@@ -956,7 +960,7 @@ extern "C" int fsm_hip_gen_affix_inputs_device(void *d_base, size_t stride, size
 	int rc = -1;
 	if (stride == 0 || stride % 8u != 0 || (reinterpret_cast<uintptr_t>(d_base) % 8u) != 0 ||
 	    fill_gen(g, d_base, stride, n, first_index, seed, alphabet, nalpha, nullptr, 0, 0) != 0 ||
-	    fill_affix(x, body, nbody, npfx, nsfx, every) != 0 ||
+	    fill_affix(x, body, nbody, body2, nbody2, npfx, nsfx, every) != 0 ||
 	    check_affixes(prefixes, npfx, stride) != 0 || check_affixes(suffixes, nsfx, stride) != 0) {
 		errno = EINVAL;
 		return -1;
@@ -985,10 +989,23 @@ fail:
 	return rc;
 }
 
-extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
+extern "C" int fsm_hip_gen_affix_inputs_device(void *d_base, size_t stride, size_t n,
 	uint64_t first_index, uint64_t seed,
 	const unsigned char *alphabet, unsigned nalpha,
 	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every, void *hip_stream)
+{
+	return fsm_hip_gen_affix2_inputs_device(d_base, stride, n, first_index, seed, alphabet, nalpha, body, nbody, nullptr, 0,
+	                                        prefixes, npfx, suffixes, nsfx, every, hip_stream);
+}
+
+extern "C" void fsm_hip_gen_affix2_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *body2, unsigned nbody2,
 	const unsigned char *prefixes, unsigned npfx,
 	const unsigned char *suffixes, unsigned nsfx,
 	unsigned every)
@@ -996,7 +1013,7 @@ extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride
 	GenArgs g;
 	AffixArgs x;
 	if (fill_gen(g, base, stride, n, first_index, seed, alphabet, nalpha, nullptr, 0, 0) != 0 ||
-	    fill_affix(x, body, nbody, npfx, nsfx, every) != 0 ||
+	    fill_affix(x, body, nbody, body2, nbody2, npfx, nsfx, every) != 0 ||
 	    check_affixes(prefixes, npfx, stride) != 0 || check_affixes(suffixes, nsfx, stride) != 0) return;
 	x.pfx = prefixes;
 	x.sfx = suffixes;
@@ -1007,6 +1024,18 @@ extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride
 			for (size_t k = 0; k < 8 && t + k < stride; k++) p[t + k] = (unsigned char)(v >> (8 * k));
 		}
 	}
+}
+
+extern "C" void fsm_hip_gen_affix_inputs_host(unsigned char *base, size_t stride, size_t n,
+	uint64_t first_index, uint64_t seed,
+	const unsigned char *alphabet, unsigned nalpha,
+	const unsigned char *body, unsigned nbody,
+	const unsigned char *prefixes, unsigned npfx,
+	const unsigned char *suffixes, unsigned nsfx,
+	unsigned every)
+{
+	fsm_hip_gen_affix2_inputs_host(base, stride, n, first_index, seed, alphabet, nalpha, body, nbody, nullptr, 0,
+	                               prefixes, npfx, suffixes, nsfx, every);
 }
 
 /* ---- HBM read-stream probe ---- */

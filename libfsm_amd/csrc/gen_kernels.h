@@ -76,8 +76,9 @@ gen_inputs_kernel(const GenArgs g)
  * [len, b0..b6]. */
 struct AffixArgs {
 	const unsigned char *pfx, *sfx; /* npfx / nsfx entries of 8 bytes */
-	uint32_t npfx, nsfx, every, nbody;
+	uint32_t npfx, nsfx, every, nbody, nbody2;
 	unsigned char body[256];
+	unsigned char body2[64];        /* nbody2 > 0: the body alternates body / body2 byte by byte, counted from the end of the prefix */
 };
 
 __host__ __device__ __forceinline__ uint64_t affix_word(const GenArgs &g, const AffixArgs &x, uint64_t gi, uint64_t wi)
@@ -86,12 +87,22 @@ __host__ __device__ __forceinline__ uint64_t affix_word(const GenArgs &g, const 
 	const uint64_t r = mix64(g.seed ^ (gi * 0x9E3779B97F4A7C15ull) ^ wi);
 	const uint64_t h = mix64(g.seed ^ gi ^ 0x5A5A5A5A5A5A5A5Aull);
 	const unsigned char *pe = x.pfx + 8u * (uint32_t)((h & 0xffffffffu) % x.npfx);
-	const unsigned char *se = x.sfx + 8u * (uint32_t)((h >> 32) % x.nsfx);
-	const uint32_t pl = pe[0], sl = se[0];
+	uint32_t si = (uint32_t)((h >> 32) % x.nsfx);
+	const uint32_t pl = pe[0];
+	if (x.nbody2 != 0) {
+		/* alternating body: take the first suffix (from si on) that leaves a whole number of pairs */
+		for (uint32_t t = 0; t < x.nsfx; t++) {
+			const uint32_t cand = (si + t) % x.nsfx;
+			if (((g.stride - pl - x.sfx[8u * cand]) & 1u) == 0u) { si = cand; break; }
+		}
+	}
+	const unsigned char *se = x.sfx + 8u * si;
+	const uint32_t sl = se[0];
 	uint64_t o = 0;
 	for (int k = 0; k < 8; k++) {
 		const uint64_t pos = wi * 8u + k;
-		unsigned char b = x.body[((r >> (8 * k)) & 0xff) % x.nbody];
+		const uint32_t rb = (uint32_t)((r >> (8 * k)) & 0xff);
+		unsigned char b = (x.nbody2 != 0 && ((pos - pl) & 1u)) ? x.body2[rb % x.nbody2] : x.body[rb % x.nbody];
 		if (pos < pl) b = pe[1 + pos];
 		else if (pos >= g.stride - sl) b = se[1 + (pos - (g.stride - sl))];
 		o |= (uint64_t)b << (8 * k);

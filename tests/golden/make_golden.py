@@ -296,6 +296,34 @@ def gen_c3():
     print("c3: accepts", int((ret == 1).sum()), "of", len(ret), "multi-id ends", int(sum(1 for k in range(len(ret)) if io[k + 1] - io[k] > 1)))
 
 
+def c3t_patterns(n=1024, seed=C3_SEED + 7):
+    """The transition-dense twin of C3: 1 024 patterns ^<2-3 lowercase>([0-9][a-f])+(x|yz)$ -- a row that stays alive
+    alternates between two states on every byte, so no 16-byte chunk is ever a run of self-loops."""
+    rng = random.Random(seed)
+    pats = []
+    while len(pats) < n:
+        k = 2 if rng.random() < 0.62 else 3
+        pre = "".join(rng.choice("ghijklmnopqrstuvwxyz") for _ in range(k))   # prefixes avoid [a-f], the pair's second class
+        pats.append(f"^{pre}([0-9][a-f])+(x|yz)$".encode())
+    return pats
+
+
+def gen_c3t():
+    from libfsm_amd import gen_affix_inputs_host
+    pats = c3t_patterns()
+    f = RefFsm.union_res("pcre", pats, 0)
+    flat = f.flatten()
+    print("c3t: states", flat.nstates, "end states", int(flat.is_end.sum()))
+    pf = [p[1:p.index(b"(")] for p in pats]
+    data = gen_affix_inputs_host(512, 1024, 0, 0x5EEDF5A1, b"abcdefghijklmnopqrstuvwxyz0123456789", b"0123456789", pf, [b"x", b"yz"], 2, body2=b"abcdef")
+    ret, end = f.exec_stride(data)
+    io, ii = endid_csr(f, end)
+    flat.save(os.path.join(OUT, "c3t.npz"), in_rows=data, ret=ret, end=end, ids_off=io, ids=ii,
+              patterns=np.frombuffer(b"\n".join(pats), np.uint8),
+              meta=np.frombuffer(json.dumps(dict(source="transition-dense twin of BASELINE.json configs[2]", seed=C3_SEED + 7, npatterns=len(pats))).encode(), np.uint8))
+    print("c3t: accepts", int((ret == 1).sum()), "of", len(ret))
+
+
 def c_unescape(lit: str) -> bytes:
     """A C string literal body -> bytes (the escapes the reference's test sources use)."""
     out, i = bytearray(), 0
@@ -598,6 +626,7 @@ if __name__ == "__main__":
     gen_re_strings()
     gen_c1()
     gen_c3()
+    gen_c3t()
     gen_eager()
     gen_fsm_corpus()
     gen_recorded()
