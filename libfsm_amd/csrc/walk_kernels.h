@@ -138,7 +138,7 @@ struct TinyPol {
 	const W *colp; /* LDS column table, already offset by lane%32 */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 32u * (uint32_t)sizeof(W); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		W *col = reinterpret_cast<W *>(lds);
 		const uint64_t *src = static_cast<const uint64_t *>(a.tab);
@@ -211,7 +211,7 @@ struct Tiny5Pol {
 	uint32_t lanebase;         /* LDS byte address of this lane's copy of column 0: table base + (lane << 2) */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t) { return 256u * 64u * 4u; }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		uint32_t *col = reinterpret_cast<uint32_t *>(lds);
 		const uint32_t *src = static_cast<const uint32_t *>(a.tab);
@@ -244,7 +244,7 @@ struct LdsPol {
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
@@ -279,7 +279,7 @@ struct LdsSelfPol {
 	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
@@ -322,7 +322,7 @@ struct CombPol {
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
@@ -349,7 +349,7 @@ struct Comb256Pol {
 	uint32_t abs_min, dflt;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		copy_table(lds, a);
 		comb = reinterpret_cast<const uint32_t *>(lds);
@@ -388,7 +388,7 @@ struct CombSelfPol {
 	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		/* device image = comb64[n] (8 B each), dsm[32] (8 B each), smask[n]; LDS gets the first two parts */
 		bp = setup_btab(lds, a);
@@ -451,7 +451,7 @@ struct GlobPol {
 	uint32_t abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
@@ -488,15 +488,18 @@ struct SparsePol {
 	__device__ __forceinline__ S init(uint32_t code) const { return code; }
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	typedef const u32x4 __attribute__((address_space(3))) *lds_rec_p;
+	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
 	const uint16_t *pm;        /* LDS: byte -> class | bit << 8 */
 	const uint32_t *ldense;    /* LDS: first dense rows         */
-	const u32x4 *lrec;         /* LDS: first H records          */
+	const u32x4 *lrec;         /* LDS: first H records (generic pointer: see the note on flat loads above) */
+	uint32_t lrec_lds;         /* the same as an LDS byte address, for the turns that are known to stay in LDS */
 	const u32x4 *grec;
 	const uint32_t *gdense, *exc;
 	uint32_t H, HDE, abs_min;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		copy_table(lds, a);
 		const uint32_t *hdr = static_cast<const uint32_t *>(a.tab);
@@ -506,6 +509,7 @@ struct SparsePol {
 		pm = reinterpret_cast<const uint16_t *>(lds + 64);
 		ldense = reinterpret_cast<const uint32_t *>(lds + hdr[3]);
 		lrec = reinterpret_cast<const u32x4 *>(lds + hdr[4]);
+		lrec_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + hdr[4]);
 		grec = reinterpret_cast<const u32x4 *>(g + hdr[5]);
 		gdense = reinterpret_cast<const uint32_t *>(g + hdr[6]);
 		exc = reinterpret_cast<const uint32_t *>(g + hdr[7]);
@@ -524,16 +528,26 @@ struct SparsePol {
 		 * that moves on to the base -- are computed straight-line and selected; only the rare ones (a
 		 * dense row, a hit on a record that still owns an exception list) branch.  The walk is bound by
 		 * the instructions of this loop: every path is live in some lane of a 64-lane wave. */
+		/* first turn: the record of the state itself, LDS or global (one flat load of a selected address) */
+		bool first = true;
 		while (live) {
 			u32x4 r;
-			if (st < H) r = lrec[st]; else r = grec[st];
+			if (first) {
+				if (st < H) r = lrec[st]; else r = grec[st];
+			} else {
+				/* later turns visit bases, and a base is nearly always one of the LDS-resident records
+				 * nearest the start state: a plain ds_read_b128, no address selection */
+				if (__builtin_expect(st < H, 1)) r = *(lds_rec_p)(uintptr_t)(lrec_lds + st * 16u);
+				else r = grec[st];
+			}
+			first = false;
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
 			const bool hit = (bits & sel) != 0u;
 			const uint32_t id = r.z & 0x1FFFFFFFu;
 			const bool dense = (r.z & 0x80000000u) != 0u;            /* a dense record has no bits */
 			const bool fb = !hit && hasbit && (r.z & 0x20000000u) != 0u;
 			uint32_t v = r.w + (uint32_t)__popcll(bits & below);
-			if (fb) v = lrec[id].w + bit;
+			if (fb) v = *(lds_u32_p)(uintptr_t)(lrec_lds + id * 16u + 12u) + bit;
 			if (dense || (hit && !(r.z & 0x40000000u))) {
 				if (dense) {
 					const uint32_t o = r.w + cls;
@@ -570,7 +584,7 @@ struct EagerPol : Pol {
 	const uint64_t *emask;
 	uint32_t lo_end, hi_begin, span, fin_div, abs_min_code;
 
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		Pol::setup(lds, a);
 		abs_min_code = a.abs_min;
@@ -664,7 +678,7 @@ struct EagerWidePol : Pol {
 	const uint64_t *ew_mask;
 	uint32_t lo_end, hi_begin, fin_div, abs_min_code;
 
-	__device__ void setup(unsigned char *lds, const WalkArgs &a)
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		Pol::setup(lds, a);
 		abs_min_code = a.abs_min;

@@ -26,6 +26,7 @@ for step in "$@"; do
 	        rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OLDPWD/gpurun_out/${TAG}_calib/req -o r -- python $OLDPWD/tools/fetch_calib.py >> $OLDPWD/gpurun_out/${TAG}_calib_run.txt 2>&1
 	        cd $OLDPWD; python tools/fetch_calib.py --read gpurun_out/${TAG}_calib/fetch gpurun_out/${TAG}_calib/req > gpurun_out/${TAG}_fetch_calib.json 2>&1; cat gpurun_out/${TAG}_fetch_calib.json | tail -12
 	        rm -rf gpurun_out/${TAG}_calib ;;
+	smoke)  timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -6 gpurun_out/${TAG}_smoke.log ;;
 	node)   timeout 300 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "node or retest" > gpurun_out/${TAG}_node.log 2>&1; tail -5 gpurun_out/${TAG}_node.log ;;
 	esac
 done
