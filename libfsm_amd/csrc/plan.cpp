@@ -728,14 +728,17 @@ static int build_comb(Plan &p, uint32_t max_entries, bool bytewise)
 
 	std::vector<uint32_t> &comb = bytewise ? p.comb256 : p.comb;
 	std::vector<uint32_t> &cfin = bytewise ? p.comb256_fin : p.comb_fin;
-	comb.assign(size, 0xFFFF0000u); /* owner 0xFFFF never matches a real offset */
+	/* owner 0xFFFF never matches a real offset.  CombPol / CombSelfPol entries are owner << 16 | next; the
+	 * bytewise form (Comb256Pol) keeps the NEXT state in the high half, next << 16 | owner: the walk then
+	 * carries the raw entry as its state and needs one 16-bit compare and one select per byte */
+	comb.assign(size, bytewise ? 0x0000FFFFu : 0xFFFF0000u);
 	cfin.assign(size, FSM_HIP_NO_MATCH);
 	for (uint32_t n = 0; n < S1; n++) {
 		uint32_t o = off[n];
 		cfin[o] = p.fin[n];
 		for (uint32_t w = 0; w < W; w++) {
 			uint32_t t = cell(n, w);
-			if (t != dflt[w]) comb[o + w] = (o << 16) | off[t];
+			if (t != dflt[w]) comb[o + w] = bytewise ? (off[t] << 16) | o : (o << 16) | off[t];
 		}
 	}
 	if (p.emask.empty()) { eager_lo_off = 0; eager_hi_off = 0xFFFFFFFFu; }

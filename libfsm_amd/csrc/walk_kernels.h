@@ -341,26 +341,31 @@ struct CombPol {
 struct Comb256Pol {
 	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
+	/* the state is carried as the raw comb entry that led to it: next state (a row offset) in the high half,
+	 * whatever owner tag the entry had in the low half.  That shortens the dependent chain per byte to
+	 * bfe (state) -> add_lshl (address) -> ds_read -> 16-bit compare (owner tag == state) -> select:
+	 * 4 vector operations where the owner << 16 | next form needed 7 (the walk is bound by the latency of
+	 * this chain times the 16 waves a 91 KB table leaves room for, not by LDS bandwidth) */
 	typedef uint32_t S;
-	__device__ __forceinline__ S init(uint32_t code) const { return code; }
-	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ S init(uint32_t code) const { return code << 16; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s >> 16; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
-	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte */
-	uint32_t abs_min, dflt;
+	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte: next << 16 | owner */
+	uint32_t dflt_e;        /* the default state in entry form */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
 	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
 		copy_table(lds, a);
 		comb = reinterpret_cast<const uint32_t *>(lds);
-		abs_min = a.abs_min;
-		dflt = a.dflt;
+		dflt_e = a.dflt << 16;
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return b; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P b) const
+	__device__ __forceinline__ S next(S s, P b) const
 	{
-		const uint32_t x = comb[st + b] ^ (st << 16);
-		return x < 0x10000u ? x : dflt;
+		const uint32_t st = s >> 16;
+		const uint32_t e = comb[st + b];
+		return (uint16_t)e == (uint16_t)st ? e : dflt_e;
 	}
 };
 
@@ -516,10 +521,28 @@ struct SparsePol {
 		abs_min = a.abs_min;
 	}
 	__device__ __forceinline__ P pre(uint32_t b) const { return pm[b]; }
-	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const
+	__device__ __forceinline__ uint32_t next(uint32_t st, P p) const { return next_t<false>(st, p); }
+	/* A chunk whose 16 bytes all belong to classes that own a bit (on a literal set: every byte of its
+	 * alphabet) is walked with the `has a bit` tests compiled out: one wave vote per chunk saves five
+	 * operations per byte */
+	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
+	{
+		uint32_t mx = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) mx = pre[k] > mx ? pre[k] : mx;
+		if (__all((mx >> 8) < 64u)) {
+#pragma unroll
+			for (int k = 0; k < 16; k++) st = next_t<true>(st, pre[k]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 16; k++) st = next_t<false>(st, pre[k]);
+		}
+	}
+	template <bool ALLBITS>
+	__device__ __forceinline__ uint32_t next_t(uint32_t st, P p) const
 	{
 		const uint32_t cls = p & 0xffu, bit = p >> 8;            /* bit 0xff: the class owns no bit */
-		const bool hasbit = bit < 64u;
+		const bool hasbit = ALLBITS || bit < 64u;
 		const uint64_t sel = hasbit ? (uint64_t)1 << bit : 0u, below = hasbit ? sel - 1u : 0u;
 		uint32_t res = st;
 		bool live = st < abs_min;

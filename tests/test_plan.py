@@ -182,8 +182,8 @@ def check_plan(flat, layout):
         cfin = p.get("comb256_fin")
         assert len(set(off.tolist())) == S1
         st = off[:, None]
-        x = comb[st + bytes_[None, :]] ^ (st << 16)
-        nxt_off = np.where(x < 0x10000, x, p.comb256_dflt)
+        e = comb[st + bytes_[None, :]]                         # next << 16 | owner
+        nxt_off = np.where((e & 0xffff) == st, e >> 16, p.comb256_dflt)
         back = np.full(len(comb), -1, np.int64)
         back[off] = np.arange(S1)
         got = back[nxt_off]
