@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-early-retire", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="inputs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--node-front", action="store_true",
+                    help="measure the C multi-device front (fsm_hip_node_*: one replica + host thread per visible GPU, one process) "
+                         "on the main workload and print its JSON; bench.py runs this by itself, in a subprocess, when N = 1 sees several GPUs")
     ap.add_argument("--full-parity", action="store_true",
                     help="after timing, stream ALL inputs back and compare every end state with the threaded CPU table walker")
     return ap.parse_args()
@@ -266,6 +269,54 @@ def full_parity(torch, flat, buf, end, n, L):
             "cpu_walk_GBps": round(n * L / 1e9 / t_cpu, 2), "checker": "oracle dense-table walker (oracle/dfa_oracle.c), all inputs"}
 
 
+def node_front(a):
+    """The C host's way to use a whole node (include/fsm_hip.h fsm_hip_node_*): ONE process, one table replica and one
+    host thread per visible GPU, device-resident shards by contiguous global index range, ONE in-place ncclAllGather of
+    the accept bitmap + one ncclAllReduce of the match count per step (RCCL bound by dlopen inside libfsm_hip.so).
+    Wall-clock around K calls of fsm_hip_node_exec_batch_device, which returns after every device has finished."""
+    import torch
+    import libfsm_amd as hip
+    hip.load_library()
+    L = a.len
+    wl = a.workload if a.workload in ("c2", "c3", "c3t") else "c3"
+    flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev))
+    if os.environ.get("FSM_BENCH_NODE_REPLICAS"):      # a rig with fewer GPUs than replicas: repeat device 0
+        devices = [0] * int(os.environ["FSM_BENCH_NODE_REPLICAS"])
+    node = hip.HipNode(flat, devices)
+    per = a.n if a.n > 0 else 100_000_000
+    n = per * len(devices) // (64 * len(devices)) * (64 * len(devices))
+    W = node.bitmap_words(n)
+    bufs, ends, bms = [], [], []
+    for k, dv in enumerate(devices):
+        f, c = node.shard(n, k)
+        torch.cuda.set_device(dv)
+        b = torch.empty((max(c, 1), L), dtype=torch.uint8, device=f"cuda:{dv}")
+        generate(hip, wl, b.data_ptr(), c, L, f)
+        bufs.append(b)
+        ends.append(torch.empty(max(c, 1), dtype=torch.int32, device=f"cuda:{dv}"))
+        bms.append(torch.zeros(W, dtype=torch.int64, device=f"cuda:{dv}"))
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    torch.cuda.set_device(devices[0])
+    args = ([b.data_ptr() for b in bufs], L, n, [e.data_ptr() for e in ends], [m.data_ptr() for m in bms])
+    for _ in range(4 + a.warmup):
+        cnt = node.exec_batch_device(*args, want_count=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cnt = node.exec_batch_device(*args, want_count=True)
+    el = time.perf_counter() - t0
+    # every replica holds the whole bitmap; its popcount is the reduced match count
+    same = all(int(np.unpackbits(m.cpu().numpy().view(np.uint8)).sum()) == cnt for m in bms[:2])
+    out = {"front": "fsm_hip_node_exec_batch_device (C ABI, one process, one host thread per device)", "devices": devices,
+           "uses_rccl": node.uses_rccl(), "workload": wl, "inputs_total": n, "input_len": L, "steps": a.steps,
+           "ms_per_step": round(el / a.steps * 1e3, 4), "value_GBps": round(n * L / (el / a.steps) / 1e9, 2),
+           "accepted_inputs": int(cnt), "bitmap_popcount_matches_count_on_every_checked_replica": bool(same)}
+    node.close()
+    print(json.dumps(out), flush=True)
+
+
 WORKLOAD_TEXT = {
     "c2": "c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), ",
     "c3": "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, ",
@@ -277,6 +328,10 @@ WORKLOAD_TEXT = {
 
 def main():
     a = parse()
+    if a.node_front:
+        import __graft_entry__ as ge
+        ge.build()
+        return node_front(a)
     import torch
     import torch.distributed as dist
 
@@ -516,6 +571,21 @@ def main():
     for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity"):
         if k in main_res:
             res[k] = main_res[k]
+    # N = 1 on a box that shows several GPUs: the C multi-device front on all of them, in a subprocess of its own
+    # (its failure must not cost the line above); FSM_BENCH_NODE_FRONT=1 forces it on a one-GPU box
+    if world == 1 and a.subs == "auto" and a.n == 0 and (torch.cuda.device_count() > 1 or os.environ.get("FSM_BENCH_NODE_FRONT")):
+        import subprocess
+        del buf, bm
+        buf_all = end_all = None
+        torch.cuda.empty_cache()
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--node-front", "--workload", a.workload, "--steps", str(a.steps),
+                   "--warmup", str(a.warmup), "--len", str(L)]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            res["node_front"] = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
+        except Exception as e:  # noqa: BLE001
+            res["node_front"] = {"error": repr(e)[:300]}
     if subs:
         res["sub_results"] = subs
         if any(s.get("parity_vs_cpu_sample") == "MISMATCH" for s in subs):

@@ -567,3 +567,20 @@ def test_node_front_shards_and_gathers(hip, devices):
     e = int(want[want != NO][0])
     assert np.array_equal(r0.endids(e), o.endids(e))
     node.close()
+
+
+def test_bench_node_front_mode(hip):
+    """bench.py --node-front: the C multi-device front measured the way bench.py runs it for itself when N = 1 sees
+    several GPUs -- here with two replicas on the one GPU (peer-copy exchange) and with the single device (RCCL)."""
+    import json
+    import sys
+    for env_extra, ndev, rccl in (({"FSM_BENCH_NODE_REPLICAS": "2"}, 2, False), ({}, 1, True)):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--node-front", "--n", "200000", "--steps", "2", "--warmup", "1"],
+                             capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert len(r["devices"]) == ndev and r["uses_rccl"] == rccl and r["workload"] == "c3"
+        assert r["inputs_total"] == 200000 * ndev // (64 * ndev) * (64 * ndev)
+        assert r["accepted_inputs"] == r["inputs_total"] // 2 and r["bitmap_popcount_matches_count_on_every_checked_replica"]
+        assert r["value_GBps"] > 0
