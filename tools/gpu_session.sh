@@ -11,6 +11,7 @@ for step in "$@"; do
 	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
 	fullpar) timeout 900 python bench.py --steps 5 --warmup 2 --subs none --full-parity > gpurun_out/${TAG}_bench_fullparity.json 2> gpurun_out/${TAG}_bench_fullparity.err; echo "fullparity rc=$?"; python -c "import json,sys; r=json.loads(open('gpurun_out/${TAG}_bench_fullparity.json').read().strip().splitlines()[-1]); print(r['value'], r.get('full_parity'))" ;;
+	benchnode) FSM_BENCH_NODE_FRONT=1 FSM_BENCH_NODE_REPLICAS=2 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_benchnode.json 2> gpurun_out/${TAG}_benchnode.err; echo "benchnode rc=$?"; python -c "import json; r=json.loads(open('gpurun_out/${TAG}_benchnode.json').read().strip().splitlines()[-1]); print(r['value'], r.get('node_front'))" ;;
 	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
