@@ -62,7 +62,8 @@ enum {
 	FSM_HIP_PLAN_EW_OFF      = 19, /* u32[S1+1] wide eager sets (> 64 ids): per state a run of (word, mask) pairs */
 	FSM_HIP_PLAN_EW_WORD     = 20, /* u32[] */
 	FSM_HIP_PLAN_EW_MASK     = 21, /* u64[] */
-	FSM_HIP_PLAN_TINY5_COL   = 22  /* u32[256], <= 6 states: 5-bit fields of 5 * next state */
+	FSM_HIP_PLAN_TINY5_COL   = 22, /* u32[256], <= 6 states: 5-bit fields of 5 * next state */
+	FSM_HIP_PLAN_COMB_RNG    = 23  /* u16[] by comb row offset: self-loop byte range lo | hi << 8 (0x0080: none) */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

@@ -193,11 +193,12 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			break;
 		}
 		case FSM_HIP_LAYOUT_COMBSELF: {
-			/* image: comb64[n] = {entry, smask(next)}, dsm[32] (mask of each class's default state)
-			 * -- these two parts go to LDS (tab_bytes) -- then smask[n] by row offset (global only) */
+			/* image: comb64[n] = {entry, smask(next)}, dsm[32] (mask of each class's default state), rng16[n]
+			 * (self-loop byte range by row offset) -- these three parts go to LDS (tab_bytes) -- then smask[n]
+			 * by row offset (global only: seeds a walk) */
 			uint32_t *t = nullptr;
-			const size_t n = p.comb.size();
-			std::vector<uint32_t> img(2 * n + 64 + n, 0);
+			const size_t n = p.comb.size(), rw = (n + 1) / 2;   /* rng16[n] in u32 words */
+			std::vector<uint32_t> img(2 * n + 64 + rw + n, 0);
 			for (size_t k = 0; k < n; k++) {
 				img[2 * k] = p.comb[k];
 				const uint32_t nxt = p.comb[k] & 0xffffu;
@@ -207,12 +208,14 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 				img[2 * n + 2 * c] = p.comb_dflt[c];
 				img[2 * n + 2 * c + 1] = p.comb_smask[p.comb_dflt[c]];
 			}
-			for (size_t k = 0; k < n; k++) img[2 * n + 64 + k] = p.comb_smask[k];
+			for (size_t k = 0; k < n; k++) img[2 * n + 64 + k / 2] |= (uint32_t)p.comb_rng[k] << (16 * (k & 1));
+			for (size_t k = 0; k < n; k++) img[2 * n + 64 + rw + k] = p.comb_smask[k];
 			HIP_TRY(upload(&t, img));
 			d->d_tab = t;
 			HIP_TRY(upload(&d->d_fin, p.comb_fin));
 			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
-			a.tab_bytes = (uint32_t)((2 * n + 64) * 4);
+			a.tab_bytes = (uint32_t)((2 * n + 64 + rw) * 4);
+			a.dflt = (uint32_t)n;   /* entries: tells the kernel where dsm[] and rng16[] start */
 			a.start = p.comb_off[p.start];
 			a.abs_min = p.comb_abs_min_off;
 			a.fin_div = 1;
@@ -471,7 +474,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	else if (eager && mode == IN_LDSDMA) wmax = 12;
 	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
-	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16) waves = d->knob_waves;
+	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16 &&
+	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA)) waves = d->knob_waves;   /* that kernel is compiled for 12 */
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
@@ -753,7 +757,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_LDSSELF: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
-	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 8 + 256; break;
+	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 10 + 256; break;
 	case FSM_HIP_LAYOUT_SPARSE: out->table_bytes = p.sparse_img.size() * 4; break;
 	default: out->table_bytes = p.glob_tab.size() * 4; break;
 	}
@@ -853,6 +857,7 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;
 	case FSM_HIP_PLAN_COMB_SMASK: *data = p.comb_smask.data(); *count = p.comb_smask.size(); return 0;
+	case FSM_HIP_PLAN_COMB_RNG: *data = p.comb_rng.data(); *count = p.comb_rng.size(); return 0;
 	case FSM_HIP_PLAN_EMASK: *data = p.emask.data(); *count = p.emask.size(); return 0;
 	case FSM_HIP_PLAN_EAGER_IDS: *data = p.eager_ids.data(); *count = p.eager_ids.size(); return 0;
 	case FSM_HIP_PLAN_EW_OFF: *data = p.ew_off.data(); *count = p.ew_off.size(); return 0;

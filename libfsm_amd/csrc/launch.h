@@ -46,6 +46,11 @@ static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs
 	return hipGetLastError();
 }
 
+/* thread cap of the plain LDS-DMA kernel: CombSelfPol runs 12 waves behind LDS-DMA (measured best, and its
+ * range-skip state + the 32-VGPR tile want more than the 128 registers of a 16-wave workgroup) */
+template <class Pol> struct ldsdma_threads { static constexpr int value = 1024; };
+template <> struct ldsdma_threads<CombSelfPol> { static constexpr int value = 768; };
+
 /* plain walk: every input path */
 template <class Pol>
 static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
@@ -55,8 +60,8 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
 	case IN_GENERIC: k = walk_generic<Pol>; break;
 	case IN_LDSDMA:
-		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2> : walk_ldsdma<Pol, 128, 0>;
-		else k = walk_ldsdma<Pol, 64, 0>;
+		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2, ldsdma_threads<Pol>::value> : walk_ldsdma<Pol, 128, 0, ldsdma_threads<Pol>::value>;
+		else k = walk_ldsdma<Pol, 64, 0, ldsdma_threads<Pol>::value>;
 		break;
 	default:
 		if (!c.prefetch && c.nb == 4) k = walk_direct_np<Pol, 4>;

@@ -281,12 +281,22 @@ try {
 		int r = build_comb(p, max_entries, false);
 		if (r) return r;
 		p.comb_smask.assign(p.comb.size(), 0u);
+		p.comb_rng.assign(p.comb.size(), (uint16_t)0x0080u);
 		for (uint32_t n = 0; n < S1; n++) {
 			uint32_t m = 0;
 			for (uint32_t c = 0; c < C; c++)
 				if (p.dense[(size_t)n * C + c] == n) m |= 1u << c;
 			if (n >= p.abs_min) m = 0xFFFFFFFFu;
 			p.comb_smask[p.comb_off[n]] = m;
+			/* the self-loop bytes as one range, if they are one ([0-9]+, [a-z]*, .*, an absorbing state) */
+			int lo = -1, hi = -1, runs = 0;
+			for (int b = 0; b < 256; b++) {
+				const bool in = n >= p.abs_min || ((m >> p.cls[b]) & 1u);
+				if (in && (b == 0 || !(n >= p.abs_min || ((m >> p.cls[b - 1]) & 1u)))) { runs++; if (lo < 0) lo = b; }
+				if (in) hi = b;
+			}
+			if (runs == 1 && lo <= 128 && (hi <= 127 || hi == 255))
+				p.comb_rng[p.comb_off[n]] = (uint16_t)(lo | (hi << 8));
 		}
 		p.layout = FSM_HIP_LAYOUT_COMBSELF;
 		return 0;

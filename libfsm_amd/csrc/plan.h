@@ -74,6 +74,10 @@ struct Plan {
 	/* COMBSELF: comb + per-row-offset self-loop masks (bit c: class c loops to the same state;
 	 * absorbing states: all ones).  Device image = comb[] followed by comb_smask[].   */
 	std::vector<uint32_t> comb_smask;
+	/* COMBSELF: per row offset the state's self-loop BYTE set when it is one contiguous range lo..hi that a
+	 * SWAR test can check on raw input dwords (lo <= 128 and hi <= 127 or hi == 255): lo | hi << 8; 0x0080
+	 * (lo 128, hi 0: no byte passes) otherwise.  Absorbing states: 0xFF00 (every byte). */
+	std::vector<uint16_t> comb_rng;
 	double selfloop_fraction = 0.0;   /* non-absorbing states owning at least one self-loop class */
 	/* COMB256: the same over raw bytes (256-wide rows), one default state for
 	 * every column: no byte->class lookup at all in the walk.                */

@@ -378,7 +378,7 @@ struct Comb256Pol {
  * skipped by the whole wavefront when none does.  Absorbing states have every bit set, so
  * retired lanes drop out of the LDS traffic for free.  Needs <= 32 byte classes.
  */
-struct CombSelfState { uint32_t st, sm; };
+struct CombSelfState { uint32_t st, sm, rng; };
 
 struct CombSelfPol {
 	static constexpr bool heavy_next = false;
@@ -388,6 +388,7 @@ struct CombSelfPol {
 	const uint2 *comb;      /* LDS comb array of {owner_off << 16 | next_off, smask(next)}:
 	                         * one ds_read_b64 brings the next state AND its self-loop mask */
 	const uint2 *dsm;       /* LDS [32]: {row offset, self-loop mask} of each class's default state */
+	const uint16_t *rng16;  /* LDS: self-loop byte range lo | hi << 8 by row offset      */
 	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
 	uint32_t start, start_sm;
 	bool skip_on;
@@ -395,11 +396,12 @@ struct CombSelfPol {
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
 	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
 	{
-		/* device image = comb64[n] (8 B each), dsm[32] (8 B each), smask[n]; LDS gets the first two parts */
+		/* device image = comb64[n] (8 B each), dsm[32] (8 B each), rng16[n]; then smask[n] (global only) */
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		comb = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES);
-		dsm = reinterpret_cast<const uint2 *>(lds + FSMHIP_BTAB_BYTES + a.tab_bytes - 256u);
+		dsm = comb + a.dflt;   /* a.dflt = number of comb entries */
+		rng16 = reinterpret_cast<const uint16_t *>(dsm + 32);
 		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
 		start = a.start;
 		start_sm = smask0[a.start];
@@ -409,12 +411,31 @@ struct CombSelfPol {
 	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
 	__device__ __forceinline__ S init(uint32_t code) const
 	{
-		S s = { code, code == start ? start_sm : smask0[code] };
+		S s = { code, code == start ? start_sm : smask0[code], rng16[code] };
 		return s;
 	}
 	__device__ __forceinline__ static uint32_t code(S s) { return s.st; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	/*
+	 * The cheapest test first, on the raw input, before any class lookup: when a state's self-loop bytes
+	 * are one contiguous range ([0-9]+, [a-z]*, .* and every absorbing state: the planner stores lo | hi << 8
+	 * per state), "all 16 bytes of the chunk lie in lo..hi" is a SWAR test on the four dwords -- exists a
+	 * byte < lo: (x - lo*0x01010101) & ~x & 0x80808080; exists a byte > hi: ((x + (127-hi)*0x01010101) | x)
+	 * & 0x80808080 (exact for the existence question for lo <= 128, hi <= 127; hi = 255 switches the upper
+	 * test off) -- about 25 vector operations and NO LDS traffic, where the class-mask form below costs 16
+	 * LDS lookups + 32 operations.  On C3's inputs every chunk but a row's first and last passes it, and the
+	 * LDS pipe, which the DMA tiles also land in, is left to the tiles.
+	 */
+	__device__ __forceinline__ bool skip16_raw(const S &s, const u32x4 &w) const
+	{
+		const uint32_t lo = s.rng & 0xffu, hi = s.rng >> 8;
+		const uint32_t LO = lo * 0x01010101u, AD = (127u - hi) * 0x01010101u;
+		const uint32_t MM = hi == 255u ? 0u : 0x80808080u;
+		const uint32_t aL = ((w.x - LO) & ~w.x) | ((w.y - LO) & ~w.y) | ((w.z - LO) & ~w.z) | ((w.w - LO) & ~w.w);
+		const uint32_t aM = ((w.x + AD) | w.x) | ((w.y + AD) | w.y) | ((w.z + AD) | w.z) | ((w.w + AD) | w.w);
+		return skip_on && __all(((aL | (aM & MM)) & 0x80808080u) == 0u);
+	}
 	/* all 16 classes of the chunk are self-loops of every lane's state (digit runs, dead lanes):
 	 * 16 shift-ORs and one wave vote replace 16 test-and-branch steps */
 	__device__ __forceinline__ bool skip16(const S &s, const P (&c)[16]) const
@@ -437,6 +458,7 @@ struct CombSelfPol {
 				s.st = d.x;
 				s.sm = d.y;
 			}
+			s.rng = rng16[s.st];
 		}
 		return s;
 	}
@@ -638,6 +660,12 @@ struct EagerPol : Pol {
 	{
 		return Pol::skip16(st.s, pre);
 	}
+	template <class Q = Pol>
+	__device__ __forceinline__ auto skip16_raw(const S &st, const u32x4 &w) const
+		-> decltype(static_cast<const Q *>(nullptr)->skip16_raw(st.s, w))
+	{
+		return Pol::skip16_raw(st.s, w);
+	}
 	__device__ __forceinline__ S next(S st, P p) const
 	{
 		const uint32_t before = Pol::code(st.s);
@@ -735,6 +763,12 @@ struct EagerWidePol : Pol {
 	{
 		return Pol::skip16(st.s, pre);   /* pending outputs stay pending: the state is unchanged */
 	}
+	template <class Q = Pol>
+	__device__ __forceinline__ auto skip16_raw(const S &st, const u32x4 &w) const
+		-> decltype(static_cast<const Q *>(nullptr)->skip16_raw(st.s, w))
+	{
+		return Pol::skip16_raw(st.s, w);
+	}
 	/* The kernels may compute next() for a byte past the end of a ragged input and drop the result,
 	 * so a step must not write.  The state handed IN is committed: its pending outputs are written
 	 * here, the new state's are left pending (the last one is written by finish()). */
@@ -788,7 +822,7 @@ __device__ __forceinline__ LdsSelfState pick(bool c, const LdsSelfState &x, cons
 }
 __device__ __forceinline__ CombSelfState pick(bool c, const CombSelfState &x, const CombSelfState &y)
 {
-	CombSelfState r = { c ? x.st : y.st, c ? x.sm : y.sm };
+	CombSelfState r = { c ? x.st : y.st, c ? x.sm : y.sm, c ? x.rng : y.rng };
 	return r;
 }
 template <class Pol>
@@ -864,6 +898,19 @@ __device__ __forceinline__ bool skip_chunk(const Pol &, const typename Pol::S &,
 	return false;
 }
 
+/* ... or, cheaper still, from the raw 16 input bytes before any lookup (skip16_raw) */
+template <class Pol>
+__device__ __forceinline__ auto skip_chunk_raw(const Pol &pol, const typename Pol::S &st, const u32x4 &w, int)
+	-> decltype(pol.skip16_raw(st, w))
+{
+	return pol.skip16_raw(st, w);
+}
+template <class Pol>
+__device__ __forceinline__ bool skip_chunk_raw(const Pol &, const typename Pol::S &, const u32x4 &, long)
+{
+	return false;
+}
+
 /* a policy may walk a whole chunk itself (walk16: EagerPol's rare-event form) */
 template <class Pol>
 __device__ __forceinline__ auto walk_chunk(const Pol &pol, typename Pol::S &st, const typename Pol::P (&pre)[16], int)
@@ -881,6 +928,7 @@ __device__ __forceinline__ void walk_chunk(const Pol &pol, typename Pol::S &st, 
 template <class Pol, int ROWS>
 __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
+	if (ROWS == 1 && skip_chunk_raw(pol, st[0], w[0], 0)) return;
 	typename Pol::P pre[ROWS][16];
 #pragma unroll
 	for (int r = 0; r < ROWS; r++)

@@ -176,6 +176,16 @@ def check_plan(flat, layout):
             bits = (sm[off][:, None] >> np.arange(Cn)[None, :]) & 1
             assert np.array_equal(bits[~absorbing].astype(bool), loops[~absorbing])
             assert (sm[off][absorbing] == 0xFFFFFFFF).all()
+            # self-loop BYTE range for the SWAR chunk test: exactly the state's self-loop bytes, or "none"
+            rng = p.get("comb_rng").astype(np.int64)[off]
+            lo, hi = rng & 0xff, rng >> 8
+            selfb = want == np.arange(S1)[:, None]                       # [S1][256]
+            for n in range(S1):
+                if rng[n] == 0x0080:
+                    continue
+                assert lo[n] <= 128 and (hi[n] <= 127 or hi[n] == 255)
+                assert np.array_equal(selfb[n], (bytes_ >= lo[n]) & (bytes_ <= hi[n])), (n, lo[n], hi[n])
+            assert (rng[absorbing] == 0xFF00).all()
     elif p.layout == LAYOUT_COMB256:
         comb = p.get("comb256").astype(np.int64)
         off = p.get("comb256_off").astype(np.int64)
