@@ -27,6 +27,7 @@ NO_EARLY_RETIRE = 0x10
 KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 KNOB_NOSKIP = 13
 KNOB_RAGGED_ALIGN = 14
+KNOB_DMA_BUFS = 15
 IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
