@@ -69,7 +69,6 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
-	int knob_dma_bufs = 0;       /* LDS-DMA (128-byte segments): tiles per wave, 1 or 2; 0 auto */
 	int knob_ragged_align = -1;  /* ragged kernel: 1 = 128-byte-aligned segments, 0 = 16-byte-aligned, -1 default */
 	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes */
 	unsigned flags = 0;
@@ -463,11 +462,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		if (m >= 0) mode = m;
 	}
 	c.mode = mode;
-	/* two tiles per wave (walk_ldsdma2: no gap between a tile landing and the next DMA going out): plain walks
-	 * on 128-byte segments, when at least 4 waves' pairs of tiles fit next to the table */
-	c.bufs = 1;
-	if (mode == IN_LDSDMA && c.seg == 128 && !eager && d->knob_dma_bufs == 2 && d->table_lds + 4u * 16384u <= d->lds_limit) c.bufs = 2;
-	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg * (uint32_t)c.bufs : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
+	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
 	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
@@ -478,10 +473,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	else if (eager && mode == IN_GENERIC) wmax = 8;
 	else if (eager && mode == IN_LDSDMA) wmax = 12;
 	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
-	if (c.bufs == 2) wmax = 8;   /* walk_ldsdma2 is compiled for 8 waves (16 KiB of tiles each) */
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16 &&
-	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) && c.bufs != 2) waves = d->knob_waves;   /* those kernels are compiled for 12 / 8 */
+	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA)) waves = d->knob_waves;   /* that kernel is compiled for 12 */
 	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
@@ -794,7 +788,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
 	case FSM_HIP_KNOB_RAGGED_ALIGN: d->knob_ragged_align = value; break;
-	case FSM_HIP_KNOB_DMA_BUFS: d->knob_dma_bufs = value; break;
+	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
 	}
 	return 0;

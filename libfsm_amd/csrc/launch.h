@@ -20,7 +20,6 @@ struct LaunchCfg {
 	int seg;             /* LDS-DMA: 64 or 128 */
 	int prefetch;        /* direct: register double-buffer (0: <= 64 VGPRs, occupancy instead) */
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
-	int bufs;            /* LDS-DMA, 128-byte segments: tiles per wave (2: walk_ldsdma2) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 };
 
@@ -61,8 +60,7 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
 	case IN_GENERIC: k = walk_generic<Pol>; break;
 	case IN_LDSDMA:
-		if (c.seg == 128 && c.bufs == 2) k = c.nt ? walk_ldsdma2<Pol, 2, 512> : walk_ldsdma2<Pol, 0, 512>;   /* 16 KiB per wave: <= 8 waves */
-		else if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2, ldsdma_threads<Pol>::value> : walk_ldsdma<Pol, 128, 0, ldsdma_threads<Pol>::value>;
+		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2, ldsdma_threads<Pol>::value> : walk_ldsdma<Pol, 128, 0, ldsdma_threads<Pol>::value>;
 		else k = walk_ldsdma<Pol, 64, 0, ldsdma_threads<Pol>::value>;
 		break;
 	default:

@@ -1154,92 +1154,6 @@ walk_ldsdma(const WalkArgs a)
 	}
 }
 
-/*
- * walk_ldsdma2: the same input path with TWO tiles per wavefront.  In walk_ldsdma a wave re-issues its DMA into
- * the single tile only after the tile has been copied to registers, so between "tile landed" and "next DMA out"
- * it has nothing in flight; with a dozen waves per CU that gap is ~12 % of the time, which is the distance
- * between the walk (6.1-6.2 TB/s) and the read-only probe of the same access pattern (7.0).  Here the next
- * segment's DMA goes into the other tile the moment the current one has landed, before it is even read; the
- * stream of (tile, segment) items runs on across 64-row tiles, so there is no exposed latency at tile boundaries
- * either.  16 KiB of LDS per wave: half as many waves fit, each with no idle gap.  128-byte segments only.
- */
-template <class Pol, int AUX, int MAXT = 1024>
-__global__ void __launch_bounds__(MAXT)
-walk_ldsdma2(const WalkArgs a)
-{
-	constexpr uint32_t TILE = 8192u;
-	extern __shared__ __align__(16) unsigned char lds[];
-	Pol pol;
-	pol.setup(lds, a);
-	__syncthreads();
-
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * 2u * TILE;
-	const uint64_t ntiles = (a.n + 63u) / 64u, tstep = (uint64_t)gridDim.x * nw;
-	const uint32_t nseg = (uint32_t)(a.stride / 128u); /* host guarantees stride % 128 == 0 */
-	const uint32_t lr = lane / 8u, lq = lane % 8u;                       /* loader role */
-	const unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
-	const uint32_t rot = (lane >> 1) & 7u;
-
-	uint64_t tile = (uint64_t)blockIdx.x * nw + wave;
-	if (tile >= ntiles) return;
-	const unsigned char *src[8];
-	auto set_src = [&](uint64_t t) {
-#pragma unroll
-		for (uint32_t j = 0; j < 8; j++) {
-			const uint32_t ri = j * 8u + lr;
-			uint64_t row = t * 64u + ri;
-			if (row >= a.n) row = a.n - 1;
-			src[j] = a.base + row * a.stride + ((lq - ((ri >> 1) & 7u)) & 7u) * 16u;
-		}
-	};
-	auto issue = [&](uint32_t seg, uint32_t buf) {
-#pragma unroll
-		for (uint32_t j = 0; j < 8; j++)
-			__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)seg * 128u),
-			                                 (lds_void_t *)(stg + buf * TILE + j * 1024u), 16, 0, AUX);
-	};
-	set_src(tile);
-	uint32_t cur = 0;   /* the item about to be walked is (landing) in tile buffer `cur` */
-	issue(0, cur);
-	for (; tile < ntiles; tile += tstep) {
-		const uint64_t i = tile * 64u + lane;
-		const bool valid = i < a.n;
-		const uint64_t ntile = tile + tstep;
-		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
-		for (uint32_t s = 0; s < nseg; s++) {
-			__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): item (tile, s) has landed */
-			__asm__ volatile("" ::: "memory");
-			/* the next item goes out at once, into the other buffer */
-			if (s + 1 < nseg) {
-				issue(s + 1, cur ^ 1u);
-			} else if (ntile < ntiles) {
-				set_src(ntile);
-				issue(0, cur ^ 1u);
-			}
-			u32x4 w[8][1];
-#pragma unroll
-			for (uint32_t p = 0; p < 8; p++)
-				w[p][0] = *reinterpret_cast<const u32x4 *>(rd + cur * TILE + ((p + rot) & 7u) * 16u);
-			cur ^= 1u;
-#pragma unroll
-			for (uint32_t p = 0; p < 8; p++) step16<Pol, 1>(pol, st, w[p]);
-			if ((a.early & 1u) && s + 1 < nseg && __all(Pol::code(st[0]) >= a.abs_min)) {
-				/* the rest of this tile cannot change anything: drop the segment in flight, fetch the next tile */
-				__builtin_amdgcn_s_waitcnt(0x0F70);
-				__asm__ volatile("" ::: "memory");
-				if (ntile < ntiles) {
-					set_src(ntile);
-					issue(0, cur);
-				}
-				break;
-			}
-		}
-		write_result(a, tile, i, valid, Pol::code(st[0]));
-		finish_state(pol, a, i, valid, st[0], 0);
-	}
-}
-
 /* ------------------------------------------------------------------ */
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */

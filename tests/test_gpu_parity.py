@@ -74,13 +74,11 @@ def test_fast_paths_every_mode(hip, name):
     for L, dfa in layouts_for(hip, g.flat):
         variants = [(hip.IN_GENERIC, 0, 0), (hip.IN_RAGGED, 0, 0), (hip.IN_RAGGED, 0, 3), (hip.IN_LDSDMA, 64, 0), (hip.IN_LDSDMA, 64, 4),
                     (hip.IN_LDSDMA, 128, 0), (hip.IN_LDSDMA, 128, 2)]
-        variants += [(hip.IN_LDSDMA, 128 + 2, 0), (hip.IN_LDSDMA, 128 + 2, 3)]      # + 2: two tiles per wave (walk_ldsdma2)
         variants += [(hip.IN_DIRECT, nb, 0) for nb in (4, 8)]
         variants += [(hip.IN_DIRECT, 4, w) for w in (1, 2, 8)]
         for mode, nb, waves in variants:
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
-            dfa.tune(hip.KNOB_SEG, (nb & ~3) if mode == hip.IN_LDSDMA else 0)
-            dfa.tune(hip.KNOB_DMA_BUFS, 2 if mode == hip.IN_LDSDMA and nb & 2 else 1)
+            dfa.tune(hip.KNOB_SEG, nb if mode == hip.IN_LDSDMA else 0)
             dfa.tune(hip.KNOB_NB, nb if mode == hip.IN_DIRECT else 0)
             dfa.tune(hip.KNOB_WAVES, waves)
             for early, pre in ((0, 1), (1, 1), (0, 0), (1, 0)):

@@ -194,9 +194,8 @@ def test_rows_beyond_4GiB_and_the_last_partial_tile(hip, workload):
     bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
     dfa = hip.HipDfa(flat)
     ref_end = None
-    for mode in (-1, -2, hip.IN_DIRECT, hip.IN_RAGGED):           # -2: the default LDS-DMA kernel with two tiles per wave
-        dfa.tune(hip.KNOB_INPUT_MODE, -1 if mode == -2 else mode)
-        dfa.tune(hip.KNOB_DMA_BUFS, 2 if mode == -2 else 1)
+    for mode in (-1, hip.IN_DIRECT, hip.IN_RAGGED):
+        dfa.tune(hip.KNOB_INPUT_MODE, mode)
         end.fill_(-2)
         bm.fill_(-1)
         dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), bm.data_ptr())

@@ -12,10 +12,6 @@ for step in "$@"; do
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
 	fullpar) timeout 900 python bench.py --steps 5 --warmup 2 --subs none --full-parity > gpurun_out/${TAG}_bench_fullparity.json 2> gpurun_out/${TAG}_bench_fullparity.err; echo "fullparity rc=$?"; python -c "import json,sys; r=json.loads(open('gpurun_out/${TAG}_bench_fullparity.json').read().strip().splitlines()[-1]); print(r['value'], r.get('full_parity'))" ;;
 	benchnode) FSM_BENCH_NODE_FRONT=1 FSM_BENCH_NODE_REPLICAS=2 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_benchnode.json 2> gpurun_out/${TAG}_benchnode.err; echo "benchnode rc=$?"; python -c "import json; r=json.loads(open('gpurun_out/${TAG}_benchnode.json').read().strip().splitlines()[-1]); print(r['value'], r.get('node_front'))" ;;
-	dma2)   for wl in c3 c2; do for v in "15=1" "15=2" "15=2 --waves 6" "15=2 --waves 4"; do
-	            echo "== $wl knob $v" >> gpurun_out/${TAG}_dma2.txt
-	            timeout 300 python bench.py --workload $wl --subs none --no-cpu-baseline --steps 10 --warmup 3 --knob $v 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['config']['waves_per_block'], r['config']['lds_bytes_per_block'], r['config']['accepted_inputs'])" >> gpurun_out/${TAG}_dma2.txt 2>&1
-	        done; done; cat gpurun_out/${TAG}_dma2.txt ;;
 	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
