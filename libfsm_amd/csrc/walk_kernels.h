@@ -5,48 +5,44 @@
  * against the same DFA (the data-parallel form of the reference's per-input
  * loop `while ((c = getc()) != EOF) state = delta(state, c)`,
  * src/libfsm/exec.c:132-151).  No MFMA: there is no contraction here; the
- * kernel is bound by HBM input bandwidth and by the LDS lookup rate.
+ * kernels are bound by HBM input bandwidth (tiny / combself), by the latency of
+ * the dependent lookup chain (the generic LDS layouts) or by the instructions of
+ * a divergent chain walk (sparse).
  *
  * Table policies (how delta(state, byte) is evaluated).  Each policy splits a
  * step into  pre(byte)  -- independent of the state, so all 16 of a 16-byte
  * chunk are issued together --  and  next(state, pre)  -- the dependent chain:
- *   TinyPol<uint64_t> 7..16 states (a 32-bit column format for <= 8 states measured slower: dropped).  LDS holds, per byte
- *              value, the whole transition COLUMN (4-bit next states packed in
- *              one word), replicated once per LDS bank so lane l always reads
- *              bank l%32: conflict-free by construction.  pre = the column,
- *              next = shift+mask: the state chain never touches memory.
+ *   TinyPol<uint64_t> 7..16 states.  LDS holds, per byte value, the whole transition COLUMN (4-bit next
+ *              states packed in one word), one copy per LDS bank: conflict-free by construction.
+ *              pre = the column, next = one 64-bit shift: the state chain never touches memory.
  *   Tiny5Pol   <= 6 states: 5-bit fields of 5 * next state, one private column copy per lane at LDS
  *              address (byte << 8) | (lane << 2): one v_perm_b32 + one v_bfe_u32 per input byte.
  *   LdsPol     class-compressed dense table T[state][class] (u16) in LDS plus a
  *              256-byte byte->class map (conflict-free for 7-bit text, <= 2-way otherwise).
- *   CombPol    column-default + comb exceptions over byte CLASSES (B table
- *              carries class and per-class default), see plan.cpp.
- *   Comb256Pol comb exceptions over raw BYTES with one default state for every
- *              column (typically DEAD): pre is the byte itself, one LDS lookup
- *              per input byte in total.
- *   CombSelfPol CombPol + a self-loop mask per state kept in a register: bytes on
- *              which the state does not change cost only the conflict-free B lookup.
+ *   CombPol    column-default + comb exceptions over byte CLASSES, see plan.cpp.
+ *   Comb256Pol comb exceptions over raw BYTES with one default state for every column (typically
+ *              DEAD): one LDS lookup per input byte; the state is the raw entry (next << 16 | owner).
+ *   CombSelfPol CombPol + the current state's self-loop class mask and self-loop byte range in
+ *              registers: whole chunks of self-loops are skipped with one wave vote.
  *   LdsSelfPol LdsPol + the current state's self-loop mask in a register (rows carry their mask).
- *   GlobPol    T[state][class] (u32) in HBM/L2, B in LDS (+ LDS mirror of its head).
- *   SparsePol  per-state record {exception bitmap, base state} + exception lists in HBM/L2, the
+ *   GlobPol    T[state][class] (u32) in HBM/L2, class map in LDS (+ LDS mirror of the table's head).
+ *   SparsePol  per-state record {exception bitmap, base state | flags, offset} in HBM/L2, the
  *              records nearest the start state in LDS (failure-link form of big tables).
  * Wrappers: EagerPol (<= 64 eager-output ids, set in registers), EagerWidePol (more: set in memory).
- * Optional policy hooks, found by SFINAE: pre_dw (lookup from the raw input dword), skip16 (one wave
- * vote skips a 16-byte chunk that changes no lane's state), init_at / finish_at (input index).
- * MASK: lanes already in an absorbing state skip the state-dependent lookup
- * (exec-masked), which takes their addresses out of the LDS bank arbitration.
+ * Optional policy hooks, found by SFINAE: pre_dw (lookup from the raw input dword), skip16_raw (skip a
+ * chunk after a test on its raw bytes), skip16 (the same after the class lookups), walk16 (a whole chunk
+ * at once), init_at / finish_at (input index).
  *
- * Input staging (uniform-length, 16-byte aligned rows):
- *   walk_direct  every lane reads its own row(s) 16 bytes at a time, NB chunks
- *                in flight, ROWS independent rows per lane (two interleaved
- *                state chains hide LDS latency when the table leaves room for
- *                one workgroup per CU only).
- *   walk_ldsdma  rows are fetched as whole 64- or 128-byte segments (4 / 8
- *                adjacent lanes per row) by global_load_lds_dwordx4 straight
- *                into a 4 / 8 KiB per-wave LDS tile, piece-rotated so the
- *                row-per-lane ds_read_b128 that follows is bank-conflict-free;
- *                no VGPR staging, no ds_write.
- *   walk_generic ragged lengths / arbitrary alignment / packed offsets.
+ * Kernels.  Uniform-length, 16-byte aligned rows:
+ *   walk_ldsdma  rows are fetched as whole 64- or 128-byte segments (4 / 8 adjacent lanes per row) by
+ *                global_load_lds_dwordx4 straight into a 4 / 8 KiB per-wave LDS tile, piece-rotated so
+ *                that the row-per-lane ds_read_b128 that follows is bank-conflict-free; no VGPR
+ *                staging, no ds_write.
+ *   walk_direct  every lane reads its own row 16 bytes at a time, NB = 4 or 8 chunks in flight;
+ *   walk_direct_np  the same without the register double-buffer (<= 64 VGPRs, occupancy instead).
+ * Any length / alignment / packed offsets:
+ *   walk_ragged  the LDS-DMA input path with per-lane source addresses + lane refill per segment;
+ *   walk_generic per-lane 16-byte loads (fallback, and the better one for very short inputs).
  */
 #ifndef FSM_HIP_WALK_KERNELS_H
 #define FSM_HIP_WALK_KERNELS_H
