@@ -143,7 +143,8 @@ int fsm_hip_dfa_info(const struct fsm_hip_dfa *dfa, struct fsm_hip_dfa_info *out
  * Host pointers; data is staged through HBM (PCIe-inclusive).
  * Replaces the per-input loop over fsm_runner_run() in retest/reperf
  * (src/retest/main.c:1114, src/retest/reperf.c:772-784).
- * Returns 0, or -1 + errno. */
+ * Returns 0, or -1 + errno.  One input may be up to 2^36 - 1 bytes long (the kernels count its 16-byte
+ * chunks in 32 bits); longer ones go through fsm_hip_exec_batch_resume() in pieces. */
 int fsm_hip_exec_batch(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *accept_bitmap);

@@ -348,8 +348,9 @@ class Plan:
 class HipDfa:
     """struct fsm_hip_dfa *: a DFA resident on the GPU."""
 
-    def __init__(self, flat: Optional[FlatDfa] = None, flags: int = 0, *, handle=None):
+    def __init__(self, flat: Optional[FlatDfa] = None, flags: int = 0, *, handle=None, borrowed: bool = False):
         self._lib = load_library()
+        self._borrowed = borrowed      # a replica owned by a HipNode: never freed from here
         if handle is not None:
             self._h = handle
         else:
@@ -371,7 +372,8 @@ class HipDfa:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.fsm_hip_dfa_free(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.fsm_hip_dfa_free(self._h)
             self._h = None
 
     __del__ = close
@@ -591,10 +593,7 @@ class HipNode:
         h = self._lib.fsm_hip_node_dfa(C.c_void_p(self._h), C.c_int(k))
         if not h:
             raise _oserr("fsm_hip_node_dfa")
-        r = HipDfa(handle=h)
-        r.close = lambda: None
-        r.__class__ = type("BorrowedHipDfa", (HipDfa,), {"__del__": lambda self: None})
-        return r
+        return HipDfa(handle=h, borrowed=True)
 
     def shard(self, n: int, k: int):
         f, c = C.c_size_t(), C.c_size_t()

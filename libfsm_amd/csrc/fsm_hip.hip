@@ -70,7 +70,8 @@ struct fsm_hip_dfa {
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
 	int knob_ragged_align = -1;  /* ragged kernel: 1 = 128-byte-aligned segments, 0 = 16-byte-aligned, -1 default */
-	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes */
+	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes
+	                              * (or the batch is big enough to hold an input of 2^36 bytes): take walk_generic */
 	unsigned flags = 0;
 };
 
@@ -704,7 +705,7 @@ static int exec_host(const struct fsm_hip_dfa *d,
 		fsm_hip_dfa *d;
 		Hint(fsm_hip_dfa *d_, bool v) : d(d_) { d->hint_short = v; }
 		~Hint() { d->hint_short = false; }
-	} hint(hc.d, (len != nullptr || off != nullptr) && in_bytes / n < 96u);
+	} hint(hc.d, ((len != nullptr || off != nullptr) && in_bytes / n < 96u) || in_bytes >= ((size_t)1 << 36));   /* or: an input the ragged kernel's 32-bit chunk count could not hold */
 	if (off) {
 		if (fsm_hip_exec_batch_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
 		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;
