@@ -1,0 +1,81 @@
+/* tests/c/stub_fsm_hip.c -- TEST DOUBLE, not part of the product and never shipped.
+ *
+ * The patched retest (integration/retest) links libfsm_hip.so.  This file builds a stand-in with the
+ * same soname for the CPU test suite (tests/test_retest_patch.py), so the control flow the patch adds to
+ * the reference's retest -- read ahead to the end of a record, one fsm_hip_exec_batch_offsets() call for
+ * its test lines, results handed out by fsm_runner_run() -- can be checked on a box without a GPU.  The
+ * four entry points the patch calls are answered by the reference's own DFAVM (fsm_vm_*, resolved from
+ * the retest executable, which contains libfsm), and each call is counted: the counts are printed when
+ * the process exits.  The GPU suite runs the same retest binary against the real library. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+struct fsm;
+struct fsm_dfavm;
+struct fsm_dfavm *fsm_vm_compile(const struct fsm *fsm);
+int fsm_vm_match_buffer(const struct fsm_dfavm *vm, const char *buf, size_t n);
+void fsm_vm_free(struct fsm_dfavm *vm);
+
+struct fsm_hip_dfa { struct fsm_dfavm *vm; };
+
+static unsigned long n_compile, n_batch, n_batch_inputs, n_single;
+
+static void
+report(void)
+{
+	fprintf(stderr, "stub_fsm_hip: compile=%lu batch_calls=%lu batch_inputs=%lu single_calls=%lu\n",
+		n_compile, n_batch, n_batch_inputs, n_single);
+}
+
+struct fsm_hip_dfa *
+fsm_hip_compile(const struct fsm *fsm, unsigned flags)
+{
+	struct fsm_hip_dfa *d;
+	(void) flags;
+	if (n_compile++ == 0) {
+		atexit(report);
+	}
+	d = malloc(sizeof *d);
+	if (d == NULL) {
+		return NULL;
+	}
+	d->vm = fsm_vm_compile(fsm);
+	if (d->vm == NULL) {
+		free(d);
+		return NULL;
+	}
+	return d;
+}
+
+void
+fsm_hip_dfa_free(struct fsm_hip_dfa *d)
+{
+	if (d != NULL) {
+		fsm_vm_free(d->vm);
+		free(d);
+	}
+}
+
+int
+fsm_hip_match_buffer(const struct fsm_hip_dfa *d, const char *buf, size_t n)
+{
+	n_single++;
+	return fsm_vm_match_buffer(d->vm, buf, n);
+}
+
+int
+fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *d, const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	size_t i;
+	(void) end_out;
+	n_batch++;
+	n_batch_inputs += n;
+	for (i = 0; i < n; i++) {
+		if (fsm_vm_match_buffer(d->vm, (const char *) base + off[i], (size_t) (off[i + 1] - off[i]))) {
+			accept_bitmap[i / 64] |= (uint64_t) 1 << (i % 64);
+		}
+	}
+	return 0;
+}

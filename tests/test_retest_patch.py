@@ -1,0 +1,108 @@
+"""integration/retest/impl_hip.patch, control flow only (no GPU): the patched copy of the reference's retest
+is run against a stand-in libfsm_hip.so (tests/c/stub_fsm_hip.c: the four entry points the patch calls,
+answered by the reference's DFAVM and counted).  What is checked here is what the patch adds to main.c /
+runner.c: `-l hip` reads ahead to the end of each record and matches its '+' / '-' lines with ONE
+fsm_hip_exec_batch_offsets() call, fsm_runner_run() then hands out the held results in order; `-l hip-line`
+keeps one call per line.  The GPU suite (tests/test_gpu_round2.py::test_retest_l_hip) runs the same binary
+against the real library."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from common import retest_tst_lines
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+EXE = os.path.join(ROOT, "integration", "_build", "retest")
+
+
+@pytest.fixture(scope="module")
+def stub_dir(tmp_path_factory):
+    if not os.path.isdir("/root/reference/src/retest") and not os.path.exists(EXE):
+        pytest.skip("patched retest not built and no reference tree to build it from")
+    sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
+    if not os.path.exists(EXE):
+        pytest.skip("integration/_build/retest not built: " + sh.stderr[-300:])
+    d = tmp_path_factory.mktemp("stub")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-shared", "-fPIC", os.path.join(ROOT, "tests", "c", "stub_fsm_hip.c"),
+                           "-Wl,-soname,libfsm_hip.so", "-o", str(d / "libfsm_hip.so")])
+    return str(d)
+
+
+def run(stub_dir, impl, path):
+    env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)      # searched before the binary's RUNPATH
+    out = subprocess.run([EXE, "-l", impl, str(path)], capture_output=True, text=True, errors="replace", env=env, timeout=300)
+    m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=(\d+) batch_inputs=(\d+) single_calls=(\d+)", out.stderr)
+    assert m, out.stderr[-500:]
+    # retest forks one child per file: one report
+    return out, tuple(int(x) for x in m[-1])
+
+
+def test_record_lines_go_out_in_one_call(stub_dir, tmp_path):
+    lines, flip = retest_tst_lines()
+    tst = tmp_path / "all.tst"
+    tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    records_with_cases = 0
+    in_rec = False
+    for i, l in enumerate(lines):
+        if l == "":
+            in_rec = False
+        elif l[0] in "+-" and not in_rec:
+            in_rec = True
+            records_with_cases += 1
+
+    out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip", tst)
+    tail = out.stdout.strip().splitlines()[-2:]
+    assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+    assert tail[0].endswith("37 regexps, 115 test cases") and tail[1].endswith("0 re errors, 0 errors")
+    assert out.stdout.count("[OK    ]") == 115 and "[NOT OK]" not in out.stdout
+    assert (ncomp, nbatch, nin, nsingle) == (37, records_with_cases, 115, 0)
+    assert out.stdout.count("[BATCH ]") == records_with_cases
+
+    out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip-line", tst)
+    assert out.returncode == 0 and out.stdout.count("[OK    ]") == 115
+    assert (ncomp, nbatch, nin, nsingle) == (37, 0, 0, 115)
+
+    # a wrong expectation is still reported, on its own line number
+    lines[flip] = "-" + lines[flip][1:]
+    bad = tmp_path / "bad.tst"
+    bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
+    out, counts = run(stub_dir, "hip", bad)
+    assert out.returncode == 1 and out.stdout.count("[NOT OK]") == 1
+    assert "[NOT OK] line %d:" % (flip + 1) in out.stdout
+    assert counts[3] == 0
+
+
+def test_lines_the_read_ahead_did_not_see_fall_back(stub_dir, tmp_path):
+    """Comment lines, a line with a bad escape (reported by the main loop, not matched), an 'M'-prefixed line inside
+    a record (the main loop takes it as a flags line), an over-long line (fgets splits it the same way in both
+    passes), an empty input, and a last record that ends at EOF without a blank line."""
+    long_in = "a" * 5000
+    text = "\n".join([
+        "O +e",
+        "R pcre",
+        "^a*$",
+        "# comment",
+        "+",
+        "+aaa",
+        "-aab",
+        "+\\x61\\x61",
+        "+bad\\xZZ",
+        "M i",
+        "+" + long_in,
+        "",
+        "R literal",
+        "abc",
+        "+abc",
+        "-abd",
+    ]) + "\n"
+    tst = tmp_path / "odd.tst"
+    tst.write_text(text)
+    out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip", tst)
+    ref = subprocess.run([EXE, "-l", "vm", str(tst)], capture_output=True, text=True, errors="replace", timeout=300)
+    strip = lambda s: [l for l in s.splitlines() if not l.startswith("[BATCH ]")]
+    assert strip(out.stdout) == strip(ref.stdout)          # line for line what the reference's own VM reports
+    assert out.returncode == ref.returncode
+    assert ncomp == 2 and nbatch == 2 and nsingle == 0, (ncomp, nbatch, nin, nsingle)
