@@ -31,7 +31,7 @@ enum {
 	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
 	FSM_HIP_KNOB_NOSKIP        = 13, /* 1: self-loop layouts never skip a whole chunk (measurement aid: every byte pays its test) */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
-	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* ragged kernel: 1 = an input's segments start at a 128-byte boundary (one line per DMA row), 0 = at a 16-byte one */
+	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };
 
 int fsm_hip_dfa_tune(struct fsm_hip_dfa *dfa, int knob, int value);

@@ -69,7 +69,6 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
-	int knob_ragged_align = -1;  /* ragged kernel: 1 = 128-byte-aligned segments, 0 = 16-byte-aligned, -1 default */
 	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes
 	                              * (or the batch is big enough to hold an input of 2^36 bytes): take walk_generic */
 	unsigned flags = 0;
@@ -502,7 +501,6 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	if (d->knob_noskip > 0) a.early |= 4u;
-	if (d->knob_ragged_align > 0) a.early |= 8u;
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events are per dfa */
 	hipError_t e = hipSuccess;
@@ -788,7 +786,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
-	case FSM_HIP_KNOB_RAGGED_ALIGN: d->knob_ragged_align = value; break;
+	case FSM_HIP_KNOB_RAGGED_ALIGN: break;   /* retired: segments start at the input's own first byte now */
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
 	}

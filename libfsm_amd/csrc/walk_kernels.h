@@ -124,7 +124,14 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 
 template <class W>
 struct TinyPol {
-	static constexpr bool heavy_next = false;
+	/* No chunk-level form (EagerPol::walk16) over this policy.  One build of walk_ragged<EagerPol<TinyPol<u64>>>
+	 * -- chunk-level walk + results held back one iteration -- gave an intermittent wrong end state / id set
+	 * for a single input (~3 % of launches, only in the second wavefront of a SIMD, never with <= 4 wavefronts
+	 * per workgroup).  A full s_waitcnt 0 + wave barrier in front of the tile reads did not cure it and neither
+	 * did wait states around the 64-bit shift below, so it is not the input path; without walk16, or with the
+	 * results written at once, 0 of 2700 launches failed (tests/tools/eager_tiny64_stress.py, the probes under
+	 * tools/probes/).  Root cause not found: both suspects are avoided and the stress run is part of the GPU suite. */
+	static constexpr bool heavy_next = true;
 	static_assert(sizeof(W) == 8, "16 states x 4 bits per column");
 	typedef W P;
 	typedef uint32_t S;   /* carried unmasked: only bits 3:0 are the state (see next) */
@@ -1150,6 +1157,56 @@ walk_ldsdma(const WalkArgs a)
 	}
 }
 
+/* does the policy have a chunk-level skip test (on raw bytes or on classes)? */
+template <class Pol>
+constexpr auto has_skip_raw(int) -> decltype(static_cast<const Pol *>(nullptr)->skip16_raw(*static_cast<const typename Pol::S *>(nullptr), *static_cast<const u32x4 *>(nullptr)), true) { return true; }
+template <class Pol> constexpr bool has_skip_raw(long) { return false; }
+template <class Pol>
+constexpr auto has_skip_cls(int) -> decltype(static_cast<const Pol *>(nullptr)->skip16(*static_cast<const typename Pol::S *>(nullptr), *static_cast<const typename Pol::P (*)[16]>(nullptr)), true) { return true; }
+template <class Pol> constexpr bool has_skip_cls(long) { return false; }
+
+/* A chunk of which only bytes [lo, lo + cnt) belong to the input (cnt >= 1): the others are replaced by a
+ * copy of byte lo, so that a chunk-level skip test -- "does any of these 16 bytes leave the state's
+ * self-loop set" -- answers for the input's own bytes alone. */
+__device__ __forceinline__ u32x4 fill_invalid(const u32x4 &w, uint32_t lo, uint32_t cnt)
+{
+	const uint32_t vm = (0xffffu >> (16u - cnt)) << lo;                  /* bit k: byte k is the input's */
+	const uint32_t d = lo < 8u ? (lo < 4u ? w.x : w.y) : (lo < 12u ? w.z : w.w);
+	const uint32_t rep = ((d >> ((lo & 3u) * 8u)) & 0xffu) * 0x01010101u;
+	/* four mask bits -> four mask bytes: n * 0x00204081 puts bit t of n at bit 8t */
+	const uint32_t m0 = ((((vm      ) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+	const uint32_t m1 = ((((vm >>  4) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+	const uint32_t m2 = ((((vm >>  8) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+	const uint32_t m3 = ((((vm >> 12) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+	u32x4 r;
+	r.x = (w.x & m0) | (rep & ~m0);
+	r.y = (w.y & m1) | (rep & ~m1);
+	r.z = (w.z & m2) | (rep & ~m2);
+	r.w = (w.w & m3) | (rep & ~m3);
+	return r;
+}
+
+/* 16 bytes of which only [lo, lo + cnt) belong to the input: the policy's chunk-level skip tests first
+ * (on the filled chunk), then 16 predicated steps */
+template <class Pol>
+__device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st, const u32x4 &w0, uint32_t lo, uint32_t cnt)
+{
+	u32x4 w = w0;
+	if (has_skip_raw<Pol>(0) || has_skip_cls<Pol>(0)) {
+		w = fill_invalid(w0, lo, cnt);
+		if (skip_chunk_raw(pol, st, w, 0)) return;
+	}
+	typename Pol::P pre[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) pre[k] = pre_of(pol, w, k, 0);
+	if (skip_chunk(pol, st, pre, 0)) return;
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const typename Pol::S nx = pol.next(st, pre[k]);
+		st = pick(((uint32_t)k - lo) < cnt, nx, st); /* k < lo wraps: fails the test */
+	}
+}
+
 /* ------------------------------------------------------------------ */
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
@@ -1198,12 +1255,7 @@ walk_generic(const WalkArgs a)
 					/* every lane still walking has a whole chunk: no per-byte predicate */
 					step16<Pol, 1>(pol, st, w);
 				} else {
-					const uint32_t cnt = hi - lo;
-#pragma unroll
-					for (int k = 0; k < 16; k++) {
-						const typename Pol::S nx = pol.next(st[0], pol.pre(byte_of(w[0], k)));
-						st[0] = pick(((uint32_t)k - lo) < cnt, nx, st[0]); /* k < lo wraps: fails the test */
-					}
+					step16_part(pol, st[0], w[0], lo, hi - lo);
 				}
 				w[0] = wn;
 			}
@@ -1231,19 +1283,8 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
 		atomicOr(reinterpret_cast<unsigned long long *>(a.bitmap + (i >> 6)), 1ull << (i & 63u));
 }
 
-/* 16 bytes of which only [lo, lo + cnt) belong to the input */
-template <class Pol>
-__device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t lo, uint32_t cnt)
-{
-#pragma unroll
-	for (int k = 0; k < 16; k++) {
-		const typename Pol::S nx = pol.next(st, pre_of(pol, w, k, 0));
-		st = pick(((uint32_t)k - lo) < cnt, nx, st); /* k < lo wraps: fails the test */
-	}
-}
-
 #define FSMHIP_RAGGED_RING 128u                                  /* staged (offset, length) pairs per wave */
-#define FSMHIP_RAGGED_WAVE_LDS (8192u + FSMHIP_RAGGED_RING * 16u) /* 8 KiB tile + the ring */
+#define FSMHIP_RAGGED_WAVE_LDS (8192u + FSMHIP_RAGGED_RING * 16u + 1024u) /* 8 KiB tile + the ring + one 16-byte row record per lane */
 
 /*
  * The retest / rx front: inputs of any length at any byte offset (packed back to back with an offsets
@@ -1253,15 +1294,25 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
  *  - input bytes arrive as in walk_ldsdma: per 128-byte segment of a lane's input, 8 adjacent loader
  *    lanes fetch its 8 16-byte pieces with ONE global_load_lds_dwordx4 (each row's source address is
  *    the owner lane's current position, handed to the loaders by cross-lane shuffles; pieces beyond
- *    the input's last chunk are masked off), piece-rotated so the row-per-lane ds_read_b128 that
+ *    the input's last one are masked off), piece-rotated so the row-per-lane ds_read_b128 that
  *    follows is conflict-free; the next segment is in flight while the current one is walked;
+ *  - the source of a piece is the input's own byte address + 16 * piece: global_load_lds_dwordx4 takes
+ *    any byte alignment on gfx950 (tools/probes/unaligned_dma.hip), so an input's first byte is byte 0 of
+ *    its piece 0 wherever the input starts and no chunk is partial at the head.  The last piece of an
+ *    input whose length is not a multiple of 16 is fetched from (end - 16): it overlaps bytes already
+ *    walked, which its one predicated step skips, and nothing outside the input is ever read.  (Inputs
+ *    shorter than 16 bytes read [start, start + 16) when that stays inside the batch; the handful at the
+ *    very end of the buffer are assembled from byte loads.)
  *  - a wavefront owns a contiguous range of inputs and REFILLS its lanes at every segment boundary:
  *    a lane whose input ends with the segment in hand (or sits in an absorbing state: fsm_exec's own
  *    early exit, exec.c:133-138) claims the next unclaimed input of the range -- ballot, popcount
  *    rank, no atomics -- so lanes stay busy whatever the length distribution.  The (offset, length)
  *    pairs of the next <= 128 inputs wait in an LDS ring that is topped up 64 at a time, one
  *    iteration ahead of their use.
- * Results are written per lane when its input ends.
+ * Results are written per lane when its input ends.  (Holding them back one iteration, so that the stores
+ * go out right after the wait for the tile, measured no faster -- profiles/r02t_ragged_variants.txt -- and
+ * that build of walk_ragged<EagerPol<TinyPol<u64>>> returned a wrong result in ~3 % of launches with two
+ * wavefronts per SIMD: see the note at TinyPol::heavy_next.)
  */
 template <class Pol, int MAXT>
 __global__ void __launch_bounds__(MAXT)
@@ -1276,6 +1327,7 @@ walk_ragged(const WalkArgs a)
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * FSMHIP_RAGGED_WAVE_LDS;
 	uint64_t *ring = reinterpret_cast<uint64_t *>(stg + 8192u);   /* [RING][2]: byte offset, length */
+	unsigned char *rows = stg + 8192u + RING * 16u;               /* [64] row records for the loaders */
 
 	/* contiguous range of whole bitmap words per wavefront */
 	const uint64_t nwaves = (uint64_t)gridDim.x * nw, gw = (uint64_t)blockIdx.x * nw + wave;
@@ -1283,19 +1335,22 @@ walk_ragged(const WalkArgs a)
 	const uint64_t w_lo = gw * per < a.n ? gw * per : a.n;
 	const uint64_t w_hi = w_lo + per < a.n ? w_lo + per : a.n;
 	if (w_lo >= w_hi) return;
+	/* one past the last byte of the batch: no 16-byte fetch may reach beyond it */
+	const uint64_t limit = reinterpret_cast<uint64_t>(a.base) + (a.off != nullptr ? a.off[a.n] : a.n * a.stride);
 
 	const uint32_t lr = lane / 8u, lq = lane % 8u;                   /* loader role */
-	const unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
+	unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
 	const uint32_t rot = (lane >> 1) & 7u;
 	const uint64_t lt = (1ull << lane) - 1ull;
 
 	uint64_t staged = w_lo, next = w_lo;      /* wave-uniform: ring holds [next, staged) */
-	uint64_t sb = 0, sl = 0;                  /* staging loads in flight (this lane's pair) */
+	u32x4 soff = {0u, 0u, 0u, 0u};            /* staging loads in flight: this lane's off[i], off[i + 1] ... */
+	uint32_t slen = 0;                        /* ... or its len[i] */
 	uint32_t spend = 0;                       /* wave-uniform: how many pairs they are */
 
 	bool have = false;                        /* this lane holds an input whose segment is in the tile */
-	uint64_t ci = 0, csrc = 0, span = 0;      /* its index, address of its chunk kpos, head + length */
-	uint32_t nch = 0, kpos = 0, head = 0;     /* chunks in all / walked so far, offset of the first byte */
+	uint64_t ci = 0, csrc = 0;                /* its index, address of its piece kpos */
+	uint32_t nfull = 0, tail = 0, kpos = 0;   /* whole 16-byte pieces, bytes after them, pieces walked so far */
 	typename Pol::S st = init_state(pol, a.start, a, 0, false, 0);
 	bool tile = false;                        /* wave-uniform: a segment is in flight */
 
@@ -1307,37 +1362,42 @@ walk_ragged(const WalkArgs a)
 		}
 		if (spend != 0) {
 			if (lane < spend) {
-				ring[((staged + lane) & (RING - 1u)) * 2u] = sb;
-				ring[((staged + lane) & (RING - 1u)) * 2u + 1u] = sl;
+				const uint64_t i = staged + lane;
+				uint64_t b, l;
+				if (a.off != nullptr) {
+					b = ((uint64_t)soff.y << 32) | soff.x;
+					l = (((uint64_t)soff.w << 32) | soff.z) - b;
+				} else {
+					b = i * a.stride;
+					l = a.len != nullptr ? slen : a.stride;
+				}
+				ring[(i & (RING - 1u)) * 2u] = b;
+				ring[(i & (RING - 1u)) * 2u + 1u] = l;
 			}
 			staged += spend;
 			spend = 0;
 		}
-		/* the first and the last chunk of an input may be partial: they are fetched once more, by their
-		 * (lane-varying) index, for the two predicated steps below */
-		u32x4 hw = {0u, 0u, 0u, 0u}, tw = {0u, 0u, 0u, 0u};
-		const uint32_t c_lo = (head + 15u) >> 4;                   /* first full chunk of the input */
-		const uint32_t c_hi = (uint32_t)(span >> 4);               /* one past its last full chunk = index of the tail */
+		/* the piece after an input's last whole one holds its final (len % 16) bytes: it is read by its
+		 * (lane-varying) index for the one predicated step below */
+		u32x4 tw = {0u, 0u, 0u, 0u};
 		if (tile) {
 #pragma unroll
 			for (uint32_t p = 0; p < 8; p++)
 				w[p] = *reinterpret_cast<const u32x4 *>(rd + ((p + rot) & 7u) * 16u);
-			const uint32_t hidx = kpos == 0u ? (head >> 4) & 7u : 0u;
-			const uint32_t tidx = (c_hi - kpos) & 7u;
-			hw = *reinterpret_cast<const u32x4 *>(rd + ((hidx + rot) & 7u) * 16u);
-			tw = *reinterpret_cast<const u32x4 *>(rd + ((tidx + rot) & 7u) * 16u);
+			tw = *reinterpret_cast<const u32x4 *>(rd + ((((nfull - kpos) & 7u) + rot) & 7u) * 16u);
 		}
 		__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile in registers (slot reusable), ring written */
 		__asm__ volatile("" ::: "memory");
 		__builtin_amdgcn_wave_barrier();
 
 		/* lanes whose input ends with the segment in hand */
-		const bool fin = have && (kpos + 8u >= nch || ((a.early & 1u) && Pol::code(st) >= a.abs_min));
+		const uint32_t nch = nfull + (tail != 0u ? 1u : 0u);
+		const bool fin = have && (nch - kpos <= 8u || ((a.early & 1u) && Pol::code(st) >= a.abs_min));
 		const bool cont = have && !fin;
 		/* refill: every lane that will be idle claims the next unclaimed input, in lane order */
-		bool got = false;
-		uint64_t ni = 0, nq0 = 0, nspan = 0;
-		uint32_t nnch = 0, nhead = 0;
+		bool got = false, direct = false;
+		uint64_t ni = 0, np0 = 0;
+		uint32_t nnfull = 0, ntail = 0;
 		uint64_t need = __ballot(!cont);
 		while (need != 0 && next < staged) {   /* wave-uniform; repeats only over empty inputs */
 			const uint64_t idx = next + (uint64_t)__builtin_popcountll(need & lt);
@@ -1346,80 +1406,95 @@ walk_ragged(const WalkArgs a)
 			next = next + want < staged ? next + want : staged;
 			if (take) {
 				const uint64_t beg = ring[(idx & (RING - 1u)) * 2u], len = ring[(idx & (RING - 1u)) * 2u + 1u];
-				const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
-				/* segments start at a 16-byte boundary, or (early bit 3) at a 128-byte one: every DMA row is then
-				 * exactly one cache line, at the price of up to 7 empty chunks in the input's first segment */
-				nq0 = p0 & ~(uint64_t)((a.early & 8u) ? 127 : 15);
-				nhead = (uint32_t)(p0 - nq0);
-				nspan = len ? nhead + len : 0;
-				nnch = (uint32_t)((nspan + 15u) / 16u);
+				np0 = reinterpret_cast<uint64_t>(a.base) + beg;
+				nnfull = (uint32_t)(len >> 4);
+				ntail = (uint32_t)len & 15u;
 				ni = idx;
-				if (nnch == 0) {
+				if (len == 0) {
 					/* empty input: accepted iff the start state is an end state; no bytes to fetch */
 					const typename Pol::S e = init_state(pol, start_code(a, idx, true), a, idx, true, 0);
 					write_result_lane(a, idx, Pol::code(e));
 					finish_state(pol, a, idx, true, e, 0);
 				} else {
 					got = true;
+					if (nnfull == 0u && np0 + 16u > limit) {
+						/* fewer than 16 bytes, less than 16 bytes before the end of the batch: byte loads, placed
+						 * where the DMA would have put piece 0 of this lane's row */
+						uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+						for (uint32_t k = 0; k < 15; k++)
+							if (k < ntail) d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(np0)[k] << ((k & 3u) * 8u);
+						const u32x4 dv = {d[0], d[1], d[2], d[3]};
+						*reinterpret_cast<u32x4 *>(rd + (rot & 7u) * 16u) = dv;
+						direct = true;
+					}
 				}
 			}
 			need = __ballot(!cont && !got);
 		}
 
-		/* source and chunk budget of every row's next segment */
-		const uint64_t lsrc = cont ? csrc + 128u : nq0;
-		const uint32_t lrem = cont ? nch - (kpos + 8u) : (got ? nnch : 0u);
-		const bool more = __any(lrem != 0u);
-		if (more) {
-#pragma unroll
-			for (uint32_t j = 0; j < 8; j++) {
-				const uint32_t ri = j * 8u + lr;   /* the reader lane this row belongs to */
-				const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)lsrc, (int)ri);
-				const uint32_t hi32 = (uint32_t)__shfl((int)(uint32_t)(lsrc >> 32), (int)ri);
-				const uint32_t rem = (uint32_t)__shfl((int)lrem, (int)ri);
-				const uint32_t piece = (lq - ((ri >> 1) & 7u)) & 7u;
-				if (piece < rem) {
-					const unsigned char *src = reinterpret_cast<const unsigned char *>(((uint64_t)hi32 << 32) | lo32) + piece * 16u;
-					__builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
-				}
-			}
-		}
-		/* top the ring up, one iteration ahead of the claims that will read it */
+		/* top the ring up, one iteration ahead of the claims that will read it -- and BEFORE this iteration's tile
+		 * requests go out: whatever wait the compiler attaches to these loads then has nothing of the tile to wait for */
 		if (staged - next < 64u && staged < w_hi) {
 			const uint64_t c = w_hi - staged < 64u ? w_hi - staged : 64u;
+			/* The loads land in registers of their own and nothing is computed from them here: any arithmetic
+			 * (or a copy into a variable shared by the two fronts) makes the compiler wait for them -- and with
+			 * them for the tile requests issued just above -- on the spot. */
 			if (lane < c) {
 				const uint64_t i = staged + lane;
-				if (a.off != nullptr) { sb = a.off[i]; sl = a.off[i + 1] - sb; }
-				else { sb = i * a.stride; sl = a.len != nullptr ? a.len[i] : a.stride; }
+				const u32x4 *po = reinterpret_cast<const u32x4 *>(a.off + i);   /* off[i] and off[i + 1] */
+				const uint32_t *pl = a.len + i;                                  /* (both addresses first: a temporary formed
+				                                                                 * after one load would be ordered behind it) */
+				if (a.off != nullptr) soff = *po;
+				else if (a.len != nullptr) slen = *pl;
 			}
 			spend = (uint32_t)c;
 		}
 
-		/* walk the segment in hand.  Only the first chunk of an input (its bytes start `head` bytes into
-		 * an aligned chunk) and its last one can be partial: those two take one predicated step each per
-		 * segment -- before and after the loop over the full chunks, for all lanes at once -- instead of
-		 * predicating every byte of every chunk (with 64 ragged lanes some lane is nearly always in a
-		 * partial chunk: the first version of this kernel spent 7 VALU operations per byte on that). */
-		if (tile && have) {
-			const uint32_t hc = head >> 4, hlo = head & 15u;     /* chunk and offset of the first byte */
-			if (kpos == 0u && hlo != 0u) {
-				const uint64_t hend = span - (uint64_t)hc * 16u;  /* bytes from that chunk's start to the input's end */
-				step16_part(pol, st, hw, hlo, (hend < 16u ? (uint32_t)hend : 16u) - hlo);
+		/* source, piece budget and last-piece pull-back of every row's next segment: each lane leaves a
+		 * 16-byte record for the 8 loader lanes of its row (one ds_write + 8 broadcast ds_reads per lane and
+		 * ONE wait, where cross-lane shuffles cost 3 per row and a wait each).  The record holds the source
+		 * moved back by the pull-back, so that every piece but the last adds it again: offsets stay >= 0. */
+		const uint64_t lsrc = cont ? csrc + 128u : np0;
+		const uint32_t lrem = cont ? nch - (kpos + 8u) : (got && !direct ? nnfull + (ntail != 0u ? 1u : 0u) : 0u);
+		const uint32_t ltail = cont ? tail : ntail, lfull = cont ? nfull : nnfull;
+		const uint32_t ladj = (ltail != 0u && lfull != 0u) ? 16u - ltail : 0u;
+		const bool more = __any(lrem != 0u || direct);
+		if (more) {
+			const uint64_t lbase = lsrc - ladj;
+			const u32x4 rec = {(uint32_t)lbase, (uint32_t)(lbase >> 32), lrem, ladj};
+			*reinterpret_cast<u32x4 *>(rows + lane * 16u) = rec;
+			u32x4 rr[8];
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++)
+				rr[j] = *reinterpret_cast<const u32x4 *>(rows + (j * 8u + lr) * 16u);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++) {
+				const uint32_t piece = (lq - ((j * 4u + (lr >> 1)) & 7u)) & 7u;   /* rotation of row j * 8 + lr: (row >> 1) & 7 */
+				if (piece < rr[j].z) {
+					const uint32_t o = piece * 16u + (piece + 1u == rr[j].z ? 0u : rr[j].w);
+					const unsigned char *src = reinterpret_cast<const unsigned char *>(((uint64_t)rr[j].y << 32) | rr[j].x) + o;
+					__builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(stg + j * 1024u), 16, 0, 0);
+				}
 			}
+		}
+		/* walk the segment in hand: its whole pieces, then -- for the lanes whose input ends here with a
+		 * partial piece -- one predicated step, for all of them at once (predicating every byte of every
+		 * chunk instead costs 7 VALU operations per byte: with 64 ragged lanes some lane is nearly always
+		 * in a partial chunk) */
+		if (tile && have) {
+			const uint32_t m = nfull - kpos;
 #pragma unroll
 			for (uint32_t p = 0; p < 8; p++) {
-				const uint32_t k = kpos + p;
-				if (k >= c_lo && k < c_hi) {
+				if (p < m) {
 					typename Pol::S s1[1] = { st };
 					const u32x4 w1[1] = { w[p] };
 					step16<Pol, 1>(pol, s1, w1);
 					st = s1[0];
 				}
 			}
-			const uint32_t tail = (uint32_t)span & 15u;
-			/* the tail chunk, unless it is the head chunk (an input that ends inside its first chunk) */
-			if (tail != 0u && c_hi >= c_lo && c_hi >= kpos && c_hi < kpos + 8u)
-				step16_part(pol, st, tw, 0u, tail);
+			if (tail != 0u && m < 8u)
+				step16_part(pol, st, tw, nfull != 0u ? 16u - tail : 0u, tail);
 		}
 		if (fin) {
 			write_result_lane(a, ci, Pol::code(st));
@@ -1429,7 +1504,7 @@ walk_ragged(const WalkArgs a)
 			kpos += 8u;
 			csrc += 128u;
 		} else if (got) {
-			ci = ni; csrc = nq0; span = nspan; nch = nnch; head = nhead; kpos = 0;
+			ci = ni; csrc = np0; nfull = nnfull; tail = ntail; kpos = 0;
 			st = init_state(pol, start_code(a, ni, true), a, ni, true, 0);
 		}
 		have = cont || got;

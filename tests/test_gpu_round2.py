@@ -10,6 +10,7 @@
 Bit-exact everywhere."""
 import ctypes
 import os
+import sys
 import subprocess
 import threading
 
@@ -85,6 +86,18 @@ def test_eager_outputs_fast_kernels_golden_dfas(hip):
                 n_checked += len(rows)
             dfa.close()
     assert n_checked > 100000 and n_fired > 2000
+
+
+def test_eager_64bit_columns_repeated_launches(hip):
+    """Regression / tripwire: eager walks of the 7..16-state goldens in the TINY layout, every input mode at
+    4 / 8 / 12 wavefronts, 40 launches each on two alternating row sets (so a stale result is a wrong one).
+    One build of the ragged kernel failed ~3 % of these launches (walk_kernels.h, note at TinyPol::heavy_next);
+    the single launch per configuration of the test above would mostly miss that."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import eager_tiny64_stress
+    lines = []
+    n, bad = eager_tiny64_stress.run(40, out=lines.append)
+    assert n >= 4 * 3 * 40 and bad == 0, lines
 
 
 @pytest.mark.parametrize("nids", [40, 64, 65, 300])
@@ -271,10 +284,9 @@ def test_ragged_kernel_length_distributions(hip, name, alpha):
                 dfa = hip.HipDfa(g.flat, L)
             except OSError:
                 continue
-            for mode, waves, align in ((hip.IN_RAGGED, 0, 0), (hip.IN_RAGGED, 1, 1), (hip.IN_RAGGED, 7, 0), (hip.IN_RAGGED, 0, 1), (hip.IN_GENERIC, 0, 0)):
+            for mode, waves, align in ((hip.IN_RAGGED, 0, 0), (hip.IN_RAGGED, 1, 0), (hip.IN_RAGGED, 7, 0), (hip.IN_GENERIC, 0, 0)):
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
-                dfa.tune(hip.KNOB_RAGGED_ALIGN, align)      # an input's segments start at a 16- or a 128-byte boundary
                 for early in (1, 0):
                     dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                     end, bm = dfa.exec_batch_offsets(base, off)
@@ -297,6 +309,68 @@ def test_ragged_kernel_length_distributions(hip, name, alpha):
         e = o.endids(int(want[i]))
         assert ids[i] == (int(e[0]) if len(e) else 0xFFFFFFFE)
     assert (ids[want == NO] == NO).all()
+    dfa.close()
+
+
+def test_ragged_kernel_batch_end_and_tiny_inputs(hip):
+    """The ragged kernel fetches 16-byte pieces from the inputs' own byte addresses and never reads beyond the
+    batch: an input's last partial piece comes from (end - 16), and inputs shorter than 16 bytes that sit within
+    16 bytes of the batch's end are assembled from byte loads.  Device-resident batches of EXACTLY the inputs'
+    size (packed, and fixed stride < 16 with lengths): every total from 0 to 40 bytes, tiny inputs at the end
+    after long ones, all lengths 0..33 at every start alignment -- against the oracle."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))        # [Ll]ibf+(sm)*, unanchored: "libf" anywhere accepts
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(11)
+    a = np.frombuffer(b"Llibfsmx\0", np.uint8)
+
+    def rnd(k):
+        return bytes(a[rng.randint(0, len(a), k)])
+
+    def tiny(k):
+        s = bytearray(rnd(k))
+        if k >= 4 and rng.randint(2):
+            at = rng.randint(0, k - 3)
+            s[at:at + 4] = b"libf"
+        return bytes(s)
+
+    dfa = hip.HipDfa(g.flat)
+    dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_RAGGED)
+    batches = []
+    for total in range(0, 41):                                   # whole batch smaller than / around one piece
+        cut = sorted(rng.randint(0, total + 1, rng.randint(0, 6)))
+        body = tiny(total)
+        batches.append([body[x:y] for x, y in zip([0] + cut, cut + [total])])
+    for k in range(60):                                          # long inputs, then tiny ones up to the last byte
+        batches.append([tiny(rng.randint(0, 700)) for _ in range(rng.randint(1, 150))] + [tiny(rng.randint(0, 16)) for _ in range(rng.randint(1, 9))])
+    batches.append([tiny(L) for L in range(34) for _ in range(16)])           # every length at every alignment
+    batches.append([tiny(L) for L in range(33, -1, -1) for _ in range(17)])
+    for strings in batches:
+        ret, want = o.exec_strings(strings)
+        base, off = _packed(strings)
+        d_base = torch.from_numpy(base.copy()).cuda() if len(base) else torch.empty(0, dtype=torch.uint8, device="cuda")
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        d_end = torch.full((len(strings),), 7, dtype=torch.int32, device="cuda")
+        d_bm = torch.zeros((len(strings) + 63) // 64, dtype=torch.int64, device="cuda")
+        for waves in (0, 1):
+            dfa.tune(hip.KNOB_WAVES, waves)
+            dfa.exec_batch_offsets_device(d_base.data_ptr(), d_off.data_ptr(), len(strings), d_end.data_ptr(), d_bm.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (len(strings), len(base))
+            assert np.array_equal(bits(d_bm.cpu().numpy(), len(strings)), ret == 1)
+    # fixed stride below 16 with lengths: the rows at the end of the buffer take the byte-load path
+    for stride in (1, 3, 5, 15, 16, 17, 31):
+        n = 1000 + stride
+        rows = np.stack([np.frombuffer(tiny(stride), np.uint8) for _ in range(n)])
+        lens = rng.randint(0, stride + 1, n).astype(np.uint32)
+        ret, want = o.exec_stride(rows, lens)
+        d_rows = torch.from_numpy(rows).cuda()
+        d_len = torch.from_numpy(lens.view(np.int32)).cuda()
+        d_end = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        dfa.exec_batch_device(d_rows.data_ptr(), stride, n, d_end.data_ptr(), 0, d_len=d_len.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), stride
     dfa.close()
 
 

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""tests/tools/eager_tiny64_stress.py -- repeated launches of the eager walks whose automaton has 7..16 states
+(64-bit transition columns, TinyPol<u64>) in the TINY layout, every input mode, 4 / 8 / 12 wavefronts per workgroup.
+
+Two row sets alternate, so a result left over from the previous launch is a wrong one.  One build of the ragged
+kernel gave an intermittent wrong result here (walk_kernels.h, note at TinyPol::heavy_next): this is the run that
+showed it (61-86 bad launches of 2700) and that the shipped kernels pass.  REPS = launches per configuration.
+Prints one line per (mode, waves) and exits non-zero if any launch was wrong."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(reps, modes=None, waves=(4, 8, 12), out=print):
+    import libfsm_amd as hip
+    from common import Golden, eager_golden_paths
+    from oracle.pyoracle import Oracle
+    hip.load_library()
+    rng = np.random.RandomState(77)
+    modes = modes or (hip.IN_LDSDMA, hip.IN_DIRECT, hip.IN_GENERIC, hip.IN_RAGGED)
+    stats = {}
+    for path in eager_golden_paths():
+        g = Golden(path)
+        if not 7 <= g.flat.nstates + 1 <= 16:
+            continue
+        pats = [p.encode("latin1").strip(b"^$") for p in g.meta["patterns"]]
+        alpha = np.frombuffer((" ".join(g.meta["patterns"]) + " xyz").encode("latin1"), np.uint8)
+        sets_ = []
+        for v in range(2):
+            rows = alpha[rng.randint(0, len(alpha), (330, 256))]
+            for i in range(v, 330, 3):
+                p = pats[rng.randint(len(pats))]
+                if 0 < len(p) <= 60 and not any(c in p for c in b"[]()*+?|\\."):
+                    at = rng.randint(0, 256 - len(p))
+                    rows[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
+            _, wend, wsets = Oracle(g.flat).exec_eager(rows)
+            sets_.append((rows, wend, wsets))
+        try:
+            dfa = hip.HipDfa(g.flat, hip.LAYOUT_TINY)
+        except OSError:
+            continue
+        for mode in modes:
+            for w in waves:
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, w)
+                t = stats.setdefault((mode, w), [0, 0, set()])
+                for rep in range(reps):
+                    rows, wend, wsets = sets_[rep & 1]
+                    end, sets = dfa.exec_batch_eager(rows)
+                    bad = [i for i in range(len(rows)) if end[i] != wend[i] or not np.array_equal(sets[i], wsets[i])]
+                    t[0] += 1
+                    if bad:
+                        t[1] += 1
+                        t[2].update(b // 64 for b in bad)
+        dfa.close()
+    total_bad = 0
+    for (mode, w), t in sorted(stats.items()):
+        out(f"eager, 64-bit columns, input mode {mode}, {w:2d} wavefronts: {t[0]} launches, {t[1]} wrong (bitmap words {sorted(t[2])})")
+        total_bad += t[1]
+    return sum(t[0] for t in stats.values()), total_bad
+
+
+if __name__ == "__main__":
+    n, bad = run(int(os.environ.get("REPS", 100)))
+    sys.exit(1 if bad else 0)

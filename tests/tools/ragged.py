@@ -23,6 +23,7 @@ def main():
     buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
     end = torch.empty(n, dtype=torch.int32, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(1)
+    only = os.environ.get("RAGGED_CASES")      # e.g. "c2:packed:3,c2:rows:1": workload:front:mode filters (profiling runs)
     for dist in ("uniform0-1024", "short8-64"):
         if dist.startswith("uniform"):
             lens = torch.randint(0, L + 1, (n,), device="cuda", dtype=torch.int32, generator=g)
@@ -35,33 +36,45 @@ def main():
             flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
             bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
             torch.cuda.synchronize()
-            mask = torch.arange(L, device="cuda", dtype=torch.int32)[None, :] < lens[:, None]
-            packed = torch.cat([buf[mask], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+            ar = torch.arange(L, device="cuda", dtype=torch.int32)[None, :]
+            packed = torch.empty(total, dtype=torch.uint8, device="cuda")      # exactly the inputs' bytes: nothing after the last one
+            for r0 in range(0, n, 1 << 20):                                     # masked selects of <= 1 GiB at a time
+                r1 = min(n, r0 + (1 << 20))
+                packed[int(off[r0]):int(off[r1])] = buf[r0:r1][ar < lens[r0:r1, None]]
             dfa = hip.HipDfa(flat)
             idx = np.random.RandomState(0).randint(0, n, 1024)
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
             ref = None
-            for front, mode, waves, align in (("packed", 3, 0, 0), ("packed", 3, 0, 1), ("packed", 3, 6, 0), ("packed", 2, 0, 0),
-                                              ("stride+len", 3, 0, 0), ("stride+len", 3, 0, 1), ("stride+len", 2, 0, 0)):
+            for front, mode, waves, align in (("packed", 3, 0, 0), ("packed", 3, 8, 0), ("packed", 3, 16, 0), ("packed", 2, 0, 0),
+                                              ("stride+len", 3, 0, 0), ("stride+len", 2, 0, 0), ("rows", 3, 0, 0), ("rows", -1, 0, 0)):
+                if only is not None and f"{wl}:{front}:{mode}" not in only.split(","):
+                    continue
+                if front == "rows" and dist != "uniform0-1024":
+                    continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
-                dfa.tune(hip.KNOB_RAGGED_ALIGN, align)
                 ms = []
                 for r in range(4):
                     if front == "packed":
                         dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n, end.data_ptr(), 0)
+                    elif front == "rows":       # whole 1024-byte rows: what the same kernel (3) / the LDS-DMA kernel (-1) does without raggedness
+                        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)
                     else:
                         dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0, d_len=lens.data_ptr())
                     t = dfa.last_kernel_ms()
                     if r:
                         ms.append(t)
                 torch.cuda.synchronize()
+                if front == "rows":
+                    print(f"{wl} {dfa.info()['layout_name']:8s} lens=1024           front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
+                          f"GB/s(walked)={n * L / min(ms) / 1e6:8.1f}", flush=True)
+                    continue
                 ok = np.array_equal(end.cpu().numpy().view(np.uint32)[idx], want)
                 if ref is None:
                     ref = end.clone()
                 ok = ok and bool(torch.equal(ref, end))
-                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode} waves={waves:2d} align128={align} ms={min(ms):8.3f} "
+                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
                       f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
             dfa.close()
 
