@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(reps, modes=None, waves=(4, 8, 12), out=print):
+def run(reps, modes=None, waves=(4, 8, 12), out=print, layouts=("TINY",), states=(7, 16), fronts=("eager",)):
     import libfsm_amd as hip
     from common import Golden, eager_golden_paths
     from oracle.pyoracle import Oracle
@@ -26,7 +26,7 @@ def run(reps, modes=None, waves=(4, 8, 12), out=print):
     stats = {}
     for path in eager_golden_paths():
         g = Golden(path)
-        if not 7 <= g.flat.nstates + 1 <= 16:
+        if not states[0] <= g.flat.nstates + 1 <= states[1]:
             continue
         pats = [p.encode("latin1").strip(b"^$") for p in g.meta["patterns"]]
         alpha = np.frombuffer((" ".join(g.meta["patterns"]) + " xyz").encode("latin1"), np.uint8)
@@ -39,32 +39,42 @@ def run(reps, modes=None, waves=(4, 8, 12), out=print):
                     at = rng.randint(0, 256 - len(p))
                     rows[i, at:at + len(p)] = np.frombuffer(p, np.uint8)
             _, wend, wsets = Oracle(g.flat).exec_eager(rows)
-            sets_.append((rows, wend, wsets))
-        try:
-            dfa = hip.HipDfa(g.flat, hip.LAYOUT_TINY)
-        except OSError:
-            continue
-        for mode in modes:
-            for w in waves:
-                dfa.tune(hip.KNOB_INPUT_MODE, mode)
-                dfa.tune(hip.KNOB_WAVES, w)
-                t = stats.setdefault((mode, w), [0, 0, set()])
-                for rep in range(reps):
-                    rows, wend, wsets = sets_[rep & 1]
-                    end, sets = dfa.exec_batch_eager(rows)
-                    bad = [i for i in range(len(rows)) if end[i] != wend[i] or not np.array_equal(sets[i], wsets[i])]
-                    t[0] += 1
-                    if bad:
-                        t[1] += 1
-                        t[2].update(b // 64 for b in bad)
-        dfa.close()
+            sets_.append((rows, wend, wsets, Oracle(g.flat).exec_stride(rows)[1]))
+        for lname in layouts:
+            try:
+                dfa = hip.HipDfa(g.flat, getattr(hip, "LAYOUT_" + lname))
+            except OSError:
+                continue
+            for front in fronts:
+                for mode in modes:
+                    for w in waves:
+                        dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                        dfa.tune(hip.KNOB_WAVES, w)
+                        t = stats.setdefault((lname, front, mode, w), [0, 0, set()])
+                        for rep in range(reps):
+                            rows, wend, wsets, wplain = sets_[rep & 1]
+                            if front == "eager":
+                                end, sets = dfa.exec_batch_eager(rows)
+                                bad = [i for i in range(len(rows)) if end[i] != wend[i] or not np.array_equal(sets[i], wsets[i])]
+                            else:
+                                end, _ = dfa.exec_batch(rows)
+                                bad = list(np.nonzero(end != wplain)[0])
+                            t[0] += 1
+                            if bad:
+                                t[1] += 1
+                                t[2].update(int(b) // 64 for b in bad)
+            dfa.close()
     total_bad = 0
-    for (mode, w), t in sorted(stats.items()):
-        out(f"eager, 64-bit columns, input mode {mode}, {w:2d} wavefronts: {t[0]} launches, {t[1]} wrong (bitmap words {sorted(t[2])})")
+    for (lname, front, mode, w), t in sorted(stats.items()):
+        out(f"{lname:8s} {front:5s} input mode {mode}, {w:2d} wavefronts: {t[0]} launches, {t[1]} wrong (bitmap words {sorted(t[2])})")
         total_bad += t[1]
     return sum(t[0] for t in stats.values()), total_bad
 
 
 if __name__ == "__main__":
-    n, bad = run(int(os.environ.get("REPS", 100)))
+    if os.environ.get("ALL_LAYOUTS"):      # every eager-capable layout, every automaton, eager and plain fronts
+        n, bad = run(int(os.environ.get("REPS", 40)), modes=(1, 3), waves=(8, 12), states=(1, 1 << 30), fronts=("eager", "plain"),
+                     layouts=("TINY", "COMBSELF", "COMB256", "LDSSELF", "LDS", "COMB", "SPARSE", "GLOBAL"))
+    else:
+        n, bad = run(int(os.environ.get("REPS", 100)))
     sys.exit(1 if bad else 0)
