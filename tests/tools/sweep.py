@@ -66,7 +66,7 @@ def main():
             flat = c5_dfa()
             hip.gen_inputs_device(buf.data_ptr(), n, L, 0, 0x5EEDF5A1, b"abcdefghijklmnopqrstuvwxyz")
         else:
-            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else "c3.npz"))
+            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", {"c2": "c1.npz", "c3t": "c3t.npz"}.get(wl, "c3.npz")))
             bench.generate(hip, wl, buf.data_ptr(), n, L, 0)
         torch.cuda.synchronize()
         first = True
@@ -95,6 +95,9 @@ def main():
                 variants = [(-1, 0, 0, 0, 0, -1, 1), (hip.IN_LDSDMA, 128, 1, 16, 0, 4, 1), (hip.IN_LDSDMA, 128, 1, 12, 0, 4, 1),
                             (hip.IN_LDSDMA, 128, 1, 8, 0, 4, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 1, 16, 0, 2, 1),
                             (hip.IN_RAGGED, 0, 1, 0, 0, 0, 1), (hip.IN_GENERIC, 0, 1, 16, 0, 0, 1)]
+            if a.set == "rows":  # one vs two inputs per lane (needs walk_direct<Pol,4,2> instantiated: profiles/r03b_*; rows=2 is ignored otherwise)
+                variants = [(-1, 0, 0, 0, 0, -1, 1), (hip.IN_DIRECT, 4, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 2, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 2, 12, 0, 0, 1),
+                            (hip.IN_DIRECT, 4, 2, 8, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1), (hip.IN_LDSDMA, 128, 1, 8, 0, 4, 1)]
             if a.set == "dma":  # LDS-DMA staging next to an LDS table: how many waves fit / pay
                 variants = [(hip.IN_LDSDMA, 128, 1, w, b, m, 1) for w in (16, 14, 12, 10, 8) for b in (0, 1) for m in (0, 4)]
                 variants += [(hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 2, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]
