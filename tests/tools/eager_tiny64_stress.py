@@ -55,7 +55,7 @@ def run(reps, modes=None, waves=(4, 8, 12), out=print, layouts=("TINY",), states
                             rows, wend, wsets, wplain = sets_[rep & 1]
                             if front == "eager":
                                 end, sets = dfa.exec_batch_eager(rows)
-                                bad = [i for i in range(len(rows)) if end[i] != wend[i] or not np.array_equal(sets[i], wsets[i])]
+                                bad = [i for i in range(len(rows)) if end[i] != wend[i] or (os.environ.get("CHECK") != "end" and not np.array_equal(sets[i], wsets[i]))]
                             else:
                                 end, _ = dfa.exec_batch(rows)
                                 bad = list(np.nonzero(end != wplain)[0])
