@@ -505,6 +505,15 @@ def main():
                          "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        # "also report touched bytes when early-retire is enabled".  A wavefront stops reading once all 64 of its
+        # inputs sit in absorbing states (fsm_exec's own early exit, exec.c:133-138); what was actually fetched is the
+        # read side of the recorded PMC traffic.
+        res["roofline"]["early_retire"] = {
+            "enabled": True,   # the library default; FSM_HIP_NO_EARLY_RETIRE at create time switches it off
+            "touched_bytes_per_launch": traffic,
+            "touched_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
+            "note": "HBM bytes per launch from the recorded PMC passes (reads + the 4-byte results): ~1.00 means every input byte was still fetched",
+        }
         if wl == "c5":
             res["roofline"]["note"] = ("this walk is bound by the instructions of its divergent chain loop, not by HBM (DESIGN.md section 3; "
                                        "profiles/r02n_c5_rocprof_summary.json: 0.33 L2 requests per input byte, 93.8 % hits, calibrated HBM traffic "
