@@ -98,6 +98,10 @@ def test_eager_64bit_columns_repeated_launches(hip):
     lines = []
     n, bad = eager_tiny64_stress.run(40, out=lines.append)
     assert n >= 4 * 3 * 40 and bad == 0, lines
+    # and the ragged kernel on packed inputs, plain walks, every layout of the C1 / C3 automata: 30 launches each
+    lines = []
+    n, bad = eager_tiny64_stress.run_packed(30, out=lines.append)
+    assert n >= 300 and bad == 0, lines
 
 
 @pytest.mark.parametrize("nids", [40, 64, 65, 300])

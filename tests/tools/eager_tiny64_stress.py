@@ -71,10 +71,66 @@ def run(reps, modes=None, waves=(4, 8, 12), out=print, layouts=("TINY",), states
     return sum(t[0] for t in stats.values()), total_bad
 
 
+def run_packed(reps, out=print):
+    """The ragged kernel on packed inputs, plain walks: two different batches (uniform 0..300-byte inputs, some
+    accepted) alternate on every layout that holds the C1 / C3 automaton; every launch is compared with the oracle."""
+    import libfsm_amd as hip
+    from common import GOLDEN, Golden
+    from oracle.pyoracle import Oracle
+    hip.load_library()
+    total = bad_total = 0
+    for name, alpha in (("c1.npz", b"Llibfsmx\0"), ("c3.npz", b"abcdwxyz0123456789")):
+        g = Golden(os.path.join(GOLDEN, name))
+        o = Oracle(g.flat)
+        rng = np.random.RandomState(len(alpha))
+        a = np.frombuffer(alpha, np.uint8)
+        pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n") if name == "c3.npz" else None
+
+        def one(k):
+            if k >= 8 and rng.randint(3) == 0:
+                if pats is None:
+                    s = bytearray(a[rng.randint(0, len(a), k)])
+                    at = rng.randint(0, k - 5)
+                    s[at:at + 6] = b"Libfsm"
+                    return bytes(s)
+                p = pats[rng.randint(len(pats))]
+                return p[1:p.index(b"[")] + bytes(rng.randint(48, 58, max(1, k - 6)).astype(np.uint8)) + b"yz"
+            return bytes(a[rng.randint(0, len(a), k)])
+
+        batches = []
+        for v in range(2):
+            strings = [one(rng.randint(0, 301)) for _ in range(700 + 37 * v)]
+            off = np.zeros(len(strings) + 1, np.uint64)
+            off[1:] = np.cumsum([len(s) for s in strings])
+            batches.append((np.frombuffer(b"".join(strings), np.uint8), off, o.exec_strings(strings)[1]))
+        for layout in hip.ALL_LAYOUTS:
+            try:
+                dfa = hip.HipDfa(g.flat, layout)
+            except OSError:
+                continue
+            dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_RAGGED)
+            for w in (0, 6):
+                dfa.tune(hip.KNOB_WAVES, w)
+                n = bad = 0
+                for rep in range(reps):
+                    base, off, want = batches[rep & 1]
+                    end, _ = dfa.exec_batch_offsets(base, off)
+                    n += 1
+                    bad += not np.array_equal(end, want)
+                out(f"{name} {dfa.info()['layout_name']:8s} packed, ragged kernel, waves {w:2d}: {n} launches, {bad} wrong")
+                total += n
+                bad_total += bad
+            dfa.close()
+    return total, bad_total
+
+
 if __name__ == "__main__":
-    if os.environ.get("ALL_LAYOUTS"):      # every eager-capable layout, every automaton, eager and plain fronts
+    if os.environ.get("PACKED"):
+        n, bad = run_packed(int(os.environ.get("REPS", 100)))
+    elif os.environ.get("ALL_LAYOUTS"):      # every eager-capable layout, every automaton, eager and plain fronts
         n, bad = run(int(os.environ.get("REPS", 40)), modes=(1, 3), waves=(8, 12), states=(1, 1 << 30), fronts=("eager", "plain"),
                      layouts=("TINY", "COMBSELF", "COMB256", "LDSSELF", "LDS", "COMB", "SPARSE", "GLOBAL"))
     else:
         n, bad = run(int(os.environ.get("REPS", 100)))
     sys.exit(1 if bad else 0)
+
