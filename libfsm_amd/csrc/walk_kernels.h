@@ -1293,7 +1293,7 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
  * (half the lane-steps idle at uniform 0..1024 B).  Here
  *  - input bytes arrive as in walk_ldsdma: per 128-byte segment of a lane's input, 8 adjacent loader
  *    lanes fetch its 8 16-byte pieces with ONE global_load_lds_dwordx4 (each row's source address is
- *    the owner lane's current position, handed to the loaders by cross-lane shuffles; pieces beyond
+ *    the owner lane's current position, left for the loaders in a per-lane LDS record; pieces beyond
  *    the input's last one are masked off), piece-rotated so the row-per-lane ds_read_b128 that
  *    follows is conflict-free; the next segment is in flight while the current one is walked;
  *  - the source of a piece is the input's own byte address + 16 * piece: global_load_lds_dwordx4 takes
