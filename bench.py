@@ -406,6 +406,8 @@ def main():
             dfa.tune(int(k), int(v))
         if variant == "noskip":
             dfa.tune(KNOB_NOSKIP, 1)
+        if variant == "loadskip":
+            dfa.tune(hip.KNOB_EARLY_RETIRE, 3)   # bit 1: a lane in an absorbing state stops reading its row (fsm_exec's own early exit)
         info = dfa.info()
         nwords = (n_ + 63) // 64
         bm = torch.zeros(nwords, dtype=torch.int64, device="cuda")
@@ -476,8 +478,8 @@ def main():
         # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 passes (tools/profile.sh),
         # never inside this run -- quoted only when the recorded launch is the same workload, size and kernel
         traffic, traffic_source = None, None
-        pj = os.path.join(ROOT, "profiles", f"pmc_{wl}.json")
-        if variant is None and os.path.exists(pj):
+        pj = os.path.join(ROOT, "profiles", f"pmc_{wl}.json" if variant is None else f"pmc_{wl}_{variant}.json")
+        if variant in (None, "loadskip") and os.path.exists(pj):
             try:
                 t = json.load(open(pj))
                 if int(t.get("n", 0)) == n_ and int(t.get("len", 0)) == L:
@@ -489,6 +491,9 @@ def main():
         text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl in ("c3", "c3t") else (len(words), flat.nstates) if wl == "c5" else ())
         if variant == "noskip":
             text += "chunk skip disabled (every byte pays its self-loop test: the transition-dense bound of this table), "
+        if variant == "loadskip":
+            text += ("per-lane load skip ON (a lane whose input can no longer change state stops reading it, as fsm_exec stops pulling bytes "
+                     "at a missing edge: the rate counts the bytes MATCHED, fewer are touched -- roofline.early_retire), ")
         res = {
             "value": round(value, 2), "ms_per_step": round(ms_step, 4),
             "config": {
@@ -510,6 +515,7 @@ def main():
         # read side of the recorded PMC traffic.
         res["roofline"]["early_retire"] = {
             "enabled": True,   # the library default; FSM_HIP_NO_EARLY_RETIRE at create time switches it off
+            "per_lane_load_skip": variant == "loadskip",
             "touched_bytes_per_launch": traffic,
             "touched_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
             "note": "HBM bytes per launch from the recorded PMC passes (reads + the 4-byte results): ~1.00 means every input byte was still fetched",
@@ -538,6 +544,9 @@ def main():
             if res["full_parity"]["mismatches"]:
                 res["value"] = None
         res["_buf"] = (buf, bm)
+        # a digest of all n end states: a variant run over the same inputs (noskip, loadskip) must reproduce the main run's
+        res["_digest"] = (int(end.to(torch.int64).sum().item()), int((end.to(torch.int64) * (torch.arange(n_, device="cuda", dtype=torch.int64) % 1000003 + 1)).sum().item()),
+                          int(acc_t.item())) if world == 1 else None
         dfa.close()
         return res
 
@@ -547,12 +556,19 @@ def main():
         plan = []
         if a.workload == "c3":
             plan.append(("c3", "noskip", None))
+            plan.append(("c3", "loadskip", None))
         for wl in ("c3", "c3t", "c2", "c5"):
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
         for wl, variant, n_wl in plan:
             r = run(wl, variant, n_wl, with_cpu=(variant is None))
             r.pop("_buf", None)
+            dg = r.pop("_digest", None)
+            if variant is not None and wl == a.workload:
+                same = dg is not None and dg == main_res.get("_digest")
+                r["parity_vs_main_run"] = ("bit-exact: sum, index-weighted sum and accept count of all end states equal the main run's" if same else "MISMATCH")
+                if not same:
+                    r["value"] = None
             r["workload"] = wl + ("_" + variant if variant else "")
             subs.append(r)
         # leave the main workload's inputs in the buffer for the stream probe below
@@ -563,6 +579,7 @@ def main():
         return
 
     buf, bm = main_res.pop("_buf")
+    main_res.pop("_digest", None)
     stream_gbps = None
     try:  # what a read-only kernel sustains over the same resident bytes (three access patterns, the fastest)
         stream_gbps = hip.stream_read_probe_gbps(buf.data_ptr(), buf.numel(), bm.data_ptr(), 3, stream)

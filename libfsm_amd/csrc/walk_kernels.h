@@ -1140,10 +1140,23 @@ walk_ldsdma(const WalkArgs a)
 			__builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): tile is in registers, slot reusable */
 			__asm__ volatile("" ::: "memory");
 			if (s + 1 < nseg) {
+				if (a.early & 2u) {
+					/* A lane in an absorbing state stops reading its row, as fsm_exec stops pulling bytes at a
+					 * missing edge (exec.c:133-138): the rows of the lanes that are absorbing NOW are left out of
+					 * the next tile (their slots keep stale bytes, which an absorbing state ignores -- and which
+					 * pass every chunk-level skip test, an absorbing state looping on all 256 bytes). */
+					const uint64_t mine = __ballot(Pol::code(st[0]) >= a.abs_min) >> lr;   /* bit j * RPI: row j * RPI + lr */
 #pragma unroll
-				for (uint32_t j = 0; j < NDMA; j++)
-					__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * SEG),
-					                                 (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
+					for (uint32_t j = 0; j < NDMA; j++)
+						if (!((mine >> (j * RPI)) & 1u))
+							__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * SEG),
+							                                 (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
+				} else {
+#pragma unroll
+					for (uint32_t j = 0; j < NDMA; j++)
+						__builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + (uint64_t)(s + 1) * SEG),
+						                                 (lds_void_t *)(stg + j * 1024u), 16, 0, AUX);
+				}
 			}
 #pragma unroll
 			for (uint32_t p = 0; p < PIECES; p++) step16<Pol, 1>(pol, st, w[p]);

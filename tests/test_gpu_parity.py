@@ -81,10 +81,12 @@ def test_fast_paths_every_mode(hip, name):
             dfa.tune(hip.KNOB_SEG, nb if mode == hip.IN_LDSDMA else 0)
             dfa.tune(hip.KNOB_NB, nb if mode == hip.IN_DIRECT else 0)
             dfa.tune(hip.KNOB_WAVES, waves)
-            for early, pre in ((0, 1), (1, 1), (0, 0), (1, 0)):
+            # early: bit 0 = a wavefront retires once all its lanes are absorbing, bit 1 = an absorbing lane stops
+            # reading its row (LDS-DMA and no-prefetch kernels: the row's slot keeps stale bytes)
+            for early, pre in ((0, 1), (1, 1), (0, 0), (1, 0), (3, 1), (3, 0), (2, 1)):
                 dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                 dfa.tune(hip.KNOB_PREFETCH, pre)
-                dfa.tune(hip.KNOB_NT, early)
+                dfa.tune(hip.KNOB_NT, early & 1)
                 end, bm = dfa.exec_batch(rows)
                 assert np.array_equal(end, g.end), (name, L, mode, nb, waves, early, pre)
                 assert np.array_equal(bits(bm, n), g.ret == 1)
@@ -907,10 +909,11 @@ def test_chunk_skip_never_skips_a_state_change(hip):
     lens = np.full(len(rows), L, np.uint32)
     for mode in (hip.IN_LDSDMA, hip.IN_DIRECT, hip.IN_GENERIC):
         dfa.tune(hip.KNOB_INPUT_MODE, mode)
-        for early in (0, 1):
+        for early in (0, 1, 2, 3):
             dfa.tune(hip.KNOB_EARLY_RETIRE, early)
             end, _ = dfa.exec_batch(rows)
             assert np.array_equal(end, want), (mode, early)
+    dfa.tune(hip.KNOB_EARLY_RETIRE, 1)
     end, _ = dfa.exec_batch(rows, lens)      # the ragged kernel's whole-chunk fast path
     assert np.array_equal(end, want)
     dfa.close()
