@@ -4,7 +4,7 @@
  * same soname for the CPU test suite (tests/test_retest_patch.py), so the control flow the patch adds to
  * the reference's retest -- read ahead to the end of a record, one fsm_hip_exec_batch_offsets() call for
  * its test lines, results handed out by fsm_runner_run() -- can be checked on a box without a GPU.  The
- * four entry points the patch calls are answered by the reference's own DFAVM (fsm_vm_*, resolved from
+ * entry points the patch calls are answered by the reference's own DFAVM (fsm_vm_*, resolved from
  * the retest executable, which contains libfsm), and each call is counted: the counts are printed when
  * the process exits.  The GPU suite runs the same retest binary against the real library. */
 #include <stdint.h>
@@ -19,13 +19,13 @@ void fsm_vm_free(struct fsm_dfavm *vm);
 
 struct fsm_hip_dfa { struct fsm_dfavm *vm; };
 
-static unsigned long n_compile, n_batch, n_batch_inputs, n_single;
+static unsigned long n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs;
 
 static void
 report(void)
 {
-	fprintf(stderr, "stub_fsm_hip: compile=%lu batch_calls=%lu batch_inputs=%lu single_calls=%lu\n",
-		n_compile, n_batch, n_batch_inputs, n_single);
+	fprintf(stderr, "stub_fsm_hip: compile=%lu batch_calls=%lu batch_inputs=%lu single_calls=%lu stride_calls=%lu stride_inputs=%lu\n",
+		n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs);
 }
 
 struct fsm_hip_dfa *
@@ -74,6 +74,22 @@ fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *d, const unsigned char *bas
 	n_batch_inputs += n;
 	for (i = 0; i < n; i++) {
 		if (fsm_vm_match_buffer(d->vm, (const char *) base + off[i], (size_t) (off[i + 1] - off[i]))) {
+			accept_bitmap[i / 64] |= (uint64_t) 1 << (i % 64);
+		}
+	}
+	return 0;
+}
+
+int
+fsm_hip_exec_batch(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	size_t i;
+	(void) end_out;
+	n_stride++;
+	n_stride_inputs += n;
+	for (i = 0; i < n; i++) {
+		if (fsm_vm_match_buffer(d->vm, (const char *) base + i * stride, len != NULL ? len[i] : stride)) {
 			accept_bitmap[i / 64] |= (uint64_t) 1 << (i % 64);
 		}
 	}

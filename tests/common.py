@@ -133,3 +133,17 @@ def retest_tst_lines():
         nre += 1
     assert (nre, ncases) == (37, 115)
     return lines, flip
+
+
+def reperf_scr_lines(count, flip=None):
+    """reperf/boost.scr (5 string cases, R 1 each) re-emitted in reperf's script format (src/retest/reperf.c:338-560:
+    '- name', M regexp, D dialect, S string, N runs, R expected matches, X = run) from the frozen goldens
+    tests/golden/reperf/*.npz, with N = count.  flip = index of a case whose expectation is inverted (R 0)."""
+    lines = ["# regenerated from tests/golden/reperf/*.npz"]
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "reperf", "*.npz")))
+    assert len(paths) == 5
+    for k, path in enumerate(paths):
+        g = Golden(path)
+        lines += ["", "- " + g.meta["name"], "M " + g.meta["regex"], "D " + g.meta["dialect"], "S " + g.strings()[0].decode("latin1"),
+                  "N %d" % count, "R %d" % (g.meta["expected_matches"] if k != flip else 1 - g.meta["expected_matches"]), "X"]
+    return lines

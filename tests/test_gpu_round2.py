@@ -584,6 +584,36 @@ def test_retest_l_hip(hip, tmp_path):
         assert out.stdout.strip().splitlines()[-1].endswith("0 re errors, 1 errors")
 
 
+def test_reperf_l_hip(hip, tmp_path):
+    """The reference's reperf(1) with the same runner patch (integration/_build/reperf): reperf/boost.scr's five string
+    cases, re-emitted from the frozen goldens.  `-l hip` sends the N runs of a case as batches of N copies
+    (fsm_runner_run_repeat -> fsm_hip_exec_batch: 10^6 runs = one launch), `-l hip-line` makes N calls as the loop at
+    src/retest/reperf.c:772-784 does; both agree with `-l vm`, and an inverted expectation is reported by all."""
+    from common import reperf_scr_lines
+    exe = os.path.join(ROOT, "integration", "_build", "reperf")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/reperf not built (needs /root/reference at build time)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+
+    def go(impl, lines):
+        scr = tmp_path / "t.scr"
+        scr.write_text("\n".join(lines) + "\n")
+        return subprocess.run([exe, "-C", "-l", impl, str(scr)], capture_output=True, text=True, errors="replace", env=env, timeout=600)
+
+    strip = lambda t: [l for l in t.splitlines() if "iterations took" not in l]
+    N = 1_000_000                                     # the script's own N
+    out = go("hip", reperf_scr_lines(N))
+    assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+    assert out.stdout.count("execute %d iterations took" % N) == 5
+    ref = go("vm", reperf_scr_lines(N))
+    assert strip(out.stdout) == strip(ref.stdout)
+    line = go("hip-line", reperf_scr_lines(300))
+    assert line.returncode == 0 and line.stdout.count("execute 300 iterations took") == 5
+    bad, badref = go("hip", reperf_scr_lines(5000, flip=3)), go("vm", reperf_scr_lines(5000, flip=3))
+    assert strip(bad.stdout) == strip(badref.stdout) and bad.returncode == badref.returncode
+    assert strip(bad.stdout) != strip(go("hip", reperf_scr_lines(5000)).stdout)
+
+
 # ---------------------------------------------------------------------------
 # multi-device front (C ABI): one replica per device, one host thread per device
 # ---------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import subprocess
 
 import pytest
 
-from common import retest_tst_lines
+from common import reperf_scr_lines, retest_tst_lines
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,7 +34,7 @@ def stub_dir(tmp_path_factory):
 def run(stub_dir, impl, path):
     env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)      # searched before the binary's RUNPATH
     out = subprocess.run([EXE, "-l", impl, str(path)], capture_output=True, text=True, errors="replace", env=env, timeout=300)
-    m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=(\d+) batch_inputs=(\d+) single_calls=(\d+)", out.stderr)
+    m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=(\d+) batch_inputs=(\d+) single_calls=(\d+) stride_calls=\d+ stride_inputs=\d+", out.stderr)
     assert m, out.stderr[-500:]
     # retest forks one child per file: one report
     return out, tuple(int(x) for x in m[-1])
@@ -106,3 +106,34 @@ def test_lines_the_read_ahead_did_not_see_fall_back(stub_dir, tmp_path):
     assert strip(out.stdout) == strip(ref.stdout)          # line for line what the reference's own VM reports
     assert out.returncode == ref.returncode
     assert ncomp == 2 and nbatch == 2 and nsingle == 0, (ncomp, nbatch, nin, nsingle)
+
+
+def test_reperf_runs_go_out_as_batches_of_copies(stub_dir, tmp_path):
+    """reperf(1) with the same patch: `-l hip` turns the N runs of a test (src/retest/reperf.c:772-784: N calls of
+    fsm_runner_run on the same string) into fsm_runner_run_repeat() -- batches of copies through fsm_hip_exec_batch --
+    `-l hip-line` keeps N calls; a wrong expectation (R 0 where the string matches) is reported."""
+    exe = os.path.join(ROOT, "integration", "_build", "reperf")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/reperf not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)
+
+    def go(impl, lines):
+        scr = tmp_path / "t.scr"
+        scr.write_text("\n".join(lines) + "\n")
+        out = subprocess.run([exe, "-C", "-l", impl, str(scr)], capture_output=True, text=True, errors="replace", env=env, timeout=300)
+        m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=\d+ batch_inputs=\d+ single_calls=(\d+) stride_calls=(\d+) stride_inputs=(\d+)", out.stderr)
+        assert m, out.stderr[-400:]
+        return out, tuple(int(x) for x in m[-1])
+
+    N = 3_000_000          # more than one block of 2^20 copies
+    out, (ncomp, nsingle, nstride, ninputs) = go("hip", reperf_scr_lines(N))
+    assert out.returncode == 0, out.stdout[-600:]
+    assert out.stdout.count("execute %d iterations took" % N) == 5 and "ERROR" not in out.stdout.upper().replace("ERROR_NONE", "")
+    assert (ncomp, nsingle, ninputs) == (5, 0, 5 * N) and nstride == 5 * 3
+    out, (ncomp, nsingle, nstride, ninputs) = go("hip-line", reperf_scr_lines(2000))
+    assert out.returncode == 0 and (ncomp, nsingle, nstride) == (5, 5 * 2000, 0)
+    out, counts = go("hip", reperf_scr_lines(1000, flip=2))
+    ref = subprocess.run([exe, "-C", "-l", "vm", str(tmp_path / "t.scr")], capture_output=True, text=True, errors="replace", timeout=300)
+    strip = lambda t: [l for l in t.splitlines() if "iterations took" not in l]
+    assert strip(out.stdout) == strip(ref.stdout) and out.returncode == ref.returncode     # the reference's VM reports the same failure
+    assert "should not match" in (out.stdout + out.stderr).lower() or out.returncode != 0
