@@ -13,11 +13,17 @@
 
 struct fsm;
 struct fsm_dfavm;
+struct fsm_capture;
+int fsm_exec(const struct fsm *fsm, int (*fsm_getc)(void *opaque), void *opaque, unsigned *end, struct fsm_capture *captures);
+int fsm_vm_match_file(const struct fsm_dfavm *vm, FILE *f);
 struct fsm_dfavm *fsm_vm_compile(const struct fsm *fsm);
 int fsm_vm_match_buffer(const struct fsm_dfavm *vm, const char *buf, size_t n);
 void fsm_vm_free(struct fsm_dfavm *vm);
 
-struct fsm_hip_dfa { struct fsm_dfavm *vm; };
+struct fsm_hip_dfa { struct fsm_dfavm *vm; const struct fsm *fsm; /* valid while the caller keeps it (re(1) does; retest does not) */ };
+
+struct span { const unsigned char *p, *e; };
+static int span_getc(void *o) { struct span *s = o; return s->p == s->e ? -1 : *s->p++; }
 
 static unsigned long n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs;
 
@@ -41,6 +47,7 @@ fsm_hip_compile(const struct fsm *fsm, unsigned flags)
 		return NULL;
 	}
 	d->vm = fsm_vm_compile(fsm);
+	d->fsm = fsm;
 	if (d->vm == NULL) {
 		free(d);
 		return NULL;
@@ -69,12 +76,16 @@ fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *d, const unsigned char *bas
 	uint32_t *end_out, uint64_t *accept_bitmap)
 {
 	size_t i;
-	(void) end_out;
 	n_batch++;
 	n_batch_inputs += n;
 	for (i = 0; i < n; i++) {
-		if (fsm_vm_match_buffer(d->vm, (const char *) base + off[i], (size_t) (off[i + 1] - off[i]))) {
+		if (accept_bitmap != NULL && fsm_vm_match_buffer(d->vm, (const char *) base + off[i], (size_t) (off[i + 1] - off[i]))) {
 			accept_bitmap[i / 64] |= (uint64_t) 1 << (i % 64);
+		}
+		if (end_out != NULL) {   /* the state fsm_exec returns (re -H: the caller's fsm is still alive) */
+			struct span sp = { base + off[i], base + off[i + 1] };
+			unsigned end = 0;
+			end_out[i] = fsm_exec(d->fsm, span_getc, &sp, &end, NULL) == 1 ? end : 0xFFFFFFFFu;
 		}
 	}
 	return 0;
@@ -94,4 +105,11 @@ fsm_hip_exec_batch(const struct fsm_hip_dfa *d, const unsigned char *base, size_
 		}
 	}
 	return 0;
+}
+
+int
+fsm_hip_match_file(const struct fsm_hip_dfa *d, FILE *f)
+{
+	n_single++;
+	return fsm_vm_match_file(d->vm, f);
 }

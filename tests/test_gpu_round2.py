@@ -614,6 +614,31 @@ def test_reperf_l_hip(hip, tmp_path):
     assert strip(bad.stdout) != strip(go("hip", reperf_scr_lines(5000)).stdout)
 
 
+def test_re_H(hip, tmp_path):
+    """The reference's re(1) with integration/re/hip_exec.patch (integration/_build/re): `re -H` matches all its text
+    arguments in one launch and files (-x) through fsm_hip_match_file; exit status and -z output equal plain `re`'s
+    for every case of tests/test_retest_patch.py::RE_CASES, plus a 3 MB file that needs the chunked walk."""
+    from test_retest_patch import RE_CASES
+    exe = os.path.join(ROOT, "integration", "_build", "re")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/re not built (needs /root/reference at build time)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for args, rc in RE_CASES:
+        ref = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=120)
+        got = subprocess.run([exe, "-H"] + args, capture_output=True, text=True, env=env, timeout=120)
+        assert ref.returncode == rc and got.returncode == rc, (args, got.stderr[-400:])
+        assert got.stdout == ref.stdout, args
+    f1, f2, f3 = tmp_path / "a.txt", tmp_path / "b.txt", tmp_path / "c.txt"
+    f1.write_bytes(b"a" + b"b" * 3_000_000 + b"c")
+    f2.write_bytes(b"a" + b"b" * 3_000_000 + b"d")
+    f3.write_bytes(b"")
+    for files in ([f1], [f2], [f1, f2], [f3]):
+        args = ["-r", "pcre", "-x", "^ab+c$", "--"] + [str(f) for f in files]
+        ref = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=120)
+        got = subprocess.run([exe, "-H"] + args, capture_output=True, text=True, env=env, timeout=120)
+        assert ref.returncode == got.returncode, (files, got.stderr[-300:])
+
+
 # ---------------------------------------------------------------------------
 # multi-device front (C ABI): one replica per device, one host thread per device
 # ---------------------------------------------------------------------------

@@ -23,6 +23,7 @@ def stub_dir(tmp_path_factory):
     if not os.path.isdir("/root/reference/src/retest") and not os.path.exists(EXE):
         pytest.skip("patched retest not built and no reference tree to build it from")
     sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
+    subprocess.run(["sh", os.path.join(ROOT, "integration", "re", "build.sh")], capture_output=True, text=True)
     if not os.path.exists(EXE):
         pytest.skip("integration/_build/retest not built: " + sh.stderr[-300:])
     d = tmp_path_factory.mktemp("stub")
@@ -137,3 +138,41 @@ def test_reperf_runs_go_out_as_batches_of_copies(stub_dir, tmp_path):
     strip = lambda t: [l for l in t.splitlines() if "iterations took" not in l]
     assert strip(out.stdout) == strip(ref.stdout) and out.returncode == ref.returncode     # the reference's VM reports the same failure
     assert "should not match" in (out.stdout + out.stderr).lower() or out.returncode != 0
+
+
+RE_CASES = [
+    (["-r", "pcre", "^ab+c$", "--", "abc", "abbc", "xyz", "ab", ""], 1),
+    (["-r", "pcre", "^ab+c$", "--", "abc", "abbbbbc"], 0),
+    (["-r", "pcre", "-z", "^ab+c$", "^x+$", "--", "abc", "xx"], 0),
+    (["-r", "pcre", "-z", "^ab+c$", "^x+$", "--", "abc", "xx", "q"], 1),
+    (["-r", "literal", "a.c", "--", "a.c"], 0),
+    (["-r", "glob", "-i", "*.TXT", "--", "notes.txt", "x.txt.bak"], 1),
+]
+
+
+def test_re_H_matches_all_arguments_in_one_call(stub_dir, tmp_path):
+    """re(1) with integration/re/hip_exec.patch: `re -H ... -- text...` answers like plain `re` (exit status, -z's
+    pattern lines) from ONE fsm_hip_exec_batch_offsets call over all the arguments; -x files go through
+    fsm_hip_match_file."""
+    exe = os.path.join(ROOT, "integration", "_build", "re")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/re not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)
+    for args, rc in RE_CASES:
+        ref = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=60)
+        got = subprocess.run([exe, "-H"] + args, capture_output=True, text=True, env=env, timeout=60)
+        assert ref.returncode == rc and got.returncode == rc, (args, ref.returncode, got.returncode, got.stderr[-300:])
+        assert got.stdout == ref.stdout, args
+        ntext = len(args) - args.index("--") - 1
+        assert "stub_fsm_hip: compile=1 batch_calls=1 batch_inputs=%d single_calls=0" % ntext in got.stderr, got.stderr[-300:]
+    f1, f2 = tmp_path / "a.txt", tmp_path / "b.txt"
+    f1.write_bytes(b"abbbc")
+    f2.write_bytes(b"abd" * 50000)
+    for files, rc in (([f1], 0), ([f1, f2], 1)):
+        args = ["-r", "pcre", "-x", "^ab+c$", "--"] + [str(f) for f in files]
+        ref = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=60)
+        got = subprocess.run([exe, "-H"] + args, capture_output=True, text=True, env=env, timeout=60)
+        assert ref.returncode == rc == got.returncode
+        assert "single_calls=%d" % len(files) in got.stderr
+    bad = subprocess.run([exe, "-H", "-M", "-r", "pcre", "a", "--", "a"], capture_output=True, text=True, env=env)
+    assert bad.returncode != 0 and "-H cannot be used" in bad.stderr
