@@ -113,3 +113,10 @@ fsm_hip_match_file(const struct fsm_hip_dfa *d, FILE *f)
 	n_single++;
 	return fsm_vm_match_file(d->vm, f);
 }
+
+int
+fsm_hip_exec(const struct fsm_hip_dfa *d, int (*fsm_getc)(void *opaque), void *opaque, unsigned *end, struct fsm_capture *captures)
+{
+	n_single++;
+	return fsm_exec(d->fsm, fsm_getc, opaque, end, captures);
+}

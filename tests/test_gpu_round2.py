@@ -614,6 +614,30 @@ def test_reperf_l_hip(hip, tmp_path):
     assert strip(bad.stdout) != strip(go("hip", reperf_scr_lines(5000)).stdout)
 
 
+def test_reference_test_programs_on_the_hip_path(hip):
+    """SURVEY section 8(b), "reference C tests re-linked against the shim": the reference's own tests/endids/*.c (16) and
+    tests/re_strings/*.c (4), compiled where they lie with fsm_exec() routed to fsm_hip_compile + fsm_hip_exec
+    (integration/reftests).  Their own assert()s -- accept / reject, end-id sets after union / determinise / minimise /
+    trim, per-word ids of the Aho-Corasick builds -- all hold with the GPU doing the matching: exit status 0, every
+    call on the HIP path, none falling back."""
+    import re as _re
+    from test_retest_patch import reference_test_programs
+    progs = reference_test_programs()
+    if len(progs) != 20:
+        pytest.skip("integration/_build/reftests not built (needs /root/reference at build time)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    total = 0
+    for exe in progs:
+        out = subprocess.run([exe], capture_output=True, text=True, errors="replace", env=env, timeout=600)
+        assert out.returncode == 0, (os.path.basename(exe), out.stdout[-400:], out.stderr[-400:])
+        m = _re.search(r"exec_via_hip: (\d+) fsm_exec calls answered by the HIP path, (\d+) fallbacks", out.stderr)
+        if m is None:          # a program that builds and inspects automata without executing them (endids6)
+            continue
+        assert int(m.group(1)) > 0 and int(m.group(2)) == 0, (os.path.basename(exe), out.stderr[-300:])
+        total += int(m.group(1))
+    assert total > 300
+
+
 def test_re_H(hip, tmp_path):
     """The reference's re(1) with integration/re/hip_exec.patch (integration/_build/re): `re -H` matches all its text
     arguments in one launch and files (-x) through fsm_hip_match_file; exit status and -z output equal plain `re`'s

@@ -24,6 +24,7 @@ def stub_dir(tmp_path_factory):
         pytest.skip("patched retest not built and no reference tree to build it from")
     sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
     subprocess.run(["sh", os.path.join(ROOT, "integration", "re", "build.sh")], capture_output=True, text=True)
+    subprocess.run(["sh", os.path.join(ROOT, "integration", "reftests", "build.sh")], capture_output=True, text=True)
     if not os.path.exists(EXE):
         pytest.skip("integration/_build/retest not built: " + sh.stderr[-300:])
     d = tmp_path_factory.mktemp("stub")
@@ -176,3 +177,28 @@ def test_re_H_matches_all_arguments_in_one_call(stub_dir, tmp_path):
         assert "single_calls=%d" % len(files) in got.stderr
     bad = subprocess.run([exe, "-H", "-M", "-r", "pcre", "a", "--", "a"], capture_output=True, text=True, env=env)
     assert bad.returncode != 0 and "-H cannot be used" in bad.stderr
+
+
+def reference_test_programs():
+    d = os.path.join(ROOT, "integration", "_build", "reftests")
+    return sorted(os.path.join(d, f) for f in os.listdir(d)) if os.path.isdir(d) else []
+
+
+def test_reference_test_programs_route_fsm_exec(stub_dir):
+    """integration/reftests: the reference's tests/endids (16) and tests/re_strings (4) programs, every fsm_exec() call
+    routed through exec_via_hip.c.  Against the stand-in library this checks the harness only: all 20 exit 0 and report
+    their calls as taken by the HIP entry points, none falling back."""
+    progs = reference_test_programs()
+    if len(progs) != 20:
+        pytest.skip("integration/_build/reftests not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)
+    total = 0
+    for exe in progs:
+        out = subprocess.run([exe], capture_output=True, text=True, errors="replace", env=env, timeout=300)
+        assert out.returncode == 0, (os.path.basename(exe), out.stdout[-300:], out.stderr[-300:])
+        m = re.search(r"exec_via_hip: (\d+) fsm_exec calls answered by the HIP path, (\d+) fallbacks", out.stderr)
+        if m is None:          # a program that builds and inspects automata without executing them (endids6)
+            continue
+        assert int(m.group(1)) > 0 and int(m.group(2)) == 0, (os.path.basename(exe), out.stderr[-300:])
+        total += int(m.group(1))
+    assert total > 300
