@@ -120,3 +120,15 @@ fsm_hip_exec(const struct fsm_hip_dfa *d, int (*fsm_getc)(void *opaque), void *o
 	n_single++;
 	return fsm_exec(d->fsm, fsm_getc, opaque, end, captures);
 }
+
+/* the stand-in has no eager front: exec_via_hip.c then takes the plain path */
+size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *d) { (void) d; return 0; }
+size_t fsm_hip_eager_words(const struct fsm_hip_dfa *d) { (void) d; return 1; }
+uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *d, unsigned bit) { (void) d; (void) bit; return 0xFFFFFFFFu; }
+int
+fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *eager_out)
+{
+	(void) d; (void) base; (void) stride; (void) len; (void) n; (void) end_out; (void) eager_out;
+	return -1;
+}

@@ -615,27 +615,32 @@ def test_reperf_l_hip(hip, tmp_path):
 
 
 def test_reference_test_programs_on_the_hip_path(hip):
-    """SURVEY section 8(b), "reference C tests re-linked against the shim": the reference's own tests/endids/*.c (16) and
-    tests/re_strings/*.c (4), compiled where they lie with fsm_exec() routed to fsm_hip_compile + fsm_hip_exec
-    (integration/reftests).  Their own assert()s -- accept / reject, end-id sets after union / determinise / minimise /
-    trim, per-word ids of the Aho-Corasick builds -- all hold with the GPU doing the matching: exit status 0, every
-    call on the HIP path, none falling back."""
+    """SURVEY section 8(b), "reference C tests re-linked against the shim": the reference's own tests/endids/*.c (16),
+    tests/re_strings/*.c (4) and tests/eager_output/*.c (22), compiled where they lie with fsm_exec() routed to
+    fsm_hip_compile + fsm_hip_exec -- or, for an automaton with an eager-output callback, fsm_hip_exec_batch_eager and
+    one callback call per id of the returned set (integration/reftests).  Their own assert()s -- accept / reject,
+    end-id sets after union / determinise / minimise / trim, per-word ids of the Aho-Corasick builds, eager ids of
+    anchored / unanchored pattern unions -- all hold with the GPU doing the matching: exit status 0, every call on the
+    HIP path, none falling back."""
     import re as _re
     from test_retest_patch import reference_test_programs
     progs = reference_test_programs()
-    if len(progs) != 20:
+    if len(progs) != 42:
         pytest.skip("integration/_build/reftests not built (needs /root/reference at build time)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    total = 0
+    total = eager = 0
     for exe in progs:
         out = subprocess.run([exe], capture_output=True, text=True, errors="replace", env=env, timeout=600)
         assert out.returncode == 0, (os.path.basename(exe), out.stdout[-400:], out.stderr[-400:])
-        m = _re.search(r"exec_via_hip: (\d+) fsm_exec calls answered by the HIP path, (\d+) fallbacks", out.stderr)
+        m = _re.search(r"exec_via_hip: (\d+) fsm_exec calls answered by the HIP path, (\d+) fallbacks \((\d+) with eager", out.stderr)
         if m is None:          # a program that builds and inspects automata without executing them (endids6)
             continue
         assert int(m.group(1)) > 0 and int(m.group(2)) == 0, (os.path.basename(exe), out.stderr[-300:])
+        # (an eager_output program whose patterns are all anchored carries its ids as end-ids: no eager call)
+        assert int(m.group(3)) == 0 or os.path.basename(exe).startswith("eager_"), (os.path.basename(exe), out.stderr[-300:])
         total += int(m.group(1))
-    assert total > 300
+        eager += int(m.group(3))
+    assert total > 700 and eager > 50
 
 
 def test_re_H(hip, tmp_path):
