@@ -668,6 +668,30 @@ def test_re_H(hip, tmp_path):
         assert ref.returncode == got.returncode, (files, got.stderr[-300:])
 
 
+def test_fsm_H(hip, tmp_path):
+    """The reference's fsm(1) with integration/fsm/hip_exec.patch: `fsm -H file.fsm text...` exits like plain `fsm`
+    (tests/test_retest_patch.py::FSM_CASES), -x reads a file through fsm_hip_match_file, an NFA is refused (EINVAL)."""
+    from test_retest_patch import FSM_CASES, FSM_DFA, FSM_NFA
+    exe = os.path.join(ROOT, "integration", "_build", "fsm")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/fsm not built (needs /root/reference at build time)")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    dfa, nfa, txt = tmp_path / "d.fsm", tmp_path / "n.fsm", tmp_path / "t.txt"
+    dfa.write_text(FSM_DFA)
+    nfa.write_text(FSM_NFA)
+    txt.write_bytes(b"a" + b"b" * 200_000 + b"cc")
+    for texts, rc in FSM_CASES:
+        ref = subprocess.run([exe, str(dfa)] + texts, capture_output=True, text=True, env=env, timeout=120)
+        got = subprocess.run([exe, "-H", str(dfa)] + texts, capture_output=True, text=True, env=env, timeout=120)
+        assert ref.returncode == rc == got.returncode and got.stdout == ref.stdout, (texts, got.stderr[-300:])
+    # -x: fsm(1) takes its first remaining argument as the file to read (main.c:741)
+    ref = subprocess.run([exe, "-x", str(dfa), str(txt)], capture_output=True, text=True, env=env, timeout=120)
+    got = subprocess.run([exe, "-x", "-H", str(dfa), str(txt)], capture_output=True, text=True, env=env, timeout=120)
+    assert ref.returncode == got.returncode == 0, got.stderr[-300:]
+    got = subprocess.run([exe, "-H", str(nfa), "a"], capture_output=True, text=True, env=env, timeout=120)
+    assert got.returncode != 0 and "fsm_hip_compile: Invalid argument" in got.stderr
+
+
 # ---------------------------------------------------------------------------
 # multi-device front (C ABI): one replica per device, one host thread per device
 # ---------------------------------------------------------------------------

@@ -25,6 +25,7 @@ def stub_dir(tmp_path_factory):
     sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
     subprocess.run(["sh", os.path.join(ROOT, "integration", "re", "build.sh")], capture_output=True, text=True)
     subprocess.run(["sh", os.path.join(ROOT, "integration", "reftests", "build.sh")], capture_output=True, text=True)
+    subprocess.run(["sh", os.path.join(ROOT, "integration", "fsm", "build.sh")], capture_output=True, text=True)
     if not os.path.exists(EXE):
         pytest.skip("integration/_build/retest not built: " + sh.stderr[-300:])
     d = tmp_path_factory.mktemp("stub")
@@ -203,3 +204,29 @@ def test_reference_test_programs_route_fsm_exec(stub_dir):
         assert int(m.group(1)) > 0 and int(m.group(2)) == 0, (os.path.basename(exe), out.stderr[-300:])
         total += int(m.group(1))
     assert total > 300
+
+
+FSM_DFA = '0 -> 1 "a";\n1 -> 1 "b";\n1 -> 2 "c";\n2 -> 2 "c";\nstart: 0;\nend: 2;\n'
+FSM_NFA = '0 -> 1 "a";\n0 -> 2 "a";\nstart: 0;\nend: 2;\n'
+FSM_CASES = [(["abc", "abbcc"], 0), (["abc", "abd"], 1), (["", "a"], 1), ([], 0)]
+
+
+def test_fsm_H_matches_all_arguments_in_one_call(stub_dir, tmp_path):
+    """fsm(1) with integration/fsm/hip_exec.patch: `fsm -H file.fsm text...` answers like plain `fsm` from one
+    fsm_hip_exec_batch_offsets call; an NFA is refused where fsm_exec refuses it."""
+    exe = os.path.join(ROOT, "integration", "_build", "fsm")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/fsm not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)
+    dfa, nfa = tmp_path / "d.fsm", tmp_path / "n.fsm"
+    dfa.write_text(FSM_DFA)
+    nfa.write_text(FSM_NFA)
+    for texts, rc in FSM_CASES:
+        ref = subprocess.run([exe, str(dfa)] + texts, capture_output=True, text=True, env=env, timeout=60)
+        got = subprocess.run([exe, "-H", str(dfa)] + texts, capture_output=True, text=True, env=env, timeout=60)
+        assert ref.returncode == rc == got.returncode and got.stdout == ref.stdout, (texts, got.stderr[-300:])
+        if texts:
+            assert "compile=1 batch_calls=1 batch_inputs=%d single_calls=0" % len(texts) in got.stderr
+    ref = subprocess.run([exe, str(nfa), "a"], capture_output=True, text=True, env=env, timeout=60)
+    got = subprocess.run([exe, "-H", str(nfa), "a"], capture_output=True, text=True, env=env, timeout=60)
+    assert ref.returncode != 0 and got.returncode != 0 and "fsm_hip_compile" in got.stderr
