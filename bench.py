@@ -522,7 +522,7 @@ def main():
         }
         if wl == "c5":
             res["roofline"]["note"] = ("this walk is bound by the instructions of its divergent chain loop, not by HBM (DESIGN.md section 3; "
-                                       "profiles/r02n_c5_rocprof_summary.json: 0.33 L2 requests per input byte, 93.8 % hits, calibrated HBM traffic "
+                                       "profiles/r03j_c5_rocprof_summary.json: 0.33 L2 requests per input byte, 93.8 % hits, calibrated HBM traffic "
                                        "1.81x algorithmic): the fraction of HBM peak is reported for uniformity only")
         if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
             sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if wl == "c2" else 100_000)
