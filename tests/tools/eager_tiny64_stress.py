@@ -78,15 +78,35 @@ def run_packed(reps, out=print):
     from common import GOLDEN, Golden
     from oracle.pyoracle import Oracle
     hip.load_library()
+    from common import eager_golden_paths
     total = bad_total = 0
-    for name, alpha in (("c1.npz", b"Llibfsmx\0"), ("c3.npz", b"abcdwxyz0123456789")):
-        g = Golden(os.path.join(GOLDEN, name))
+    sources = [("c1.npz", b"Llibfsmx\0", None), ("c3.npz", b"abcdwxyz0123456789", None)]
+    # 7..16-state automata (64-bit transition columns: TinyPol<u64>, whose step is inline asm) under ragged lengths
+    for path in eager_golden_paths():
+        g = Golden(path)
+        if 7 <= g.flat.nstates + 1 <= 16 and len(sources) < 8:
+            sources.append((os.path.basename(path), (" ".join(g.meta["patterns"]) + " xyz").encode("latin1"), g))
+    for name, alpha, gg in sources:
+        g = gg if gg is not None else Golden(os.path.join(GOLDEN, name))
         o = Oracle(g.flat)
         rng = np.random.RandomState(len(alpha))
         a = np.frombuffer(alpha, np.uint8)
         pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n") if name == "c3.npz" else None
 
+        lits = None
+        if gg is not None:
+            lits = [p.encode("latin1").strip(b"^$") for p in gg.meta["patterns"]]
+            lits = [p for p in lits if 0 < len(p) <= 60 and not any(c in p for c in b"[]()*+?|\\.")]
+
         def one(k):
+            if lits and k >= 8 and rng.randint(3) == 0:
+                s = bytearray(a[rng.randint(0, len(a), max(k, 64))])
+                p = lits[rng.randint(len(lits))]
+                at = rng.randint(0, len(s) - len(p) + 1)
+                s[at:at + len(p)] = p
+                return bytes(s)
+            if gg is not None:
+                return bytes(a[rng.randint(0, len(a), k)])
             if k >= 8 and rng.randint(3) == 0:
                 if pats is None:
                     s = bytearray(a[rng.randint(0, len(a), k)])
