@@ -607,7 +607,7 @@ def main():
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--node-front", "--workload", a.workload, "--steps", str(a.steps),
                    "--warmup", str(a.warmup), "--len", str(L)]
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)   # never run on real multi-GPU hardware yet: bounded
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             res["node_front"] = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
         except Exception as e:  # noqa: BLE001
