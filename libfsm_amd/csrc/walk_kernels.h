@@ -124,14 +124,7 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &w, int k)
 
 template <class W>
 struct TinyPol {
-	/* No chunk-level form (EagerPol::walk16) over this policy.  One build of walk_ragged<EagerPol<TinyPol<u64>>>
-	 * -- chunk-level walk + results held back one iteration -- gave an intermittent wrong end state / id set
-	 * for a single input (~3 % of launches, only in the second wavefront of a SIMD, never with <= 4 wavefronts
-	 * per workgroup).  A full s_waitcnt 0 + wave barrier in front of the tile reads did not cure it and neither
-	 * did wait states around the 64-bit shift below, so it is not the input path; without walk16, or with the
-	 * results written at once, 0 of 2700 launches failed (tests/tools/eager_tiny64_stress.py, the probes under
-	 * tools/probes/).  Root cause not found: both suspects are avoided and the stress run is part of the GPU suite. */
-	static constexpr bool heavy_next = true;
+	static constexpr bool heavy_next = false;
 	static_assert(sizeof(W) == 8, "16 states x 4 bits per column");
 	typedef W P;
 	typedef uint32_t S;   /* carried unmasked: only bits 3:0 are the state (see next) */
@@ -161,14 +154,18 @@ struct TinyPol {
 	}
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const
 	{
-		/* One 64-bit shift.  Its destination must not overlap its sources: the compiler's own
-		 * allocation of v_lshrrev_b64 did, and ~45 % of 16-wave launches then returned wrong
-		 * states (tests/test_gpu_parity.py::test_sixteen_state_columns_under_full_occupancy) --
-		 * hence inline asm with an early-clobber output.  The shift uses bits 5:0 of its amount,
-		 * so the state is carried unmasked (code() masks it): 2 operations per byte. */
-		uint64_t t;
+		/* One 64-bit shift; it uses bits 5:0 of its amount, so the state is carried unmasked (code() masks it):
+		 * 2 operations per byte.
+		 * History of this line.  Round 1 saw wrong states in ~45 % of 16-wavefront launches, blamed the compiler's
+		 * register allocation (destination overlapping the shift-amount register) and replaced the C++ shift by an
+		 * inline-asm v_lshrrev_b64 with an early-clobber destination.  Round 2 found that asm form returning a wrong
+		 * state in ~3 % of launches of one build of walk_ragged<EagerPol<TinyPol>> (only with a lane-divergent branch
+		 * around it, only in the second wavefront of a SIMD), while the SAME build with the C++ shift below passed --
+		 * with its destination overlapping the shift amount in 875 of 1 360 instances -- as did round 1's reproducer
+		 * and 91 000 stress launches.  An inline-asm VALU instruction is opaque to the compiler
+		 * (no hazard model, no EXEC dependence); the plain shift is not.  The asm is gone. */
 		const uint32_t sh = st << 2;
-		asm volatile("v_lshrrev_b64 %0, %1, %2" : "=&v"(t) : "v"(sh), "v"((uint64_t)v));
+		const uint64_t t = (uint64_t)v >> (sh & 63u);
 		return (uint32_t)t;
 	}
 };
@@ -1325,7 +1322,7 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
  * Results are written per lane when its input ends.  (Holding them back one iteration, so that the stores
  * go out right after the wait for the tile, measured no faster -- profiles/r02t_ragged_variants.txt -- and
  * that build of walk_ragged<EagerPol<TinyPol<u64>>> returned a wrong result in ~3 % of launches with two
- * wavefronts per SIMD: see the note at TinyPol::heavy_next.)
+ * wavefronts per SIMD: see the note in TinyPol::next.)
  */
 template <class Pol, int MAXT>
 __global__ void __launch_bounds__(MAXT)

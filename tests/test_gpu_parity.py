@@ -279,10 +279,10 @@ def test_shim_compile_vs_reference_fsm_exec(hip, dialect, regex, flags):
 
 
 def test_sixteen_state_columns_under_full_occupancy(hip):
-    """Regression: 9..16-state DFAs use 64-bit transition columns.  A v_lshrrev_b64 whose
-    destination overlapped its shift-amount register gave wrong states in ~45 % of launches with
-    16 waves per workgroup (never with 4).  The shift is now inline asm with an early-clobber destination, so
-    no overlap is possible; this test is what would notice if that were not the whole story."""
+    """Regression: 9..16-state DFAs use 64-bit transition columns.  Round 1 saw wrong states here in ~45 % of launches with
+    16 waves per workgroup (never with 4) and swapped the C++ 64-bit shift for inline asm; round 2 found the asm form failing
+    elsewhere and the C++ form passing this and everything else (walk_kernels.h, TinyPol::next; DESIGN.md section 4).  The
+    test stays as the tripwire for that line."""
     _need_ref()
     from oracle.pyoracle import RefFsm
     f = RefFsm.re_comp("glob", b"foo*bar?", 0, True, True, endid=5)

@@ -91,7 +91,7 @@ def test_eager_outputs_fast_kernels_golden_dfas(hip):
 def test_eager_64bit_columns_repeated_launches(hip):
     """Regression / tripwire: eager walks of the 7..16-state goldens in the TINY layout, every input mode at
     4 / 8 / 12 wavefronts, 40 launches each on two alternating row sets (so a stale result is a wrong one).
-    One build of the ragged kernel failed ~3 % of these launches (walk_kernels.h, note at TinyPol::heavy_next);
+    One build of the ragged kernel failed ~3 % of these launches (walk_kernels.h, note in TinyPol::next);
     the single launch per configuration of the test above would mostly miss that."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import eager_tiny64_stress

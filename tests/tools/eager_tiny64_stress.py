@@ -3,7 +3,7 @@
 (64-bit transition columns, TinyPol<u64>) in the TINY layout, every input mode, 4 / 8 / 12 wavefronts per workgroup.
 
 Two row sets alternate, so a result left over from the previous launch is a wrong one.  One build of the ragged
-kernel gave an intermittent wrong result here (walk_kernels.h, note at TinyPol::heavy_next): this is the run that
+kernel gave an intermittent wrong result here (walk_kernels.h, note in TinyPol::next): this is the run that
 showed it (61-86 bad launches of 2700) and that the shipped kernels pass.  REPS = launches per configuration.
 Prints one line per (mode, waves) and exits non-zero if any launch was wrong."""
 import os
