@@ -1100,7 +1100,9 @@ walk_ldsdma(const WalkArgs a)
 	pol.setup(lds, a);
 	__syncthreads();
 
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	/* the wavefront's index as a SCALAR: everything derived from it (tile slot, input range, ring cursors) is then
+	 * wave-uniform to the compiler too and lives in SGPRs / on the scalar unit */
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
 	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * TILE;
 	const uint64_t ntiles = (a.n + 63u) / 64u;
 	const uint32_t nseg = (uint32_t)(a.stride / SEG); /* host guarantees stride % SEG == 0 */
@@ -1334,7 +1336,9 @@ walk_ragged(const WalkArgs a)
 	pol.setup(lds, a);
 	__syncthreads();
 
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	/* the wavefront's index as a SCALAR: everything derived from it (tile slot, input range, ring cursors) is then
+	 * wave-uniform to the compiler too and lives in SGPRs / on the scalar unit */
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
 	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * FSMHIP_RAGGED_WAVE_LDS;
 	uint64_t *ring = reinterpret_cast<uint64_t *>(stg + 8192u);   /* [RING][2]: byte offset, length */
 	unsigned char *rows = stg + 8192u + RING * 16u;               /* [64] row records for the loaders */
