@@ -18,7 +18,9 @@ extern "C" {
 
 enum {
 	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles (both: uniform 16-byte-aligned rows only),
-	                                  * 2 generic (per-lane loads, any input), 3 ragged (coalesced + lane refill, any input); -1 auto */
+	                                  * 2 generic (per-lane loads, any input), 3 ragged (coalesced + lane refill, any input),
+	                                  * 4 packed (packed offsets only: a lane owns a byte range and walks across input
+	                                  * boundaries; other fronts take their auto choice); -1 auto */
 	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
 	FSM_HIP_KNOB_ROWS          = 3,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
@@ -30,6 +32,11 @@ enum {
 	FSM_HIP_KNOB_PREFETCH      = 10, /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
 	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
 	FSM_HIP_KNOB_NOSKIP        = 13, /* 1: self-loop layouts never skip a whole chunk (measurement aid: every byte pays its test) */
+	FSM_HIP_KNOB_PK_RMIN       = 16, /* packed mode: log2 of the smallest row (bytes a lane owns), 7..10, default 7   */
+	FSM_HIP_KNOB_PK_RMAX       = 17, /* packed mode: log2 of the largest row, 7..10; 0 (default) = what LDS allows     */
+	FSM_HIP_KNOB_PK_MEAN_MAX   = 18, /* auto: batches whose mean input length exceeds this go to the ragged kernel   */
+	FSM_HIP_KNOB_PK_DEBUG      = 19, /* measurement aid: bit mask of walk_packed parts switched off (results are WRONG):
+	                                  * 1 result stores, 4 input loads, 8 mask building, 16 packed_finish (raw state codes stay) */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };

@@ -19,6 +19,7 @@
 #include "plan.h"
 #include "launch.h"
 #include "gen_kernels.h"
+#include "walk_packed_aux.h"
 
 using namespace fsmhip;
 
@@ -45,6 +46,15 @@ struct fsm_hip_dfa {
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	uint32_t *d_ew_off = nullptr, *d_ew_word = nullptr; /* wide eager sets (> 64 ids) */
 	uint64_t *d_ew_mask = nullptr;
+	/* device scratch of the packed front (parameters, first[], kbits, state codes): one grow-only block per dfa.  Calls are
+	 * enqueued under the dfa's lock; a call on another stream than the block's last user first waits for that user's
+	 * event, so the block is never shared by two launches in flight */
+	unsigned char *pk_scratch = nullptr;
+	size_t pk_scratch_bytes = 0;
+	hipStream_t pk_scratch_stream = nullptr;
+	hipEvent_t pk_scratch_ev = nullptr;
+	bool pk_scratch_busy = false;
+	std::vector<void *> pk_scratch_old;              /* outgrown blocks: freed with the dfa */
 	unsigned char *arena = nullptr;                  /* device scratch of the host-pointer front */
 	size_t arena_bytes = 0;
 	unsigned char *stage = nullptr;                  /* pinned host staging for small calls */
@@ -69,8 +79,10 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
-	bool hint_short = false;     /* set by a host-pointer front for the duration of its call: inputs average < 96 bytes
-	                              * (or the batch is big enough to hold an input of 2^36 bytes): take walk_generic */
+	int knob_pk_rmin = 7;        /* packed front: smallest row, log2 bytes */
+	int knob_pk_rmax = 0;        /* ... largest row, log2 bytes (<= 10); 0 = what leaves room for a full workgroup */
+	int knob_pk_debug = 0;       /* measurement aid: parts of walk_packed switched off (results are wrong) */
+	int knob_pk_mean_max = 192;  /* ... longest mean input length (bytes) walk_packed takes; longer: walk_ragged */
 	unsigned flags = 0;
 };
 
@@ -404,6 +416,9 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_ew_off) (void)hipFree(d->d_ew_off);
 	if (d->d_ew_word) (void)hipFree(d->d_ew_word);
 	if (d->d_ew_mask) (void)hipFree(d->d_ew_mask);
+	if (d->pk_scratch) (void)hipFree(d->pk_scratch);
+	for (void *q : d->pk_scratch_old) (void)hipFree(q);
+	if (d->pk_scratch_ev) (void)hipEventDestroy(d->pk_scratch_ev);
 	if (d->arena) (void)hipFree(d->arena);
 	if (d->stage) (void)hipHostFree(d->stage);
 	if (d->hs) (void)hipStreamDestroy(d->hs);
@@ -416,7 +431,10 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* launch                                                             */
 /* ------------------------------------------------------------------ */
 
-static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager)
+/* per_lane: take walk_generic unless a knob says otherwise -- the batch may hold an input the ragged kernel's 32-bit
+ * piece count cannot (>= 2^36 bytes), or it is fixed stride + lengths averaging < 96 bytes (walk_ragged works in
+ * 128-byte segments: 0.7 vs 1.1-1.3 TB/s at 8-64 bytes).  Short PACKED inputs never get here: walk_packed takes them. */
+static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false)
 {
 	LaunchCfg c;
 	const uint32_t layout = d->plan.layout;
@@ -431,10 +449,9 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* ragged / packed / unaligned inputs: the coalesced, lane-refilling kernel whenever at least four
 	 * waves' tiles and rings fit next to the table, else per-lane loads (walk_generic) */
 	const bool ragged_fits = d->table_lds + 4u * FSMHIP_RAGGED_WAVE_LDS <= d->lds_limit;
-	/* (the refill works in 128-byte segments: inputs much shorter than that leave most of every tile unused,
-	 * and per-lane loads win -- measured 1.5 vs 0.8 TB/s at 8-64 bytes; the host fronts know the average) */
-	int mode = ragged_fits && !d->hint_short ? IN_RAGGED : IN_GENERIC;
-	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits)) mode = d->knob_input_mode;
+	/* (short packed inputs never get here: walk_packed takes them, see launch_walk) */
+	int mode = ragged_fits && !per_lane && !huge ? IN_RAGGED : IN_GENERIC;
+	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits && !huge)) mode = d->knob_input_mode;
 	else if (fast_ok) {
 		/* measured (profiles/r01_sweep*.txt): LDS-DMA staging (8 KiB tile per wave) is the better input
 		 * path whenever at least 12 waves of tiles fit next to the table (lds layout 5.1 vs 4.8 TB/s;
@@ -490,38 +507,180 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	return c;
 }
 
-static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s)
+/* what a front knows about its batch beyond the arguments (host fronts: everything; device fronts: nothing) */
+struct BatchHint {
+	uint64_t bytes = 0;        /* total input bytes, 0 = unknown */
+	bool short_mean = false;   /* fixed stride + lengths averaging < 96 bytes */
+};
+
+/* the packed front's walk_packed: rows as long as the per-wave LDS bitmask may be with a full 16-wave workgroup behind
+ * one table copy */
+static bool packed_cfg(const fsm_hip_dfa *d, LaunchCfg &c, uint32_t &rmax)
+{
+	const uint32_t layout = d->plan.layout;
+	const bool c16 = !(layout == FSM_HIP_LAYOUT_GLOBAL || layout == FSM_HIP_LAYOUT_SPARSE);
+	const int wmax = 16;   /* launch.h packed_threads */
+	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
+	const uint32_t room = d->lds_limit > d->table_lds ? d->lds_limit - d->table_lds : 0u;
+	rmax = 9;
+	if (d->knob_pk_rmax >= 7 && d->knob_pk_rmax <= (int)FSMHIP_PK_RMAX) rmax = (uint32_t)d->knob_pk_rmax;
+	else while (rmax > 7u && (uint32_t)waves * packed_wave_lds(rmax, c16) > room) rmax--;
+	if ((uint32_t)d->knob_pk_rmin > rmax) rmax = (uint32_t)d->knob_pk_rmin <= FSMHIP_PK_RMAX ? (uint32_t)d->knob_pk_rmin : FSMHIP_PK_RMAX;
+	while (waves > 1 && (uint32_t)waves * packed_wave_lds(rmax, c16) > room) waves--;
+	if ((uint32_t)waves * packed_wave_lds(rmax, c16) > room) return false;
+	memset(&c, 0, sizeof c);
+	c.mode = IN_PACKED;
+	c.waves = waves;
+	c.lds = d->table_lds + (uint32_t)waves * packed_wave_lds(rmax, c16);
+	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
+	if (bpc * waves > 32) bpc = 32 / waves;
+	if (bpc < 1) bpc = 1;
+	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
+	c.blocks_per_cu = bpc;
+	return true;
+}
+
+static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
+{
+	const Plan &p = d->plan;
+	switch (p.layout) {
+	case FSM_HIP_LAYOUT_TINY:     return launch_tiny(p.tiny5_col.empty() ? POL_TINY64 : POL_TINY5, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_LDS:      return launch_lds(POL_LDS, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_LDSSELF:  return launch_lds(POL_LDSSELF, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_COMB:     return launch_comb(POL_COMB, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_COMB256:  return launch_comb(POL_COMB256, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_COMBSELF: return launch_comb(POL_COMBSELF, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_SPARSE:   return launch_glob(POL_SPARSE, eager, c, a, grid, block, s);
+	default:                      return launch_glob(POL_GLOB, eager, c, a, grid, block, s);
+	}
+}
+
+/* FSM_HIP_DEBUG=2: synchronise after every stage of a launch and say which one it was (a GPU fault aborts the process) */
+static void debug_stage(hipStream_t s, const char *what)
+{
+	static const int lvl = getenv("FSM_HIP_DEBUG") ? atoi(getenv("FSM_HIP_DEBUG")) : 0;
+	if (lvl < 2) return;
+	fprintf(stderr, "fsm_hip: %s ...", what);
+	fflush(stderr);
+	const hipError_t e = hipStreamSynchronize(s);
+	fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+	fflush(stderr);
+}
+
+static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream_t s, const BatchHint &hint = BatchHint())
 {
 	if (a.n == 0) return 0;
 	const int eager = a.eager_out == nullptr ? 0 : a.eager_words > 1 ? 2 : 1;
-	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager);
+	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : a.off == nullptr ? (uint64_t)a.n * a.stride : 0;
+	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36));
 	const uint64_t ntiles = (a.n + 63u) / 64u;
 	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	if (d->knob_noskip > 0) a.early |= 4u;
+
+	/* Packed offsets (the retest / rx front), plain walk: walk_packed next to the ragged / generic kernel.  Which of the two
+	 * takes the batch is decided ON THE DEVICE from the mean input length (packed_first, walk_packed.h): a device-pointer
+	 * front cannot know off[n] without a synchronising copy.  The other kernel returns at once. */
+	LaunchCfg pc;
+	uint32_t pk_rmax = 0;
+	const bool packed = a.off != nullptr && eager == 0 && a.state_io == nullptr && a.n < 0xFFFFF000ull &&
+		(d->knob_input_mode < 0 || d->knob_input_mode == IN_PACKED) && packed_cfg(d, pc, pk_rmax);
+	const bool both = packed;   /* (IN_PACKED forced: any mean length goes to walk_packed, but packed_first may still refuse a batch whose rows first[] cannot hold) */
+	uint32_t *scratch = nullptr;
+
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
-	DfaLock lk(md->mu);   /* the timing events are per dfa */
+	DfaLock lk(md->mu);   /* the timing events and the packed front's scratch block are per dfa */
 	hipError_t e = hipSuccess;
+	if (packed) {
+		/* scratch (the dfa's own block, see pk_scratch): parameters, first[] (one entry per
+		 * row: rows are at least 128 bytes), the bitmap of empty inputs, and the raw state codes when the caller wants
+		 * neither end states nor ids (they are mapped in place otherwise) */
+		uint64_t nvmax = 2u * a.n < 4096u ? 4096u : 2u * a.n > ((uint64_t)1 << 23) ? ((uint64_t)1 << 23) : 2u * a.n;
+		if (known_bytes != 0 && (known_bytes >> 7) + 2u < nvmax) nvmax = (known_bytes >> 7) + 2u;
+		const size_t head = ((size_t)FSMHIP_PK_FIRST_OFF + nvmax + 2u + 3u) & ~(size_t)3u, kwords = (a.n >> 6) + 1u;
+		const bool own_codes = a.end_out == nullptr && a.out2 == nullptr;
+		const size_t want = (head + 2u * kwords + (own_codes ? a.n : 0)) * sizeof(uint32_t);
+		if (md->pk_scratch_ev == nullptr) e = hipEventCreateWithFlags(&md->pk_scratch_ev, hipEventDisableTiming);
+		if (e == hipSuccess && md->pk_scratch_busy && md->pk_scratch_stream != s) e = hipStreamWaitEvent(s, md->pk_scratch_ev, 0);
+		if (e == hipSuccess && want > md->pk_scratch_bytes) {
+			if (md->pk_scratch) md->pk_scratch_old.push_back(md->pk_scratch);   /* launches in flight may still use it */
+			md->pk_scratch = nullptr;
+			md->pk_scratch_bytes = 0;
+			size_t cap = (size_t)1 << 16;
+			while (cap < want) cap *= 2;
+			e = hipMalloc((void **)&md->pk_scratch, cap);
+			if (e == hipSuccess) md->pk_scratch_bytes = cap;
+		}
+		scratch = reinterpret_cast<uint32_t *>(md->pk_scratch);
+		if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, sizeof(PackedParams), s);
+		a.pk = scratch;
+		a.pk_kbits = reinterpret_cast<uint64_t *>(scratch + head);
+		a.pk_codes = a.end_out != nullptr ? a.end_out : a.out2 != nullptr ? a.out2 : scratch + head + 2u * kwords;
+		a.pk_rmin_bytes = 1u << (d->knob_pk_rmin < (int)pk_rmax ? d->knob_pk_rmin : (int)pk_rmax);
+		a.pk_rmax = pk_rmax;
+		a.pk_nvmax = (uint32_t)nvmax;
+		a.pk_mean_max = d->knob_input_mode < 0 ? (uint32_t)d->knob_pk_mean_max : 0xFFFFFFFFu;
+		a.pk_lanes = (uint64_t)d->ncu * pc.blocks_per_cu * pc.waves * 64u;
+		a.pk_debug = (uint32_t)d->knob_pk_debug;
+	}
 	/* the ragged kernel sets bitmap bits one input at a time */
-	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
+	if (e == hipSuccess && (!packed || both) && c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
 	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
-	if (e == hipSuccess) {
-		const dim3 grid((unsigned)nblocks), block((unsigned)c.waves * 64u);
-		const Plan &p = d->plan;
-		switch (p.layout) {
-		case FSM_HIP_LAYOUT_TINY:     e = launch_tiny(p.tiny5_col.empty() ? POL_TINY64 : POL_TINY5, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_LDS:      e = launch_lds(POL_LDS, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_LDSSELF:  e = launch_lds(POL_LDSSELF, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMB:     e = launch_comb(POL_COMB, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMB256:  e = launch_comb(POL_COMB256, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_COMBSELF: e = launch_comb(POL_COMBSELF, eager, c, a, grid, block, s); break;
-		case FSM_HIP_LAYOUT_SPARSE:   e = launch_glob(POL_SPARSE, eager, c, a, grid, block, s); break;
-		default:                      e = launch_glob(POL_GLOB, eager, c, a, grid, block, s); break;
+	if (e == hipSuccess && packed) {
+		uint64_t fb = (a.n + 1u + 255u) / 256u;
+		if (fb > (uint64_t)d->ncu * 8u) fb = (uint64_t)d->ncu * 8u;
+		if (getenv("FSM_HIP_DEBUG") && atoi(getenv("FSM_HIP_DEBUG")) >= 2) (void)hipMemsetAsync(a.pk_codes, 0xEE, a.n * sizeof(uint32_t), s);
+		debug_stage(s, "packed scratch");
+		hipLaunchKernelGGL(packed_first, dim3((unsigned)fb), dim3(256), 0, s, a);
+		e = hipGetLastError();
+		debug_stage(s, "packed_first");
+		if (e == hipSuccess) {
+			/* rows are at least 128 bytes: with the batch's size known, no more workgroups than it has tiles */
+			uint64_t pb = (uint64_t)d->ncu * pc.blocks_per_cu;
+			if (known_bytes != 0) {
+				const uint64_t t = ((known_bytes >> 7) + 2u + 63u) / 64u, b = (t + pc.waves - 1) / pc.waves;
+				if (b < pb) pb = b;
+			}
+			e = launch_layout(d, 0, pc, a, dim3((unsigned)pb), dim3((unsigned)pc.waves * 64u), s);
+			debug_stage(s, "walk_packed");
+			if (getenv("FSM_HIP_DEBUG") && atoi(getenv("FSM_HIP_DEBUG")) >= 2) {   /* which inputs got no state code? */
+				std::vector<uint32_t> h(a.n);
+				PackedParams pr;
+				(void)hipMemcpy(h.data(), a.pk_codes, a.n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+				(void)hipMemcpy(&pr, scratch, sizeof pr, hipMemcpyDeviceToHost);
+				size_t bad = 0;
+				size_t wild = 0;
+				for (size_t i = 0; i < a.n; i++) {
+					if (h[i] == 0xEEEEEEEEu) { if (bad++ < 8) fprintf(stderr, " [unwritten %zu]", i); }
+					else if (h[i] / a.fin_div >= d->fin_host.size()) { if (wild++ < 8) fprintf(stderr, " [code %zu = %#x]", i, h[i]); }
+				}
+				fprintf(stderr, " wild=%zu", wild);
+				fprintf(stderr, " packed: n=%zu unwritten=%zu rshift=%u nrows=%llu use=%u has_empty=%u next_tile=%u nvmax=%u grid=%llu x %d\n", (size_t)a.n, bad,
+				        pr.rshift, (unsigned long long)pr.nrows, pr.use, pr.has_empty, pr.next_tile, a.pk_nvmax, (unsigned long long)pb, pc.waves);
+			}
 		}
 	}
+	if (e == hipSuccess && (!packed || both)) {
+		if (both) a.skip_flag = &reinterpret_cast<const PackedParams *>(scratch)->use;
+		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
+		debug_stage(s, "walk (fixed stride / ragged / generic)");
+	}
+	if (e == hipSuccess && packed && !(d->knob_pk_debug & 16)) {   /* (16: raw state codes left in place) */
+		uint64_t fb = (ntiles + 3u) / 4u;
+		if (fb > (uint64_t)d->ncu * 8u) fb = (uint64_t)d->ncu * 8u;
+		hipLaunchKernelGGL(packed_finish, dim3((unsigned)fb), dim3(256), 0, s, a);
+		e = hipGetLastError();
+		debug_stage(s, "packed_finish");
+	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
+	if (packed && md->pk_scratch_ev != nullptr) {
+		const hipError_t e2 = hipEventRecord(md->pk_scratch_ev, s);
+		md->pk_scratch_stream = s;
+		md->pk_scratch_busy = true;
+		if (e == hipSuccess) e = e2;
+	}
 	if (e != hipSuccess) {
 		if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: launch -> %s\n", hipGetErrorString(e));
 		errno = hip_errno(e);
@@ -531,9 +690,9 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	return 0;
 }
 
-extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
+static int exec_stride_device(const struct fsm_hip_dfa *d,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
-	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
 {
 	if (d == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	DevGuard dg(d->device);
@@ -548,12 +707,19 @@ extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
 	a.bitmap = d_accept_bitmap;
 	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream), hint);
 }
 
-extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
-	const void *d_base, const uint64_t *d_off, size_t n,
+extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	return exec_stride_device(d, d_base, stride, d_len, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+static int exec_offsets_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
 {
 	if (d == nullptr || (n != 0 && d_off == nullptr)) { errno = EINVAL; return -1; }
 	DevGuard dg(d->device);
@@ -566,7 +732,14 @@ extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
 	a.n = n;
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
-	return launch_walk(d, a, false, static_cast<hipStream_t>(hip_stream));
+	return launch_walk(d, a, false, static_cast<hipStream_t>(hip_stream), hint);
+}
+
+extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	return exec_offsets_device(d, d_base, d_off, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
 }
 
 extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
@@ -699,17 +872,19 @@ static int exec_host(const struct fsm_hip_dfa *d,
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	const int p_bm = hc.add(HostCall::OUT, nullptr, accept_bitmap, ((n + 63) / 64) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
-	struct Hint {   /* under the dfa's lock, which hc holds */
-		fsm_hip_dfa *d;
-		Hint(fsm_hip_dfa *d_, bool v) : d(d_) { d->hint_short = v; }
-		~Hint() { d->hint_short = false; }
-	} hint(hc.d, ((len != nullptr || off != nullptr) && in_bytes / n < 96u) || in_bytes >= ((size_t)1 << 36));   /* or: an input the ragged kernel's 32-bit chunk count could not hold */
+	BatchHint hint;
+	hint.bytes = in_bytes;
+	if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
+		uint64_t sum = 0;
+		for (size_t i = 0; i < n; i++) sum += len[i];
+		hint.short_mean = sum / n < 96u;
+	}
 	if (off) {
-		if (fsm_hip_exec_batch_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
-		                                      hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;
+		if (exec_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
+		                        hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs, hint) != 0) return -1;
 	} else {
-		if (fsm_hip_exec_batch_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-		                              hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs) != 0) return -1;
+		if (exec_stride_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
+		                       hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs, hint) != 0) return -1;
 	}
 	return hc.end();
 }
@@ -787,6 +962,10 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
 	case FSM_HIP_KNOB_RAGGED_ALIGN: break;   /* retired: segments start at the input's own first byte now */
+	case FSM_HIP_KNOB_PK_RMIN: if (value < 7 || value > (int)FSMHIP_PK_RMAX) { errno = EINVAL; return -1; } d->knob_pk_rmin = value; break;
+	case FSM_HIP_KNOB_PK_RMAX: if (value != 0 && (value < 7 || value > (int)FSMHIP_PK_RMAX)) { errno = EINVAL; return -1; } d->knob_pk_rmax = value; break;
+	case FSM_HIP_KNOB_PK_DEBUG: d->knob_pk_debug = value; break;
+	case FSM_HIP_KNOB_PK_MEAN_MAX: if (value < 0) { errno = EINVAL; return -1; } d->knob_pk_mean_max = value; break;
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
 	}

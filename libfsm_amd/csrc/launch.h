@@ -10,11 +10,12 @@
 #define FSM_HIP_LAUNCH_H
 
 #include "walk_kernels.h"
+#include "walk_packed.h"
 
 namespace fsmhip {
 
 struct LaunchCfg {
-	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED */
+	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED | IN_PACKED */
 	int nb;              /* direct: 16-byte chunks in flight per lane (4 or 8) */
 	int waves, blocks_per_cu;
 	int seg;             /* LDS-DMA: 64 or 128 */
@@ -51,12 +52,16 @@ static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs
 template <class Pol> struct ldsdma_threads { static constexpr int value = 1024; };
 template <> struct ldsdma_threads<CombSelfPol> { static constexpr int value = 768; };
 
+/* thread cap of walk_packed: every instantiation stays under the 128 registers of a 16-wave workgroup */
+template <class Pol> struct packed_threads { static constexpr int value = 1024; };
+
 /* plain walk: every input path */
 template <class Pol>
 static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	walk_fn k = nullptr;
 	switch (c.mode) {
+	case IN_PACKED:  k = walk_packed<Pol, packed_threads<Pol>::value>; break;
 	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
 	case IN_GENERIC: k = walk_generic<Pol>; break;
 	case IN_LDSDMA:

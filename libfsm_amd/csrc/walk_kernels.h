@@ -91,6 +91,18 @@ struct WalkArgs {
 	const uint32_t *ew_off;
 	const uint32_t *ew_word;
 	const uint64_t *ew_mask;
+	/* packed front (walk_packed.h): scratch block = PackedParams + first[]; where the raw state codes go; row-size
+	 * bounds (log2 bytes), the most rows first[] holds, the longest mean input length walk_packed takes */
+	uint32_t       *pk;
+	uint32_t       *pk_codes;
+	uint64_t       *pk_kbits;       /* bit j: input j is empty */
+	uint32_t        pk_rmin_bytes;  /* smallest row in bytes (knob) */
+	uint32_t        pk_rmax;        /* log2 of the largest row: what the per-wave LDS bitmask holds (<= FSMHIP_PK_RMAX) */
+	uint32_t        pk_nvmax, pk_mean_max;
+	uint32_t        pk_debug;       /* measurement aid (FSM_HIP_KNOB_PK_DEBUG): 1 no result stores, 4 no input loads, 8 no mask building */
+	uint64_t        pk_lanes;       /* lanes of the resident grid: rows are sized to give each wavefront about four tiles */
+	/* walk_ragged / walk_generic launched next to walk_packed: return at once if *skip_flag != 0 */
+	const uint32_t *skip_flag;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu
@@ -105,7 +117,7 @@ __device__ __forceinline__ uint32_t start_code(const WalkArgs &a, uint64_t i, bo
 	return a.enc_of[sid == FSMHIP_STATE_DEAD || sid >= a.nstates ? a.nstates : sid];
 }
 
-enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3 };
+enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_PACKED = 4 };
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
 #define FSMHIP_BTAB_BYTES 256u
@@ -1227,6 +1239,7 @@ template <class Pol, int MAXT = 1024>
 __global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
 {
+	if (a.skip_flag != nullptr && *a.skip_flag != 0u) return;   /* walk_packed took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);
@@ -1331,6 +1344,7 @@ __global__ void __launch_bounds__(MAXT)
 walk_ragged(const WalkArgs a)
 {
 	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
+	if (a.skip_flag != nullptr && *a.skip_flag != 0u) return;   /* walk_packed took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);

@@ -1,0 +1,223 @@
+"""GPU (-m gpu): parity tests added in round 3, all through the C ABI.
+
+  * walk_packed -- the short-input kernel of the packed-offsets front (a lane owns a byte range and walks across
+    input boundaries): every length 0..40 at every alignment, retest-like line sets, hostile length mixes, rows
+    of 128 bytes to 1 KiB, every table layout, offsets arrays at 8-mod-16 addresses, off[0] != 0, batches that
+    end exactly on a line, the device-side choice between walk_packed and walk_ragged;
+  against the oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, Golden
+
+pytestmark = pytest.mark.gpu
+
+NO = 0xFFFFFFFF
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    torch.cuda.set_device(0)
+    import libfsm_amd
+    libfsm_amd.load_library()
+    return libfsm_amd
+
+
+def bits(bm, n):
+    return np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def _packed(strings):
+    off = np.zeros(len(strings) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    return np.frombuffer(b"".join(strings), np.uint8), off
+
+
+def _layouts(hip, flat):
+    out = []
+    for L in (hip.LAYOUT_AUTO, hip.LAYOUT_TINY, hip.LAYOUT_LDS, hip.LAYOUT_LDSSELF, hip.LAYOUT_COMB, hip.LAYOUT_COMB256,
+              hip.LAYOUT_COMBSELF, hip.LAYOUT_GLOBAL, hip.LAYOUT_SPARSE):
+        try:
+            out.append((L, hip.HipDfa(flat, L)))
+        except OSError:
+            pass
+    return out
+
+
+def _cases(name, rng):
+    a = np.frombuffer(b"Llibfsmx\0" if name == "c1.npz" else b"abcdwxyz0123456789", np.uint8)
+    pats = None
+    if name == "c3.npz":
+        pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+
+    def rnd(k):
+        return bytes(a[rng.randint(0, len(a), k)])
+
+    def accepted(k):
+        if pats is None:
+            s = bytearray(rnd(max(k, 6)))
+            at = rng.randint(0, len(s) - 5)
+            s[at:at + 6] = b"Libfsm"
+            return bytes(s)
+        p = pats[rng.randint(len(pats))]
+        return p[1:p.index(b"[")] + bytes(rng.randint(48, 58, max(1, k - 6)).astype(np.uint8)) + b"yz"
+
+    def mix(k):
+        return accepted(k) if rng.randint(3) == 0 else rnd(k)
+
+    return {
+        "len1to40": [mix(L) for L in range(1, 41) for _ in range(37)],                      # every length at every alignment
+        "len40to0": [mix(L) for L in range(40, -1, -1) for _ in range(19)],
+        "short8to64": [mix(rng.randint(8, 65)) for _ in range(20000)],
+        "tiny0to3": [rnd(rng.randint(0, 4)) for _ in range(9000)],                          # > 6 ends per 16-byte chunk: several passes
+        "one_byte": [rnd(1) for _ in range(5000)],
+        "mostly_empty": [b"" if i % 7 else mix(rng.randint(0, 90)) for i in range(6000)],
+        "all_empty": [b""] * 700,
+        "empties_at_both_ends": [b""] * 70 + [mix(rng.randint(1, 50)) for _ in range(500)] + [b""] * 70,
+        "long_among_short": [accepted(30_000) if i % 301 == 3 else mix(rng.randint(0, 40)) for i in range(3000)],
+        "uniform0to1024": [mix(rng.randint(0, 1025)) for _ in range(3000)],
+        "exact16": [mix(16) for _ in range(3000)],
+        "exact128": [mix(128) for _ in range(800)],
+        "exact127_129": [mix(127 + 2 * (i & 1)) for i in range(800)],
+        "single_short": [accepted(9)],
+        "single_long": [accepted(5000)],
+        "two": [b"", accepted(700)],
+    }
+
+
+@pytest.mark.parametrize("name", ["c1.npz", "c3.npz"])
+def test_packed_kernel_length_distributions(hip, name):
+    """walk_packed forced (IN_PACKED) and the device-side auto choice, every layout the DFA can take, 1 to 12 waves,
+    rows of 128 bytes (an input nearly always runs past its row) to 1 KiB: end states and bitmap against the oracle."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(5 + len(name))
+    g = Golden(os.path.join(GOLDEN, name))
+    o = Oracle(g.flat)
+    cases = _cases(name, rng)
+    dfas = _layouts(hip, g.flat)
+    assert len(dfas) >= 4
+    for cname, strings in cases.items():
+        ret, want = o.exec_strings(strings)
+        base, off = _packed(strings)
+        for L, dfa in dfas:
+            # (mode, waves, smallest row, largest row): rows of exactly 128 / 256 / 1024 bytes, and the kernel's own choice
+            for mode, waves, rmin, rmax in ((hip.IN_PACKED, 0, 7, 0), (hip.IN_PACKED, 1, 7, 7), (hip.IN_PACKED, 5, 8, 8), (hip.IN_PACKED, 0, 10, 10), (-1, 0, 7, 0)):
+                if L != hip.LAYOUT_AUTO and (waves, rmin) not in ((0, 7), (1, 7)):
+                    continue
+                print(name, cname, L, mode, waves, rmin, rmax, flush=True)
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_PK_RMIN, rmin)
+                dfa.tune(hip.KNOB_PK_RMAX, rmax)
+                end, bm = dfa.exec_batch_offsets(base, off)
+                bad = np.nonzero(end != want)[0]
+                assert len(bad) == 0, (name, cname, L, mode, waves, rmin, rmax, len(bad), bad[:8], [len(strings[i]) for i in bad[:8]])
+                assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, rmin)
+                end, bm = dfa.exec_batch_offsets(base, off, want_bitmap=False)      # end states only
+                assert np.array_equal(end, want)
+    for _, dfa in dfas:
+        dfa.close()
+
+
+def test_packed_kernel_device_front_alignments(hip):
+    """Device-resident batches of exactly the inputs' size: base at every byte alignment within a line, off[0] != 0,
+    the offsets array at a 16-byte and at an 8-mod-16 address, totals that end exactly on a 128-byte line, bitmap
+    only (the kernel's own code scratch), every total from 0 to 40 bytes."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(19)
+    a = np.frombuffer(b"Llibfsmx\0", np.uint8)
+
+    def tiny(k):
+        s = bytearray(bytes(a[rng.randint(0, len(a), k)]))
+        if k >= 4 and rng.randint(2):
+            at = rng.randint(0, k - 3)
+            s[at:at + 4] = b"libf"
+        return bytes(s)
+
+    dfa = hip.HipDfa(g.flat)
+    dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_PACKED)
+    batches = []
+    for total in range(0, 41):
+        cut = sorted(rng.randint(0, total + 1, rng.randint(0, 6)))
+        body = tiny(total)
+        batches.append([body[x:y] for x, y in zip([0] + cut, cut + [total])])
+    for k in range(40):
+        batches.append([tiny(rng.randint(0, 70)) for _ in range(rng.randint(1, 400))])
+    for total in (128, 256, 1024, 4096):                                  # the batch ends exactly on a line (and a row) boundary
+        strs = [tiny(rng.randint(1, 30)) for _ in range(total // 16)]
+        body = b"".join(strs)[:total - 3]
+        batches.append([body[i:i + 7] for i in range(0, len(body), 7)] + [b"lib", b"", b""])
+    for bi, strings in enumerate(batches):
+        ret, want = o.exec_strings(strings)
+        base, off = _packed(strings)
+        n = len(strings)
+        for shift, lead, osh in ((0, 0, 0), (1, 0, 1), (13, 5, 0), (127, 300, 1), (64, 128, 0)):
+            if bi % 3 and (shift, lead) != (0, 0):
+                continue
+            big = torch.zeros(256 + shift + lead + len(base), dtype=torch.uint8, device="cuda")     # 256-byte aligned allocation
+            if len(base):
+                big[shift + lead:shift + lead + len(base)] = torch.from_numpy(base.copy()).cuda()
+            d_off_store = torch.zeros(n + 3, dtype=torch.int64, device="cuda")
+            d_off = d_off_store[osh:osh + n + 1]
+            d_off.copy_(torch.from_numpy((off + np.uint64(lead)).view(np.int64)).cuda())
+            d_end = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+            d_bm = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device="cuda")
+            base_ptr = big.data_ptr() + shift
+            for waves in (0, 1):
+                dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.exec_batch_offsets_device(base_ptr, d_off.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr())
+                torch.cuda.synchronize()
+                assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (bi, n, len(base), shift, lead, osh, waves)
+                assert np.array_equal(bits(d_bm.cpu().numpy()[:(n + 63) // 64], n), ret == 1)
+                d_bm.zero_()
+                dfa.exec_batch_offsets_device(base_ptr, d_off.data_ptr(), n, 0, d_bm.data_ptr())      # bitmap only
+                torch.cuda.synchronize()
+                assert np.array_equal(bits(d_bm.cpu().numpy()[:(n + 63) // 64], n), ret == 1), (bi, "bitmap only")
+                assert int(d_bm[-1]) == 0
+    dfa.close()
+
+
+def test_packed_kernel_large_batch_and_auto_choice(hip):
+    """6e6 packed inputs of 8..64 bytes resident on the device (216 MB): walk_packed (which the auto mode picks: mean
+    36 bytes) agrees with walk_generic on every input and with the oracle on a sample; 2e6 inputs of 0..1024 bytes
+    (mean 512: auto leaves them to walk_ragged) the same, with walk_packed forced as well."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c1.npz"))
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(3)
+    dfa = hip.HipDfa(g.flat)
+    for n, lo, hi in ((6_000_000, 8, 65), (2_000_000, 0, 1025)):
+        lens = rng.randint(lo, hi, n).astype(np.int64)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        total = int(off[-1])
+        buf = torch.empty(((total + 1023) // 1024 + 1, 1024), dtype=torch.uint8, device="cuda")
+        hip.gen_inputs_device(buf.data_ptr(), buf.shape[0], 1024, 0, 0x5EEDF5A1, None, b"Libfsm", 2)
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        e = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(3)]
+        bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        ms = {}
+        for k, mode in enumerate((-1, hip.IN_PACKED, hip.IN_GENERIC)):
+            dfa.tune(hip.KNOB_INPUT_MODE, mode)
+            for rep in range(2):
+                dfa.exec_batch_offsets_device(buf.data_ptr(), d_off.data_ptr(), n, e[k].data_ptr(), bm.data_ptr() if k == 0 else 0)
+            ms[mode] = dfa.last_kernel_ms()
+        torch.cuda.synchronize()
+        assert torch.equal(e[0], e[2]) and torch.equal(e[1], e[2])
+        assert int((e[0] != -1).sum()) == int(bits(bm.cpu().numpy(), n).sum()) > 0
+        host = buf.reshape(-1)[:total].cpu().numpy()
+        idx = rng.randint(0, n, 5000)
+        strings = [bytes(host[int(off[i]):int(off[i + 1])]) for i in idx]
+        ret, want = o.exec_strings(strings)
+        assert np.array_equal(e[0].cpu().numpy().view(np.uint32)[idx], want)
+        print(f"packed front n={n} lens={lo}..{hi - 1}: auto {total / ms[-1] / 1e6:.0f} GB/s, packed {total / ms[hip.IN_PACKED] / 1e6:.0f}, generic {total / ms[hip.IN_GENERIC] / 1e6:.0f}")
+    dfa.close()

@@ -19,16 +19,17 @@ def main():
     from oracle.pyoracle import Oracle
     hip.load_library()
     torch.cuda.set_device(0)
-    n, L = int(os.environ.get("RAGGED_N", 2_000_000)), 1024
+    n, L = int(os.environ.get("RAGGED_N", 2_000_000)), 1024      # the profiles/ tables use RAGGED_N=6000000
     buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
     end = torch.empty(n, dtype=torch.int32, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(1)
     only = os.environ.get("RAGGED_CASES")      # e.g. "c2:packed:3,c2:rows:1": workload:front:mode filters (profiling runs)
-    for dist in ("uniform0-1024", "short8-64"):
+    for dist in os.environ.get("RAGGED_DISTS", "uniform0-1024,short8-64,short8-16,short32-128,mid64-256").split(","):
         if dist.startswith("uniform"):
             lens = torch.randint(0, L + 1, (n,), device="cuda", dtype=torch.int32, generator=g)
         else:
-            lens = torch.randint(8, 65, (n,), device="cuda", dtype=torch.int32, generator=g)
+            lo, hi = [int(x) for x in dist.lstrip("shortmid").split("-")]
+            lens = torch.randint(lo, hi + 1, (n,), device="cuda", dtype=torch.int32, generator=g)
         total = int(lens.sum().item())
         off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
         off[1:] = torch.cumsum(lens.to(torch.int64), 0)
@@ -46,7 +47,7 @@ def main():
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
             ref = None
-            for front, mode, waves, align in (("packed", 3, 0, 0), ("packed", 3, 8, 0), ("packed", 3, 16, 0), ("packed", 2, 0, 0),
+            for front, mode, waves, align in (("packed", -1, 0, 0), ("packed", 4, 0, 0), ("packed", 4, 8, 0), ("packed", 3, 0, 0), ("packed", 2, 0, 0),
                                               ("stride+len", 3, 0, 0), ("stride+len", 2, 0, 0), ("rows", 3, 0, 0), ("rows", -1, 0, 0)):
                 if only is not None and f"{wl}:{front}:{mode}" not in only.split(","):
                     continue
@@ -54,6 +55,9 @@ def main():
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
+                for kn, ev in ((hip.KNOB_PK_RMIN, "PK_RMIN"), (hip.KNOB_PK_RMAX, "PK_RMAX"), (hip.KNOB_PK_MEAN_MAX, "PK_MEAN_MAX"), (hip.KNOB_PK_DEBUG, "PK_DEBUG")):
+                    if os.environ.get(ev):
+                        dfa.tune(kn, int(os.environ[ev]))
                 ms = []
                 for r in range(4):
                     if front == "packed":

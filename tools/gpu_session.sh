@@ -8,11 +8,20 @@ export TMPDIR=/tmp
 for step in "$@"; do
 	case $step in
 	test)   timeout 1000 python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
+	testr3) timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s --timeout 500 > gpurun_out/${TAG}_pytest_r3.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r3.log; tail -25 gpurun_out/${TAG}_pytest_r3.log ;;
+	pkdebug) for a in ${PKDEBUG_CASES:-c1.npz:0:len40to0}; do a=$(echo $a | tr ':' ' '); FSM_HIP_DEBUG=2 timeout 200 python tests/tools/packed_debug.py $a > gpurun_out/${TAG}_pkdebug_$(echo $a | tr ' .' '__').log 2>&1; echo "pkdebug $a rc=$?"; grep -v "^  File\|^Extension" gpurun_out/${TAG}_pkdebug_$(echo $a | tr ' .' '__').log | tail -${PKDEBUG_TAIL:-14}; done ;;
+	pkprof) export RAGGED_N=6000000 RAGGED_DISTS=${PK_DISTS:-short8-64} RAGGED_CASES=${PK_CASES:-c2:packed:4,c3:packed:4}
+	        (cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/${TAG}_pktrace -o t -- python $OLDPWD/tests/tools/ragged.py > $OLDPWD/gpurun_out/${TAG}_pktrace.txt 2>&1)
+	        python tools/rocpd_top_kernels.py gpurun_out/${TAG}_pktrace >> gpurun_out/${TAG}_pktrace.txt 2>&1; rm -rf gpurun_out/${TAG}_pktrace; tail -12 gpurun_out/${TAG}_pktrace.txt
+	        timeout 600 python tools/pmc_kernel.py --match packed --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE" -- python tests/tools/ragged.py > gpurun_out/${TAG}_pkpmc.txt 2>&1; tail -70 gpurun_out/${TAG}_pkpmc.txt ;;
+	pkbisect) export RAGGED_N=6000000 RAGGED_DISTS=short8-64 RAGGED_CASES=c2:packed:4
+	        for dbg in 0 1 2 3 4 6 7 8 15; do echo "PK_DEBUG=$dbg"; PK_DEBUG=$dbg timeout 200 python tests/tools/ragged.py 2>&1 | grep "mode= 4 waves= 0"; done > gpurun_out/${TAG}_pkbisect.txt 2>&1; cat gpurun_out/${TAG}_pkbisect.txt ;;
+	testr3dbg) FSM_HIP_DEBUG=2 timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s --timeout 500 -k length_distributions > gpurun_out/${TAG}_pytest_r3dbg.log 2>&1; grep -v "^  File\|^Extension" gpurun_out/${TAG}_pytest_r3dbg.log | tail -30 ;;
 	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
 	fullpar) timeout 900 python bench.py --steps 5 --warmup 2 --subs none --full-parity > gpurun_out/${TAG}_bench_fullparity.json 2> gpurun_out/${TAG}_bench_fullparity.err; echo "fullparity rc=$?"; python -c "import json,sys; r=json.loads(open('gpurun_out/${TAG}_bench_fullparity.json').read().strip().splitlines()[-1]); print(r['value'], r.get('full_parity'))" ;;
 	benchnode) FSM_BENCH_NODE_FRONT=1 FSM_BENCH_NODE_REPLICAS=2 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_benchnode.json 2> gpurun_out/${TAG}_benchnode.err; echo "benchnode rc=$?"; python -c "import json; r=json.loads(open('gpurun_out/${TAG}_benchnode.json').read().strip().splitlines()[-1]); print(r['value'], r.get('node_front'))" ;;
-	ragged) timeout 300 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
+	ragged) timeout 400 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
 	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
 	sweep)  timeout 400 python tests/tools/sweep.py --set r2 --workloads c3,c2 > gpurun_out/${TAG}_sweep.txt 2>&1; echo "sweep rc=$?"; grep -v '^#' gpurun_out/${TAG}_sweep.txt | tail -80 ;;
