@@ -36,7 +36,7 @@ enum {
 	FSM_HIP_KNOB_PK_RMAX       = 17, /* packed mode: log2 of the largest row, 7..10; 0 (default) = what LDS allows     */
 	FSM_HIP_KNOB_PK_MEAN_MAX   = 18, /* auto: batches whose mean input length exceeds this go to the ragged kernel   */
 	FSM_HIP_KNOB_PK_DEBUG      = 19, /* measurement aid: bit mask of walk_packed parts switched off (results are WRONG):
-	                                  * 1 result stores, 4 input loads, 8 mask building, 16 packed_finish (raw state codes stay) */
+	                                  * 1 result stores, 4 input loads, 16 packed_finish (raw state codes stay)           */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };

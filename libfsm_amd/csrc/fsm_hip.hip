@@ -657,8 +657,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 					else if (h[i] / a.fin_div >= d->fin_host.size()) { if (wild++ < 8) fprintf(stderr, " [code %zu = %#x]", i, h[i]); }
 				}
 				fprintf(stderr, " wild=%zu", wild);
-				fprintf(stderr, " packed: n=%zu unwritten=%zu rshift=%u nrows=%llu use=%u has_empty=%u next_tile=%u nvmax=%u grid=%llu x %d\n", (size_t)a.n, bad,
-				        pr.rshift, (unsigned long long)pr.nrows, pr.use, pr.has_empty, pr.next_tile, a.pk_nvmax, (unsigned long long)pb, pc.waves);
+				fprintf(stderr, " packed: n=%zu unwritten=%zu rshift=%u nrows=%llu use=%u has_empty=%u nvmax=%u grid=%llu x %d\n", (size_t)a.n, bad,
+				        pr.rshift, (unsigned long long)pr.nrows, pr.use, pr.has_empty, a.pk_nvmax, (unsigned long long)pb, pc.waves);
 			}
 		}
 	}

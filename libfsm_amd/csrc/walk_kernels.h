@@ -99,7 +99,7 @@ struct WalkArgs {
 	uint32_t        pk_rmin_bytes;  /* smallest row in bytes (knob) */
 	uint32_t        pk_rmax;        /* log2 of the largest row: what the per-wave LDS bitmask holds (<= FSMHIP_PK_RMAX) */
 	uint32_t        pk_nvmax, pk_mean_max;
-	uint32_t        pk_debug;       /* measurement aid (FSM_HIP_KNOB_PK_DEBUG): 1 no result stores, 4 no input loads, 8 no mask building */
+	uint32_t        pk_debug;       /* measurement aid (FSM_HIP_KNOB_PK_DEBUG): 1 no result stores, 4 no input loads */
 	uint64_t        pk_lanes;       /* lanes of the resident grid: rows are sized to give each wavefront about four tiles */
 	/* walk_ragged / walk_generic launched next to walk_packed: return at once if *skip_flag != 0 */
 	const uint32_t *skip_flag;
@@ -1235,6 +1235,19 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
 
+/*
+ * One input per lane, 64 consecutive inputs per wavefront and step of a persistent loop.  The walk of a short input
+ * (the lines retest / rx feed) is a few hundred cycles; what it waited for, in the first version of this kernel, were
+ * four memory round trips in a row: the offsets, the first chunk, every further chunk one ahead, the fin[] lookup of
+ * the result.  Now a step has ONE wait:
+ *  - the offsets (or lengths) of the NEXT step's inputs are asked for at the top of a step;
+ *  - an input's first NC = 4 chunks are loaded together, from its own byte address: global_load_dwordx4 takes any
+ *    alignment, so chunk 0 starts at the input's first byte and only the input's LAST chunk can be partial (the first
+ *    version read aligned chunks: a packed input's first chunk was partial too, and a partial chunk costs 16 predicated
+ *    steps).  A chunk that would reach past the batch's last byte is assembled from byte loads;
+ *  - the previous step's results are looked up (fin[]) and written under the same wait.
+ * Inputs longer than NC chunks go on one chunk at a time with the next one in flight, as before.
+ */
 template <class Pol, int MAXT = 1024>
 __global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
@@ -1245,50 +1258,96 @@ walk_generic(const WalkArgs a)
 	pol.setup(lds, a);
 	__syncthreads();
 
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	const uint64_t ntiles = (a.n + 63u) / 64u;
+	constexpr uint32_t NC = 4;
+	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;   /* not a flat load */
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+	const uint64_t ntiles = (a.n + 63u) / 64u, tstride = (uint64_t)gridDim.x * nw;
+	const uint64_t base = reinterpret_cast<uint64_t>(a.base);
+	/* one past the batch's last byte: no load may reach beyond it */
+	const uint64_t limit = base + (a.off != nullptr ? a.off[a.n] : a.n * a.stride);
+	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);   /* 1 KiB that is always there: what a lane without a chunk reads */
 
-	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
+	/* 16 bytes at any address; [addr, limit) from byte loads where addr + 16 > limit */
+	auto load_chunk = [&](uint64_t addr, bool want) -> u32x4 {
+		const bool edge = want && addr + 16u > limit;
+		u32x4 x = *(glb_chunk_p)(want && !edge ? addr : safe);      /* unconditional: the loads of a step are counted, not waited for one by one */
+		if (__any(edge)) {
+			if (edge) {
+				uint32_t d[4] = {0u, 0u, 0u, 0u};
+				for (uint32_t k = 0; k < 15u && addr + k < limit; k++)
+					d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(addr)[k] << ((k & 3u) * 8u);
+				x = u32x4{d[0], d[1], d[2], d[3]};
+			}
+		}
+		return x;
+	};
+
+	/* the offsets / lengths of a step's inputs, asked for one step ahead (clamped indices: the loads are unconditional) */
+	uint64_t nb = 0, ne = 0;
+	uint32_t nl = 0;
+	auto fetch = [&](uint64_t tile) {
+		const uint64_t i = tile * 64u + lane, ic = i < a.n ? i : a.n - 1u;
+		if (a.off != nullptr) { nb = a.off[ic]; ne = a.off[ic + 1u]; }
+		else if (a.len != nullptr) nl = a.len[ic];
+	};
+
+	uint64_t tile = (uint64_t)blockIdx.x * nw + wave;
+	fetch(tile);
+	bool pend = false;                 /* wave-uniform: the previous step's results are not written yet */
+	uint64_t ptile = 0, pi = 0;
+	bool pvalid = false;
+	uint32_t pcode = 0;
+	for (; tile < ntiles; tile += tstride) {
 		const uint64_t i = tile * 64u + lane;
 		const bool valid = i < a.n;
 		uint64_t beg = 0, len = 0;
-		if (valid) {
-			if (a.off != nullptr) { beg = a.off[i]; len = a.off[i + 1] - beg; }
-			else { beg = i * a.stride; len = a.len != nullptr ? a.len[i] : a.stride; }
-		}
-		/* every 16-byte aligned chunk that contains at least one byte of the
-		 * input is read whole; bytes outside [beg, beg+len) are masked.  An
-		 * aligned 16-byte chunk never crosses a page, so this cannot fault. */
-		const uint64_t p0 = reinterpret_cast<uint64_t>(a.base) + beg;
-		const uint64_t q0 = p0 & ~(uint64_t)15;
-		const uint32_t head = (uint32_t)(p0 - q0);
-		const uint64_t span = len ? head + len : 0;
-		const uint64_t nchunks = (span + 15u) / 16u;
+		if (a.off != nullptr) { beg = nb; len = ne - nb; }
+		else { beg = i * a.stride; len = a.len != nullptr ? nl : a.stride; }
+		if (!valid) { beg = 0; len = 0; }
+		fetch(tile + tstride);
+		const uint64_t p0 = base + beg;
+		const uint64_t nchunks = (len + 15u) / 16u;
 		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
-		u32x4 w[1] = { {0u, 0u, 0u, 0u} };
-		typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;   /* not a flat load */
-		if (nchunks != 0) w[0] = *(glb_chunk_p)q0;
-		for (uint64_t c = 0; __any(c < nchunks); c++) {
+		u32x4 wq[NC];
+#pragma unroll
+		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(p0 + 16u * j, j < nchunks);
+		/* the previous step's results: their fin[] lookup is in flight with this step's chunks */
+		if (pend) write_result(a, ptile, pi, pvalid, pcode);
+#pragma unroll
+		for (uint32_t c = 0; c < NC; c++) {
+			if (!__any(c < nchunks)) break;
 			if (c < nchunks) {
-				u32x4 wn = {0u, 0u, 0u, 0u};
-				if (c + 1 < nchunks) wn = *(glb_chunk_p)(q0 + (c + 1) * 16u); /* next chunk in flight */
-				/* valid bytes of this chunk: [lo, hi) */
-				const uint32_t lo = c == 0 ? head : 0u;
-				const uint64_t left = span - c * 16u;
-				const uint32_t hi = left < 16u ? (uint32_t)left : 16u;
-				if (__all(lo == 0u && hi == 16u)) {
+				const uint64_t left = len - c * 16u;
+				if (__all(left >= 16u)) {
 					/* every lane still walking has a whole chunk: no per-byte predicate */
-					step16<Pol, 1>(pol, st, w);
+					const u32x4 w1[1] = { wq[c] };
+					step16<Pol, 1>(pol, st, w1);
 				} else {
-					step16_part(pol, st[0], w[0], lo, hi - lo);
+					step16_part(pol, st[0], wq[c], 0u, left < 16u ? (uint32_t)left : 16u);
 				}
-				w[0] = wn;
 			}
-			if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 		}
-		write_result(a, tile, i, valid, Pol::code(st[0]));
+		if (__any(nchunks > NC)) {
+			u32x4 w[1] = { load_chunk(p0 + 16u * NC, nchunks > NC) };
+			for (uint64_t c = NC; __any(c < nchunks); c++) {
+				if (c < nchunks) {
+					const u32x4 wn = load_chunk(p0 + 16u * (c + 1u), c + 1u < nchunks);   /* next chunk in flight */
+					const uint64_t left = len - c * 16u;
+					if (__all(left >= 16u)) step16<Pol, 1>(pol, st, w);
+					else step16_part(pol, st[0], w[0], 0u, left < 16u ? (uint32_t)left : 16u);
+					w[0] = wn;
+				}
+				if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
+			}
+		}
 		finish_state(pol, a, i, valid, st[0], 0);
+		pend = true;
+		ptile = tile;
+		pi = i;
+		pvalid = valid;
+		pcode = Pol::code(st[0]);
 	}
+	if (pend) write_result(a, ptile, pi, pvalid, pcode);
 }
 
 /* ------------------------------------------------------------------ */

@@ -9,7 +9,7 @@
  *  - the batch's byte range is cut into rows of R = 2^rshift bytes (128 B .. 1 KiB, 128-byte aligned
  *    addresses); a tile is 64 adjacent rows, one per lane, and every lane streams its row 128 bytes a
  *    round with eight 16-byte loads of one cache line: the access pattern of the fixed-stride kernels,
- *    whatever the inputs' lengths.  Tiles are handed to wavefronts by an atomic counter;
+ *    whatever the inputs' lengths.  Tiles are dealt round-robin to the resident wavefronts;
  *  - the inputs that start in a tile are a contiguous index range, so their offsets are read coalesced,
  *    64 per instruction, and each sets one bit -- "an input starts at this byte" -- in a per-wave LDS
  *    bitmask of the tile, laid out [round][lane] so that a lane's 128 bits of a round are one
@@ -49,8 +49,7 @@ struct PackedParams {
 	uint32_t rshift;    /* rows are 1 << rshift bytes                                                        */
 	uint32_t use;       /* 1: walk_packed takes the batch (walk_ragged / walk_generic return at once), 0: the reverse */
 	uint32_t has_empty; /* some input is empty: result indices step over them (kbits)                        */
-	uint32_t next_tile; /* the next tile to hand out                                                         */
-	uint32_t pad[6];
+	uint32_t pad[7];
 };
 #define FSMHIP_PK_FIRST_OFF 16u   /* first[] starts at this u32 index of the scratch block (after the parameters) */
 #define FSMHIP_PK_RMAX 10u        /* rows of at most 1 KiB: the tile's bitmask is 8 KiB of LDS */
@@ -62,10 +61,23 @@ template <> struct packed_code<LdsSelfPol> { static constexpr bool c16 = true; s
 template <> struct packed_code<GlobPol> { static constexpr bool c16 = false; static constexpr uint32_t shift = 0u; };
 template <> struct packed_code<SparsePol> { static constexpr bool c16 = false; static constexpr uint32_t shift = 0u; };
 
-/* per-wave LDS: the tile's bitmask (64 rows x 2^rmax / 8 bytes) + 16 codes per lane */
-__host__ __device__ constexpr uint32_t packed_wave_lds(uint32_t rmax, bool c16) { return (8u << rmax) + 64u * (c16 ? 32u : 64u); }
+/* per-wave LDS: the tile's bitmask (64 rows x 2^rmax / 8 bytes) + per lane 16 codes and, just before them, the carry-in code */
+__host__ __device__ constexpr uint32_t packed_wave_lds(uint32_t rmax, bool c16) { return (8u << rmax) + 64u * (c16 ? 48u : 80u); }
 
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+
+/* m = all ones: restart from the start state; m = 0: keep (one v_bfi_b32 per 32-bit field: no compare, no VCC) */
+__device__ __forceinline__ uint32_t pk_reset(uint32_t m, uint32_t start, uint32_t st) { return (start & m) | (st & ~m); }
+__device__ __forceinline__ LdsSelfState pk_reset(uint32_t m, const LdsSelfState &start, const LdsSelfState &st)
+{
+	LdsSelfState r = { pk_reset(m, start.st, st.st), pk_reset(m, start.sm, st.sm) };
+	return r;
+}
+__device__ __forceinline__ CombSelfState pk_reset(uint32_t m, const CombSelfState &start, const CombSelfState &st)
+{
+	CombSelfState r = { pk_reset(m, start.st, st.st), pk_reset(m, start.sm, st.sm), pk_reset(m, start.rng, st.rng) };
+	return r;
+}
 
 /* the index of the first non-empty input at or after i (kbits: bit j set = input j is empty; bits at and beyond n are clear) */
 __device__ __forceinline__ uint32_t packed_skip_empty(const uint64_t *kbits, uint32_t i)
@@ -85,11 +97,11 @@ walk_packed(const WalkArgs a)
 {
 	constexpr bool C16 = packed_code<Pol>::c16;
 	constexpr uint32_t CSH = packed_code<Pol>::shift;
-	constexpr uint32_t CW = C16 ? 32u : 64u, NONE = 0xFFFFFFFFu;
+	constexpr uint32_t CW = C16 ? 48u : 80u, NONE = 0xFFFFFFFFu;   /* record: the carry-in code just before offset 16, the codes after bytes 0..15 from offset 16 */
 	typedef typename Pol::S S;
 	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;
 
-	PackedParams *pp = reinterpret_cast<PackedParams *>(a.pk);
+	const PackedParams *pp = reinterpret_cast<const PackedParams *>(a.pk);
 	if (pp->use == 0u) return;
 
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -100,7 +112,7 @@ walk_packed(const WalkArgs a)
 	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const uint32_t mask_bytes = 8u << a.pk_rmax;
 	unsigned char *mk = lds + Pol::lds_bytes(a.tab_bytes) + wave * (mask_bytes + 64u * CW);   /* [round][lane][16 bytes] */
-	unsigned char *cs = mk + mask_bytes + lane * CW;                                            /* this lane's 16 saved codes */
+	unsigned char *cs = mk + mask_bytes + lane * CW;                                            /* this lane's saved codes: C16: code k at cs + 14 + 2 k, else cs + 12 + 4 k (k = 0: the carry-in code) */
 
 	const S start_s = init_state(pol, a.start, a, 0, false, 0);
 	const uint64_t A0 = pp->a0, Aend = pp->aend, nrows = pp->nrows;
@@ -112,35 +124,42 @@ walk_packed(const WalkArgs a)
 	const uint64_t ntiles = (nrows + 63u) / 64u, base = reinterpret_cast<uint64_t>(a.base);
 	const uint32_t tile_bytes = 64u << rsh;
 
-	/* tiles come from a counter; the next one is asked for before the current one is walked (its latency is hidden) */
-	uint32_t grabbed = 0;
-	if (lane == 0) grabbed = atomicAdd(&pp->next_tile, 1u);
-	for (;;) {
-		const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
-		if (tile >= ntiles) break;
-		if (lane == 0) grabbed = atomicAdd(&pp->next_tile, 1u);
-
-		const uint64_t v = (uint64_t)tile * 64u + lane;
-		const uint32_t fst = first_tab[v < nrows ? v : nrows], lim = first_tab[v + 1u < nrows ? v + 1u : nrows];
+	/* tiles are dealt round-robin to the resident wavefronts; a tile's first[] entries are asked for one tile ahead */
+	const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6), gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+	uint32_t fst_n = 0, lim_n = 0;
+	{
+		const uint64_t v = gw * 64u + lane;
+		fst_n = first_tab[v < nrows ? v : nrows];
+		lim_n = first_tab[v + 1u < nrows ? v + 1u : nrows];
+	}
+	for (uint64_t tile = gw; tile < ntiles; tile += nwaves) {
+		const uint32_t fst = fst_n, lim = lim_n;
+		{
+			const uint64_t v = (tile + nwaves) * 64u + lane;     /* (unconditional loads of clamped indices: nothing to wait for here) */
+			fst_n = first_tab[v < nrows ? v : nrows];
+			lim_n = first_tab[v + 1u < nrows ? v + 1u : nrows];
+		}
 		const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)fst), e1 = (uint32_t)__builtin_amdgcn_readlane((int)lim, 63);
-		const uint64_t tileaddr = A0 + ((uint64_t)tile << (rsh + 6u)), tileoff = tileaddr - base;   /* offsets relative to the tile (wraps for tile 0: fine) */
+		const uint64_t tileaddr = A0 + (tile << (rsh + 6u)), tileoff = tileaddr - base;   /* offsets relative to the tile (wraps for tile 0: fine) */
 		const uint64_t rowaddr = tileaddr + ((uint64_t)lane << rsh);
+
 
 		/* the tile's bitmask: bit p = an input starts at byte p of the tile (the end of the batch's last input counts as one) */
 		for (uint32_t k = 0; k < rpr; k++) *reinterpret_cast<u32x4 *>(mk + ((k << 6) + lane) * 16u) = u32x4{0u, 0u, 0u, 0u};
 		/* the only boundary that can lie beyond the tile and still matter: the end of the last input that starts in it */
 		const uint64_t tail = a.off[e1] - tileoff;
-		for (uint32_t e = e0; e <= e1 && !(a.pk_debug & 8u); e += 256u) {         /* 4 x 64 offsets in flight (e1 < 2^32 - 256: the host checks n) */
-			uint64_t o[4];
+		for (uint32_t e = e0; e <= e1; e += 512u) {   /* 8 x 64 offsets in flight (e1 < 2^32 - 4096: the host checks n) */
+			uint64_t o[8];
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
+			for (uint32_t q = 0; q < 8; q++) {
 				const uint32_t ei = e + 64u * q + lane;
-				o[q] = ei <= e1 ? a.off[ei] - tileoff : ~(uint64_t)0;
+				o[q] = a.off[ei <= e1 ? ei : e1];                 /* unconditional: a load under a lane mask is waited for on the spot */
 			}
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
-				if (o[q] < tile_bytes) {
-					const uint32_t p = (uint32_t)o[q];
+			for (uint32_t q = 0; q < 8; q++) {
+				const uint64_t rel = o[q] - tileoff;
+				if (e + 64u * q + lane <= e1 && rel < tile_bytes) {
+					const uint32_t p = (uint32_t)rel;
 					uint32_t *word = reinterpret_cast<uint32_t *>(mk + ((((p >> 7) & (rpr - 1u)) << 6) + (p >> rsh)) * 16u + ((p >> 5) & 3u) * 4u);
 					atomicOr(word, 1u << (p & 31u));      /* ds_or_b32, no return value */
 				}
@@ -150,8 +169,13 @@ walk_packed(const WalkArgs a)
 		__asm__ volatile("" ::: "memory");
 		__builtin_amdgcn_wave_barrier();
 
-		/* cur = the input the lane is in (NONE: the bytes before its row's first input, or done), nxt = the one after it */
+		/* Which input is the lane in?  rel = how many of its own inputs have begun (0: it is in the bytes before its row's
+		 * first input), nl = how many it owns; the r-th set bit met ends own input number rel + r (if 1 <= rel + r <= nl: index
+		 * fst + rel + r - 1) and begins the next one; the lane is done once an input beyond its own has begun.  With empty
+		 * inputs in the batch the indices are not consecutive: cur / nxt step over them through kbits instead. */
 		bool act = fst < lim;
+		const uint32_t nl = lim - fst;
+		uint32_t rel = 0;
 		uint32_t cur = NONE, nxt = fst;
 		if (emp && act) nxt = packed_skip_empty(kbits, nxt);
 		S st = start_s;
@@ -166,21 +190,26 @@ walk_packed(const WalkArgs a)
 				if (act && ra + 16u * j < Aend && !(a.pk_debug & 4u)) x = *(glb_chunk_p)(ra + 16u * j);
 				w[4 * j] = x.x; w[4 * j + 1] = x.y; w[4 * j + 2] = x.z; w[4 * j + 3] = x.w;
 			}
+			__builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0), once per round: the chunk loop below must not wait (for its own result stores) on every chunk */
+			__asm__ volatile("" ::: "memory");
 			/* this round's mask piece: the lane's own row, a neighbour's once it runs past its row's end, none beyond the tile */
 			const uint64_t rr = lane + (rpos >> rsh);
 			const bool inside = rr < 64u;
 			const unsigned char *piece = mk + (((((uint32_t)rpos >> 7) & (rpr - 1u)) << 6) + (inside ? (uint32_t)rr : 0u)) * 16u;
 			/* beyond the tile: the distance from this round's first byte to the tail boundary (saturated) */
+			const bool beyond = __any(act && !inside);
 			uint32_t tb = 0xFFFFFFFFu;
-			if (__any(act && !inside)) {
+			if (beyond) {
 				const uint64_t d = tail - (((uint64_t)lane << rsh) + rpos);
 				if (!inside && d < 0xFFFFFFFFull) tb = (uint32_t)d;
 			}
 			for (uint32_t c = 0; c < 8u; c++) {
 				const u32x4 wc = {w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
 				uint32_t bm = inside ? (uint32_t)*reinterpret_cast<const uint16_t *>(piece + 2u * c) : 0u;
-				const uint32_t tx = tb - 16u * c;         /* wraps (no bit) once the tail lies before this chunk */
-				if (tx < 16u) bm |= 1u << tx;
+				if (beyond) {
+					const uint32_t tx = tb - 16u * c;     /* wraps (no bit) once the tail lies before this chunk */
+					if (tx < 16u) bm |= 1u << tx;
+				}
 				if (!act) bm = 0u;
 				if (!__any(bm != 0u)) {
 					/* no input ends or starts in this chunk in any lane: the policy's plain chunk step */
@@ -193,44 +222,63 @@ walk_packed(const WalkArgs a)
 				typename Pol::P pre[16];
 #pragma unroll
 				for (int k = 0; k < 16; k++) pre[k] = pre_of(pol, wc, k, 0);
-				const uint32_t prevc = Pol::code(st) >> CSH;   /* the state before the chunk's first byte: what an input ending there ends in */
+				/* the state before the chunk's first byte is what an input that ends there ends in: it sits just before the 16 codes */
+				const uint32_t prevc = Pol::code(st) >> CSH;
+				if (C16) *reinterpret_cast<uint16_t *>(cs + 14) = (uint16_t)prevc;
+				else *reinterpret_cast<uint32_t *>(cs + 12) = prevc;
 				uint32_t cd[16];
 #pragma unroll
 				for (int k = 0; k < 16; k++) {
-					st = pick(((bm >> k) & 1u) != 0u, start_s, st);
+					uint32_t rm = (uint32_t)__builtin_amdgcn_sbfe((int)bm, k, 1);   /* bit k of bm, sign-extended: v_bfe_i32 */
+					__asm__("" : "+v"(rm));   /* (no instruction: it only hides that rm is 0 or ~0, which turns the v_bfi_b32 below into a shift, a compare and a select) */
+					st = pk_reset(rm, start_s, st);
 					st = pol.next(st, pre[k]);
 					cd[k] = Pol::code(st) >> CSH;
 				}
 				if (C16) {
 					const u32x4 lo = {cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16), cd[4] | (cd[5] << 16), cd[6] | (cd[7] << 16)};
 					const u32x4 hi = {cd[8] | (cd[9] << 16), cd[10] | (cd[11] << 16), cd[12] | (cd[13] << 16), cd[14] | (cd[15] << 16)};
-					*reinterpret_cast<u32x4 *>(cs) = lo;
-					*reinterpret_cast<u32x4 *>(cs + 16) = hi;
+					*reinterpret_cast<u32x4 *>(cs + 16) = lo;
+					*reinterpret_cast<u32x4 *>(cs + 32) = hi;
 				} else {
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						const u32x4 x = {cd[4 * q], cd[4 * q + 1], cd[4 * q + 2], cd[4 * q + 3]};
-						*reinterpret_cast<u32x4 *>(cs + 16 * q) = x;
+						*reinterpret_cast<u32x4 *>(cs + 16 + 16 * q) = x;
 					}
 				}
 				/* every set bit k: the lane's input (if it is in one) ends with the state before byte k; its next one begins */
 				uint32_t m = bm;
-				while (__any(m != 0u)) {
-					if (m != 0u) {
-						const uint32_t k = (uint32_t)__builtin_ctz(m);
-						m &= m - 1u;
-						uint32_t code = prevc;
-						if (k != 0u) code = C16 ? (uint32_t)*reinterpret_cast<const uint16_t *>(cs + (k - 1u) * 2u)
-						                        : *reinterpret_cast<const uint32_t *>(cs + (k - 1u) * 4u);
-						if (cur != NONE && !(a.pk_debug & 1u)) codes_out[cur] = code << CSH;
-						cur = nxt;
-						nxt = nxt + 1u;
-						if (cur >= lim) {             /* that input starts in a later row: this lane is done */
-							cur = NONE;
-							act = false;
-							m = 0u;
-						} else if (emp) {
-							nxt = packed_skip_empty(kbits, nxt);
+				if (!emp) {
+					const uint32_t rm1 = rel - 1u;        /* bit r ends own input number rel + r, at index fst + rm1 + r */
+					for (uint32_t r = 0; __any(m != 0u); r++) {
+						if (m != 0u) {
+							const uint32_t k = (uint32_t)__builtin_ctz(m);
+							m &= m - 1u;
+							const uint32_t code = C16 ? (uint32_t)*reinterpret_cast<const uint16_t *>(cs + 14u + k * 2u)
+							                          : *reinterpret_cast<const uint32_t *>(cs + 12u + k * 4u);
+							if (rm1 + r < nl && !(a.pk_debug & 1u)) codes_out[fst + rm1 + r] = code << CSH;   /* (rel + r = 0: the bytes before the first own input) */
+						}
+					}
+					rel += (uint32_t)__builtin_popcount(bm);
+					act = act && rel <= nl;
+				} else {
+					while (__any(m != 0u)) {
+						if (m != 0u) {
+							const uint32_t k = (uint32_t)__builtin_ctz(m);
+							m &= m - 1u;
+							const uint32_t code = C16 ? (uint32_t)*reinterpret_cast<const uint16_t *>(cs + 14u + k * 2u)
+							                          : *reinterpret_cast<const uint32_t *>(cs + 12u + k * 4u);
+							if (cur != NONE && !(a.pk_debug & 1u)) codes_out[cur] = code << CSH;
+							cur = nxt;
+							nxt = nxt + 1u;
+							if (cur >= lim) {             /* that input starts in a later row: this lane is done */
+								cur = NONE;
+								act = false;
+								m = 0u;
+							} else {
+								nxt = packed_skip_empty(kbits, nxt);
+							}
 						}
 					}
 				}

@@ -28,14 +28,13 @@ __device__ __forceinline__ PackedParams packed_params(const WalkArgs &a)
 	p.nrows = (span >> rs) + 1u;
 	p.use = mean <= a.pk_mean_max && p.nrows <= a.pk_nvmax ? 1u : 0u;
 	p.has_empty = 0;
-	p.next_tile = 0;
-	for (int k = 0; k < 6; k++) p.pad[k] = 0;
+	for (int k = 0; k < 7; k++) p.pad[k] = 0;
 	return p;
 }
 
 /* first[v] = the first input whose first byte lies at or after row v's start (n if none), v = 0 .. nrows:
  * input j is that input for every row that starts in (start of j - 1, start of j].  Empty inputs get their result
- * here (the start state's code) and a bit in kbits[].  The scratch block's head (has_empty, next_tile) was zeroed
+ * here (the start state's code) and a bit in kbits[].  The scratch block's head (has_empty) was zeroed
  * on the stream before the launch. */
 __global__ void __launch_bounds__(256)
 packed_first(const WalkArgs a)

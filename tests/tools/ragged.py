@@ -54,7 +54,7 @@ def main():
                 if front == "rows" and dist != "uniform0-1024":
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
-                dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_WAVES, waves or int(os.environ.get("PK_WAVES", 0)))
                 for kn, ev in ((hip.KNOB_PK_RMIN, "PK_RMIN"), (hip.KNOB_PK_RMAX, "PK_RMAX"), (hip.KNOB_PK_MEAN_MAX, "PK_MEAN_MAX"), (hip.KNOB_PK_DEBUG, "PK_DEBUG")):
                     if os.environ.get(ev):
                         dfa.tune(kn, int(os.environ[ev]))

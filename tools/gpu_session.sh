@@ -15,8 +15,15 @@ for step in "$@"; do
 	        python tools/rocpd_top_kernels.py gpurun_out/${TAG}_pktrace >> gpurun_out/${TAG}_pktrace.txt 2>&1; rm -rf gpurun_out/${TAG}_pktrace; tail -12 gpurun_out/${TAG}_pktrace.txt
 	        timeout 600 python tools/pmc_kernel.py --match packed --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE" -- python tests/tools/ragged.py > gpurun_out/${TAG}_pkpmc.txt 2>&1; tail -70 gpurun_out/${TAG}_pkpmc.txt ;;
 	pkbisect) export RAGGED_N=6000000 RAGGED_DISTS=short8-64 RAGGED_CASES=c2:packed:4
-	        for dbg in 0 1 2 3 4 6 7 8 15; do echo "PK_DEBUG=$dbg"; PK_DEBUG=$dbg timeout 200 python tests/tools/ragged.py 2>&1 | grep "mode= 4 waves= 0"; done > gpurun_out/${TAG}_pkbisect.txt 2>&1; cat gpurun_out/${TAG}_pkbisect.txt ;;
+	        for dbg in ${PK_DBGS:-0 1 4 5}; do echo "PK_DEBUG=$dbg"; PK_DEBUG=$dbg timeout 200 python tests/tools/ragged.py 2>&1 | grep "mode= 4 waves= 0"; done > gpurun_out/${TAG}_pkbisect.txt 2>&1; cat gpurun_out/${TAG}_pkbisect.txt ;;
 	testr3dbg) FSM_HIP_DEBUG=2 timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s --timeout 500 -k length_distributions > gpurun_out/${TAG}_pytest_r3dbg.log 2>&1; grep -v "^  File\|^Extension" gpurun_out/${TAG}_pytest_r3dbg.log | tail -30 ;;
+	pksweep) export RAGGED_DISTS=short8-64 RAGGED_CASES=${PK_CASES:-c2:packed:4,c3:packed:4}
+	        SW=${PK_SWEEP:-6000000:16:0,6000000:12:9,6000000:16:8,6000000:8:10,24000000:16:0,24000000:12:9}
+	        for cfg in $(echo $SW | tr ',' ' '); do
+	            n=${cfg%%:*}; r=${cfg#*:}; w=${r%%:*}; x=${r#*:}
+	            echo "== n=$n waves=$w rmax=$x"; RAGGED_N=$n PK_WAVES=$w PK_RMAX=$x timeout 300 python tests/tools/ragged.py 2>&1 | grep "mode= 4 waves= 0"
+	        done > gpurun_out/${TAG}_pksweep.txt 2>&1; cat gpurun_out/${TAG}_pksweep.txt ;;
+	testgen) timeout 1200 python -m pytest tests -m gpu -x -q --timeout 600 -k "ragged or packed or batch_sizes or golden_vectors or fuzz or arena or unaligned or error_contracts or large_batch or resume or eager_outputs_golden or endids or c_program or retest_style" > gpurun_out/${TAG}_pytest_gen.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gen.log; grep -v "^  File\|^Extension" gpurun_out/${TAG}_pytest_gen.log | tail -25 ;;
 	testr2) timeout 900 python -m pytest tests/test_gpu_round2.py -m gpu -x -q > gpurun_out/${TAG}_pytest_r2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r2.log; tail -15 gpurun_out/${TAG}_pytest_r2.log ;;
 	bench)  timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.json ;;
 	fullpar) timeout 900 python bench.py --steps 5 --warmup 2 --subs none --full-parity > gpurun_out/${TAG}_bench_fullparity.json 2> gpurun_out/${TAG}_bench_fullparity.err; echo "fullparity rc=$?"; python -c "import json,sys; r=json.loads(open('gpurun_out/${TAG}_bench_fullparity.json').read().strip().splitlines()[-1]); print(r['value'], r.get('full_parity'))" ;;
