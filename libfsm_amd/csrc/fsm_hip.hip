@@ -431,9 +431,9 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* launch                                                             */
 /* ------------------------------------------------------------------ */
 
-/* per_lane: take walk_generic unless a knob says otherwise -- the batch may hold an input the ragged kernel's 32-bit
- * piece count cannot (>= 2^36 bytes), or it is fixed stride + lengths averaging < 96 bytes (walk_ragged works in
- * 128-byte segments: 0.7 vs 1.1-1.3 TB/s at 8-64 bytes).  Short PACKED inputs never get here: walk_packed takes them. */
+/* per_lane: take walk_generic unless a knob says otherwise -- the inputs average < 96 bytes (walk_ragged works in
+ * 128-byte segments: 0.7-1.2 vs 1.5-2.1 TB/s at 8-64 bytes, profiles/r03t_*); huge: the batch may hold an input the
+ * ragged kernel's 32-bit piece count cannot (>= 2^36 bytes) */
 static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false)
 {
 	LaunchCfg c;
@@ -449,7 +449,6 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* ragged / packed / unaligned inputs: the coalesced, lane-refilling kernel whenever at least four
 	 * waves' tiles and rings fit next to the table, else per-lane loads (walk_generic) */
 	const bool ragged_fits = d->table_lds + 4u * FSMHIP_RAGGED_WAVE_LDS <= d->lds_limit;
-	/* (short packed inputs never get here: walk_packed takes them, see launch_walk) */
 	int mode = ragged_fits && !per_lane && !huge ? IN_RAGGED : IN_GENERIC;
 	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits && !huge)) mode = d->knob_input_mode;
 	else if (fast_ok) {
@@ -510,7 +509,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 /* what a front knows about its batch beyond the arguments (host fronts: everything; device fronts: nothing) */
 struct BatchHint {
 	uint64_t bytes = 0;        /* total input bytes, 0 = unknown */
-	bool short_mean = false;   /* fixed stride + lengths averaging < 96 bytes */
+	bool short_mean = false;   /* the inputs average < 96 bytes */
 };
 
 /* the packed front's walk_packed: rows as long as the per-wave LDS bitmask may be with a full 16-wave workgroup behind
@@ -580,14 +579,18 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	if (d->knob_noskip > 0) a.early |= 4u;
 
-	/* Packed offsets (the retest / rx front), plain walk: walk_packed next to the ragged / generic kernel.  Which of the two
-	 * takes the batch is decided ON THE DEVICE from the mean input length (packed_first, walk_packed.h): a device-pointer
-	 * front cannot know off[n] without a synchronising copy.  The other kernel returns at once. */
+	/* Packed offsets (the retest / rx front).  Short inputs (mean < 96 bytes) walk fastest one per lane with per-lane
+	 * loads (walk_generic), long ones in 128-byte segments with lane refill (walk_ragged).  A host-pointer front knows the
+	 * mean; a device-pointer front cannot know off[n] without a synchronising copy, so BOTH kernels are launched and
+	 * a one-thread kernel decides on the device which of them returns at once (offsets_pick, walk_packed_aux.h).
+	 * walk_packed (a lane owns a byte range and walks across input boundaries) is opt-in, FSM_HIP_KNOB_INPUT_MODE = 4: it
+	 * measured slower than walk_generic at every length (profiles/r03s_*). */
 	LaunchCfg pc;
 	uint32_t pk_rmax = 0;
 	const bool packed = a.off != nullptr && eager == 0 && a.state_io == nullptr && a.n < 0xFFFFF000ull &&
-		(d->knob_input_mode < 0 || d->knob_input_mode == IN_PACKED) && packed_cfg(d, pc, pk_rmax);
-	const bool both = packed;   /* (IN_PACKED forced: any mean length goes to walk_packed, but packed_first may still refuse a batch whose rows first[] cannot hold) */
+		d->knob_input_mode == IN_PACKED && packed_cfg(d, pc, pk_rmax);
+	const bool both = packed;   /* packed_first may refuse a batch (rows that first[] cannot hold): the ragged / generic kernel stands by */
+	const bool pick = !packed && a.off != nullptr && known_bytes == 0 && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
 	uint32_t *scratch = nullptr;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
@@ -662,8 +665,33 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 			}
 		}
 	}
+	if (e == hipSuccess && pick) {
+		/* the device-side choice: the same block of scratch, event-guarded like the packed front's */
+		if (md->pk_scratch_ev == nullptr) e = hipEventCreateWithFlags(&md->pk_scratch_ev, hipEventDisableTiming);
+		if (e == hipSuccess && md->pk_scratch_busy && md->pk_scratch_stream != s) e = hipStreamWaitEvent(s, md->pk_scratch_ev, 0);
+		if (e == hipSuccess && md->pk_scratch == nullptr) {
+			e = hipMalloc((void **)&md->pk_scratch, (size_t)1 << 16);
+			if (e == hipSuccess) md->pk_scratch_bytes = (size_t)1 << 16;
+		}
+		if (e == hipSuccess) {
+			a.pk = reinterpret_cast<uint32_t *>(md->pk_scratch);
+			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(1), 0, s, a, 96u);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) {
+			/* short: walk_generic, which returns at once unless the flag says short (1) */
+			const LaunchCfg g = pick_cfg(d, false, a.stride, eager, true, false);
+			const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
+			WalkArgs ag = a;
+			ag.skip_flag = &reinterpret_cast<const PackedParams *>(md->pk_scratch)->use;
+			ag.skip_when = 0u;
+			e = launch_layout(d, eager, g, ag, dim3((unsigned)(gb0 < gcap ? gb0 : gcap)), dim3((unsigned)g.waves * 64u), s);
+			a.skip_flag = ag.skip_flag;
+			a.skip_when = 1u;   /* long: walk_ragged, below */
+		}
+	}
 	if (e == hipSuccess && (!packed || both)) {
-		if (both) a.skip_flag = &reinterpret_cast<const PackedParams *>(scratch)->use;
+		if (both) { a.skip_flag = &reinterpret_cast<const PackedParams *>(scratch)->use; a.skip_when = 1u; }
 		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
 		debug_stage(s, "walk (fixed stride / ragged / generic)");
 	}
@@ -675,7 +703,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		debug_stage(s, "packed_finish");
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
-	if (packed && md->pk_scratch_ev != nullptr) {
+	if ((packed || pick) && md->pk_scratch_ev != nullptr) {
 		const hipError_t e2 = hipEventRecord(md->pk_scratch_ev, s);
 		md->pk_scratch_stream = s;
 		md->pk_scratch_busy = true;
@@ -878,6 +906,8 @@ static int exec_host(const struct fsm_hip_dfa *d,
 		uint64_t sum = 0;
 		for (size_t i = 0; i < n; i++) sum += len[i];
 		hint.short_mean = sum / n < 96u;
+	} else if (off != nullptr) {
+		hint.short_mean = in_bytes / n < 96u;
 	}
 	if (off) {
 		if (exec_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,

@@ -101,8 +101,9 @@ struct WalkArgs {
 	uint32_t        pk_nvmax, pk_mean_max;
 	uint32_t        pk_debug;       /* measurement aid (FSM_HIP_KNOB_PK_DEBUG): 1 no result stores, 4 no input loads */
 	uint64_t        pk_lanes;       /* lanes of the resident grid: rows are sized to give each wavefront about four tiles */
-	/* walk_ragged / walk_generic launched next to walk_packed: return at once if *skip_flag != 0 */
+	/* two kernels launched for one batch, the choice made on the device: return at once if *skip_flag == skip_when */
 	const uint32_t *skip_flag;
+	uint32_t        skip_when;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu
@@ -1252,7 +1253,7 @@ template <class Pol, int MAXT = 1024>
 __global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
 {
-	if (a.skip_flag != nullptr && *a.skip_flag != 0u) return;   /* walk_packed took the batch */
+	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);
@@ -1403,7 +1404,7 @@ __global__ void __launch_bounds__(MAXT)
 walk_ragged(const WalkArgs a)
 {
 	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
-	if (a.skip_flag != nullptr && *a.skip_flag != 0u) return;   /* walk_packed took the batch */
+	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);

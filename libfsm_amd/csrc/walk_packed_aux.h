@@ -68,6 +68,15 @@ packed_first(const WalkArgs a)
 	}
 }
 
+/* the packed-offsets front without walk_packed: is the batch short (mean length below `threshold` bytes: per-lane
+ * loads, walk_generic) or long (128-byte segments with lane refill, walk_ragged)?  One thread; writes PackedParams::use
+ * (1 = short).  A device-pointer front cannot know off[n] without a synchronising copy. */
+__global__ void offsets_pick(const WalkArgs a, uint32_t threshold)
+{
+	PackedParams *out = reinterpret_cast<PackedParams *>(a.pk);
+	out->use = (a.off[a.n] - a.off[0]) / a.n < threshold ? 1u : 0u;
+}
+
 /* raw state codes -> the caller's results */
 __global__ void __launch_bounds__(256)
 packed_finish(const WalkArgs a)
