@@ -45,8 +45,8 @@ KNOB_NOSKIP = 13
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5"])
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
@@ -68,7 +68,10 @@ def parse():
                     help="measure the C multi-device front (fsm_hip_node_*: one replica + host thread per visible GPU, one process) "
                          "on the main workload and print its JSON; bench.py runs this by itself, in a subprocess, when N = 1 sees several GPUs")
     ap.add_argument("--full-parity", action="store_true",
-                    help="after timing, stream ALL inputs back and compare every end state with the threaded CPU table walker")
+                    help="(the default for the main workload at N = 1; kept for old command lines)")
+    ap.add_argument("--no-full-parity", action="store_true",
+                    help="skip the full-N check: after timing, ALL inputs of the main workload are streamed back and every end state is "
+                         "compared with the threaded CPU table walker (about 25 s at 1e8 x 1 KiB)")
     return ap.parse_args()
 
 
@@ -177,6 +180,69 @@ def sample_indices(n, sample):
     return idx[idx < n]
 
 
+def kernels_sha16():
+    """A recorded counter file speaks for the kernels it was taken from: sha256 of the device sources, first 16 hex digits
+    (tools/rocpd_summary.py stores it; a kernel edit makes bench.py drop `traffic` until tools/profile.sh is rerun)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("walk_kernels.h", "walk_packed.h", "launch.h"):
+        with open(os.path.join(ROOT, "libfsm_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def c5_reference_leg(hip):
+    """A reference-timed CPU figure beside C5.  At the bench's size (1e5 literals of 8-16 symbols: ~1e6 states) the
+    reference cannot be run in a benchmark's time (cpu_baseline.why_not_reference), so its own matchers are timed on the
+    largest literal set it builds in seconds: 1e5 literals of 4-8 letters, ~3e5 states (the automaton of
+    tests/test_gpu_parity.py::test_config5_aho_corasick_100k_literals): fsm_exec with the per-call isdfa sweep hoisted
+    (derived from exec.c, NOT the reference: the literal fsm_exec is ~3 s per call here) and VM v2, 1 thread; the HIP
+    path walks the same rows on the same automaton and must agree on every end state."""
+    import threading
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        return {"error": "oracle/_ref not built"}
+    rng = np.random.RandomState(5)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, 26, rng.randint(4, 9))]) for _ in range(100000)))
+    box = {}
+
+    def work():                       # ac.c recurses per trie node: needs a big stack
+        t0 = time.perf_counter()
+        box["f"] = pyoracle.RefFsm.re_strings(words, 0, True)
+        box["build_s"] = time.perf_counter() - t0
+        box["flat"] = box["f"].flatten()
+
+    threading.stack_size(1 << 30)
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    f, flat = box["f"], box["flat"]
+    nrows, L = 10000, 1024
+    rows = alpha[rng.randint(0, 26, (nrows, L))]
+    for i in range(0, nrows, 2):      # end half of the rows on a word so they accept
+        w = words[rng.randint(len(words))]
+        rows[i, L - len(w):] = np.frombuffer(w, np.uint8)
+    hret, hend = f.exec_hoisted_stride(rows)
+    t_ho = f.last_seconds
+    dfa = hip.HipDfa(flat)
+    got, _ = dfa.exec_batch(rows)
+    layout = dfa.info()["layout_name"]
+    dfa.close()
+    out = {"literals": len(words), "dfa_states": flat.nstates, "re_strings_seconds": round(box["build_s"], 1), "inputs": nrows, "input_len": L,
+           "fsm_exec_hoisted_value": round(nrows * L / 1e9 / t_ho, 5), "unit": "GB/s", "cores": 1,
+           "fsm_exec_hoisted_sample": "fsm_exec with the per-call fsm_all(fsm_isdfa) sweep of exec.c:106-109 removed (derived, NOT the reference), 1 thread",
+           "hip_layout": layout, "hip_vs_fsm_exec_hoisted": "bit-exact" if np.array_equal(got, hend) and int((hret == 1).sum()) >= nrows // 2 else "MISMATCH"}
+    if os.environ.get("FSM_BENCH_C5_VM", "1") != "0":
+        t0 = time.perf_counter()
+        vm = f.vm_match_stride(rows, 2)
+        out.update(vm_v2_value=round(nrows * L / 1e9 / f.last_seconds, 5), vm_v2_compile_seconds=round(time.perf_counter() - t0 - f.last_seconds, 1),
+                   vm_v2_sample="reference fsm_vm_compile + fsm_vm_match_buffer v2, 1 thread",
+                   vm_v2_vs_fsm_exec="agree" if np.array_equal(vm == 1, hret == 1) else "MISMATCH")
+    return out
+
+
 def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
     """Time the reference's CPU paths on the sampled rows (the very bytes the GPU walked, copied back from the
     device; rank 0, N = 1 only) and check the GPU's answers on them against it, bit for bit.
@@ -196,8 +262,15 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
             out["why_not_reference"] = ("at this size the reference's fsm_exec takes 3.7 s per 1 KiB input (fsm_all(fsm_isdfa) over ~1e6 states on "
                                         "every call, exec.c:106), re_strings 59 s + 7.5 GB to build the DFA and fsm_vm_compile 7 min + 15 GB "
                                         "(measured in the build container, DESIGN.md section 3); the reference is compared at 3e5 states in "
-                                        "tests/test_gpu_parity.py::test_config5_aho_corasick_100k_literals")
-        return out, bool(np.array_equal(gpu_end_sample, want))
+                                        "tests/test_gpu_parity.py::test_config5_aho_corasick_100k_literals and timed below")
+            try:
+                out["reference_at_3e5_states"] = c5_reference_leg(hip)
+            except Exception as e:  # noqa: BLE001
+                out["reference_at_3e5_states"] = {"error": repr(e)[:300]}
+        ok = bool(np.array_equal(gpu_end_sample, want))
+        if workload == "c5" and out["reference_at_3e5_states"].get("hip_vs_fsm_exec_hoisted") == "MISMATCH":
+            ok = False
+        return out, ok
     # the real reference, rebuilt as a struct fsm from its own regex sources
     if workload == "c2":
         f = pyoracle.RefFsm.re_comp("pcre", b"[Ll]ibf+(sm)*", 0, True, True, endid=0)
@@ -307,11 +380,21 @@ def node_front(a):
     for _ in range(a.steps):
         cnt = node.exec_batch_device(*args, want_count=True)
     el = time.perf_counter() - t0
+    per_dev_ms = [round(node.replica(k).last_kernel_ms(), 4) for k in range(len(devices))]
+    # the asynchronous form: two sets of bitmaps, step k's exchange under step k + 1's walk, one wait at the end
+    bms2 = [torch.zeros_like(m) for m in bms]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        node.exec_device(n, args[0], stride=L, d_end=args[3], d_bitmap_all=[m.data_ptr() for m in (bms if k % 2 == 0 else bms2)], want_count=True, async_=True)
+    cnt_async = node.wait(want_count=True)
+    el_async = time.perf_counter() - t0
     # every replica holds the whole bitmap; its popcount is the reduced match count
-    same = all(int(np.unpackbits(m.cpu().numpy().view(np.uint8)).sum()) == cnt for m in bms[:2])
+    same = all(int(np.unpackbits(m.cpu().numpy().view(np.uint8)).sum()) == cnt for m in bms[:2]) and cnt_async == cnt
     out = {"front": "fsm_hip_node_exec_batch_device (C ABI, one process, one host thread per device)", "devices": devices,
            "uses_rccl": node.uses_rccl(), "workload": wl, "inputs_total": n, "input_len": L, "steps": a.steps,
            "ms_per_step": round(el / a.steps * 1e3, 4), "value_GBps": round(n * L / (el / a.steps) / 1e9, 2),
+           "walk_kernel_ms_per_device": per_dev_ms,
+           "async_ms_per_step": round(el_async / a.steps * 1e3, 4), "async_value_GBps": round(n * L / (el_async / a.steps) / 1e9, 2),
            "accepted_inputs": int(cnt), "bitmap_popcount_matches_count_on_every_checked_replica": bool(same)}
     node.close()
     print(json.dumps(out), flush=True)
@@ -482,7 +565,7 @@ def main():
         if variant in (None, "loadskip") and os.path.exists(pj):
             try:
                 t = json.load(open(pj))
-                if int(t.get("n", 0)) == n_ and int(t.get("len", 0)) == L:
+                if int(t.get("n", 0)) == n_ and int(t.get("len", 0)) == L and t.get("kernels_sha16") == kernels_sha16():
                     traffic = t.get("hbm_bytes_per_launch")
                     traffic_source = (f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over this "
                                       f"workload at this size (kernel {str(t.get('kernel'))[:60]}); recorded, not measured in this run")
@@ -494,6 +577,11 @@ def main():
         if variant == "loadskip":
             text += ("per-lane load skip ON (a lane whose input can no longer change state stops reading it, as fsm_exec stops pulling bytes "
                      "at a missing edge: the rate counts the bytes MATCHED, fewer are touched -- roofline.early_retire), ")
+        # a kernel that does not fetch every byte (per-lane load skip) is priced on the bytes it TOUCHES; its rate over all
+        # the bytes it matched is reported beside it, under its own name
+        roof_bytes = alg_bytes
+        if variant == "loadskip":
+            roof_bytes = traffic if traffic else None
         res = {
             "value": round(value, 2), "ms_per_step": round(ms_step, 4),
             "config": {
@@ -505,8 +593,10 @@ def main():
                              if world > 1 else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "roofline": {"bound": "hbm" if wl != "c5" else "valu (divergent chain loop); HBM figures for uniformity",
+                         "achieved": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
@@ -516,12 +606,13 @@ def main():
         res["roofline"]["early_retire"] = {
             "enabled": True,   # the library default; FSM_HIP_NO_EARLY_RETIRE at create time switches it off
             "per_lane_load_skip": variant == "loadskip",
+            "matched_GBps": round(achieved, 2),   # algorithmic bytes (every input byte + 4) over the kernel time: what the caller sees
             "touched_bytes_per_launch": traffic,
             "touched_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
             "note": "HBM bytes per launch from the recorded PMC passes (reads + the 4-byte results): ~1.00 means every input byte was still fetched",
         }
         if wl == "c5":
-            res["roofline"]["note"] = ("this walk is bound by the instructions of its divergent chain loop, not by HBM (DESIGN.md section 3; "
+            res["roofline"]["note"] = ("this walk is bound by the instructions of its divergent chain loop, not by HBM (DESIGN.md section 3; profiles/r04*_c5_pmc*; "
                                        "profiles/r03j_c5_rocprof_summary.json: 0.33 L2 requests per input byte, 93.8 % hits, calibrated HBM traffic "
                                        "1.81x algorithmic): the fraction of HBM peak is reported for uniformity only")
         if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
@@ -539,7 +630,9 @@ def main():
             res["parity_sample"] = f"{len(idx)} inputs: seeded stratified sample of [0, {n_}) + first/last 64 rows" + (" + rows around byte offset 2^32" if n_ > (1 << 22) + 64 else "")
             if not (parity and twin):
                 res["value"] = None  # a fast wrong answer is not a result
-        if a.full_parity and world == 1 and wl != "c5":
+        # the full-N compare, for the main workload of a default run (c5's table walker would need the 8 GB dense
+        # table; its checks are the sample above and cpu_baseline.reference_at_3e5_states)
+        if world == 1 and wl != "c5" and (a.full_parity or (variant is None and wl == a.workload and not a.no_full_parity and with_cpu and not a.no_cpu_baseline)):
             res["full_parity"] = full_parity(torch, flat, buf, end, n_, L)
             if res["full_parity"]["mismatches"]:
                 res["value"] = None

@@ -156,7 +156,12 @@ int fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *dfa,
 
 /* Same as fsm_hip_exec_batch but every pointer is a DEVICE pointer on the
  * dfa's device and the launch is asynchronous on `hip_stream` (a hipStream_t
- * passed as void *, NULL = default stream).  Nothing crosses PCIe. */
+ * passed as void *, NULL = default stream).  Nothing crosses PCIe.
+ * CONTRACT of every *_device entry point: the metadata is the caller's to get right -- the host fronts check
+ * len[i] <= stride and off[i] <= off[i + 1], a device front cannot without a synchronising copy.  d_len[i] <= stride,
+ * d_off[] non-decreasing.  The kernels read an input 16 bytes at a time from its own first byte: up to 15 bytes past
+ * an input's end are READ (never past the batch's last byte, base + n * stride or base + d_off[n]), and the bytes
+ * between inputs (stride > len) must therefore be addressable.  Bad metadata is undefined behaviour, not EINVAL. */
 int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
@@ -258,6 +263,15 @@ int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
 	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
 
+/* the same over packed inputs (base + off[n + 1], as fsm_hip_exec_batch_offsets): the form retest / rx lines take
+ * (src/retest/main.c:1114) when a line arrives in pieces */
+int fsm_hip_exec_batch_resume_offsets(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *state_io, uint32_t *end_out);
+int fsm_hip_exec_batch_resume_offsets_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+
 /* ------------------------------------------------------------------ */
 /* end-ids delivered by the device (no host lookup per input)         */
 /* ------------------------------------------------------------------ */
@@ -292,6 +306,15 @@ int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
 	int mode, uint32_t *d_id_out, void *hip_stream);
 
+/* the same over packed inputs: what a generated rx matcher hands its caller per line -- the id(s) of the pattern(s)
+ * that matched (src/libfsm/print/c.c:569-619) -- for a whole file of lines in one launch */
+int fsm_hip_exec_batch_ids_offsets(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	int mode, uint32_t *id_out);
+int fsm_hip_exec_batch_ids_offsets_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	int mode, uint32_t *d_id_out, void *hip_stream);
+
 size_t fsm_hip_ret_count(const struct fsm_hip_dfa *dfa);
 
 /* Borrowed pointer to the sorted unique ids of set `ret_index` (valid until
@@ -310,13 +333,25 @@ int fsm_hip_ret_get(const struct fsm_hip_dfa *dfa, uint32_t ret_index,
  * bit set of W = fsm_hip_eager_words(dfa) 64-bit words (W = 1 for up to 64
  * distinct ids): bit k%64 of eager_out[i*W + k/64] <=> id fsm_hip_eager_id(dfa, k)
  * was emitted (ids numbered in ascending order).  eager_out holds n*W words.
- * end_out is as in fsm_hip_exec_batch. */
+ * end_out is as in fsm_hip_exec_batch.
+ * LIMIT: the result is a SET.  fsm_exec calls the callback once per state entered, in stream order, repeats
+ * included (exec.c:126-144); the order and the multiplicity of the emissions are not kept (the reference's own
+ * tests compare sets: tests/eager_output/utils.c:227-231).  A caller that needs the first-emission order of an
+ * input's ids must run that input through fsm_exec. */
 int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *eager_out);
 
 int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream);
+
+/* the same over packed inputs */
+int fsm_hip_exec_batch_eager_offsets(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *eager_out);
+int fsm_hip_exec_batch_eager_offsets_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint64_t *d_off, size_t n,
 	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream);
 
 size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *dfa);
@@ -370,6 +405,42 @@ size_t fsm_hip_node_bitmap_words(const struct fsm_hip_node *node, size_t n);
 int fsm_hip_node_exec_batch_device(struct fsm_hip_node *node,
 	const void *const *d_base, size_t stride, size_t n,
 	uint32_t *const *d_end_out, uint64_t *const *d_bitmap_all, uint64_t *match_count);
+
+/* The general device-resident form: every per-device array is indexed by replica k and lives on device k; unused
+ * members are NULL / 0 (memset the struct first).
+ *   d_base[k]            shard k's input bytes;
+ *   stride, d_len        fixed stride (+ optional lengths, d_len[k] = shard k's) -- or
+ *   d_off[k]             shard k's packed offsets, count + 1 of them, relative to d_base[k] (stride ignored);
+ *   d_end_out[k]         end states;  d_id_out[k] + ids_mode: end-ids as fsm_hip_exec_batch_ids;
+ *   d_eager_out[k]       eager-output sets as fsm_hip_exec_batch_eager;
+ *   d_bitmap_all[k]      the whole batch's accept bitmap on every device (all entries non-NULL), exchanged as above;
+ *   want_count           also reduce the number of accepted inputs (read by fsm_hip_node_wait).
+ * async = 0: returns after every device has finished, *match_count (optional) = accepted inputs.
+ * async = 1: returns once the work is enqueued (match_count must be NULL).  The exchange runs on a second stream per
+ * device, so the NEXT call's walk overlaps it -- provided that call uses other output buffers: alternate between two
+ * sets.  fsm_hip_node_wait() returns when everything enqueued has finished (*match_count, optional: the last call's,
+ * if it asked for one).  A failed call returns with nothing of it in flight. */
+struct fsm_hip_node_batch {
+	const void *const *d_base;
+	size_t stride;
+	const uint32_t *const *d_len;
+	const uint64_t *const *d_off;
+	uint32_t *const *d_end_out;
+	uint32_t *const *d_id_out;
+	int ids_mode;
+	uint64_t *const *d_eager_out;
+	uint64_t *const *d_bitmap_all;
+	int want_count;
+};
+int fsm_hip_node_exec_device(struct fsm_hip_node *node, const struct fsm_hip_node_batch *batch, size_t n,
+	uint64_t *match_count, int async);
+int fsm_hip_node_wait(struct fsm_hip_node *node, uint64_t *match_count);
+
+/* fsm_hip_exec_batch_ids / _eager over the whole node (host pointers; results land in the caller's arrays in place) */
+int fsm_hip_node_exec_batch_ids(struct fsm_hip_node *node,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, int mode, uint32_t *id_out);
+int fsm_hip_node_exec_batch_eager(struct fsm_hip_node *node,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, uint32_t *end_out, uint64_t *eager_out);
 
 /* ------------------------------------------------------------------ */
 /* synthetic input generator (benchmarks and parity tests)            */

@@ -504,6 +504,62 @@ class HipDfa:
         sets = [ids[row] for row in bits]
         return end, sets
 
+    # ---- the same three fronts over packed inputs (base + off[n + 1]) -----------
+    def exec_offsets_ids(self, base: np.ndarray, off: np.ndarray, mode: int) -> np.ndarray:
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        out = np.empty(n, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_ids_offsets(C.c_void_p(self._h), _ptr(base) if len(base) else None, _ptr(off), C.c_size_t(n),
+                                                    C.c_int(mode), _ptr(out)) != 0:
+            raise _oserr("fsm_hip_exec_batch_ids_offsets")
+        return out
+
+    def exec_offsets_resume(self, base: np.ndarray, off: np.ndarray, state_io: np.ndarray):
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        st = np.ascontiguousarray(state_io, dtype=np.uint32).copy()
+        end = np.empty(n, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_resume_offsets(C.c_void_p(self._h), _ptr(base) if len(base) else None, _ptr(off), C.c_size_t(n),
+                                                       _ptr(st), _ptr(end)) != 0:
+            raise _oserr("fsm_hip_exec_batch_resume_offsets")
+        return st, end
+
+    def exec_offsets_eager(self, base: np.ndarray, off: np.ndarray):
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        end = np.empty(n, dtype=np.uint32)
+        self._lib.fsm_hip_eager_words.restype = C.c_size_t
+        W = self._lib.fsm_hip_eager_words(C.c_void_p(self._h))
+        eo = np.zeros((n, W), dtype=np.uint64)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_eager_offsets(C.c_void_p(self._h), _ptr(base) if len(base) else None, _ptr(off), C.c_size_t(n),
+                                                      _ptr(end), _ptr(eo)) != 0:
+            raise _oserr("fsm_hip_exec_batch_eager_offsets")
+        self._lib.fsm_hip_eager_id_count.restype = C.c_size_t
+        self._lib.fsm_hip_eager_id.restype = C.c_uint32
+        k = self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h))
+        ids = np.array([self._lib.fsm_hip_eager_id(C.c_void_p(self._h), C.c_uint(b)) for b in range(k)], np.uint32)
+        bits = np.unpackbits(eo.view(np.uint8).reshape(n, W * 8), axis=1, bitorder="little")[:, :k].astype(bool)
+        return end, [ids[row] for row in bits]
+
+    def exec_offsets_device_front(self, what: str, d_base: int, d_off: int, n: int, d_out: int, d_aux: int = 0, mode: int = 1, stream: int = 0):
+        """The *_offsets_device entry points: what = 'ids' (d_out = ids), 'resume' (d_out = state_io, d_aux = end), 'eager' (d_out = end, d_aux = sets)."""
+        C.set_errno(0)
+        vp = C.c_void_p
+        if what == "ids":
+            r = self._lib.fsm_hip_exec_batch_ids_offsets_device(vp(self._h), vp(d_base), vp(d_off), C.c_size_t(n), C.c_int(mode), vp(d_out), vp(stream or None))
+        elif what == "resume":
+            r = self._lib.fsm_hip_exec_batch_resume_offsets_device(vp(self._h), vp(d_base), vp(d_off), C.c_size_t(n), vp(d_out), vp(d_aux or None), None, vp(stream or None))
+        else:
+            r = self._lib.fsm_hip_exec_batch_eager_offsets_device(vp(self._h), vp(d_base), vp(d_off), C.c_size_t(n), vp(d_out or None), vp(d_aux), vp(stream or None))
+        if r != 0:
+            raise _oserr("fsm_hip_exec_batch_%s_offsets_device" % what)
+
     def eager_id_count(self) -> int:
         self._lib.fsm_hip_eager_id_count.restype = C.c_size_t
         return int(self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h)))
@@ -641,6 +697,60 @@ class HipNode:
                                                     C.byref(cnt) if want_count else None) != 0:
             raise _oserr("fsm_hip_node_exec_batch_device")
         return int(cnt.value) if want_count else None
+
+
+class NodeBatch(C.Structure):
+    """struct fsm_hip_node_batch (include/fsm_hip.h)."""
+    _fields_ = [("d_base", C.POINTER(C.c_void_p)), ("stride", C.c_size_t), ("d_len", C.POINTER(C.c_void_p)), ("d_off", C.POINTER(C.c_void_p)),
+                ("d_end_out", C.POINTER(C.c_void_p)), ("d_id_out", C.POINTER(C.c_void_p)), ("ids_mode", C.c_int),
+                ("d_eager_out", C.POINTER(C.c_void_p)), ("d_bitmap_all", C.POINTER(C.c_void_p)), ("want_count", C.c_int)]
+
+
+def _node_exec_device(self, n: int, d_base, stride: int = 0, d_len=None, d_off=None, d_end=None, d_ids=None, ids_mode: int = 1,
+                      d_eager=None, d_bitmap_all=None, want_count: bool = False, async_: bool = False):
+    """fsm_hip_node_exec_device: per-device lists of device pointers (None entries allowed where the header allows them)."""
+    g = self.ndev
+
+    def arr(xs):
+        if xs is None:
+            return None
+        a = (C.c_void_p * g)(*[C.c_void_p(x or None) for x in xs])
+        keep.append(a)
+        return C.cast(a, C.POINTER(C.c_void_p))
+
+    keep = []
+    b = NodeBatch(arr(d_base), stride, arr(d_len), arr(d_off), arr(d_end), arr(d_ids), ids_mode, arr(d_eager), arr(d_bitmap_all), 1 if want_count else 0)
+    cnt = C.c_uint64(0)
+    C.set_errno(0)
+    if self._lib.fsm_hip_node_exec_device(C.c_void_p(self._h), C.byref(b), C.c_size_t(n), C.byref(cnt) if (want_count and not async_) else None,
+                                          C.c_int(1 if async_ else 0)) != 0:
+        raise _oserr("fsm_hip_node_exec_device")
+    return int(cnt.value) if (want_count and not async_) else None
+
+
+def _node_wait(self, want_count: bool = False):
+    cnt = C.c_uint64(0)
+    C.set_errno(0)
+    if self._lib.fsm_hip_node_wait(C.c_void_p(self._h), C.byref(cnt) if want_count else None) != 0:
+        raise _oserr("fsm_hip_node_wait")
+    return int(cnt.value) if want_count else None
+
+
+def _node_exec_batch_ids(self, data: np.ndarray, mode: int, lens: Optional[np.ndarray] = None) -> np.ndarray:
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n, stride = data.shape
+    out = np.empty(n, dtype=np.uint32)
+    if lens is not None:
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    C.set_errno(0)
+    if self._lib.fsm_hip_node_exec_batch_ids(C.c_void_p(self._h), _ptr(data), C.c_size_t(stride), _ptr(lens), C.c_size_t(n), C.c_int(mode), _ptr(out)) != 0:
+        raise _oserr("fsm_hip_node_exec_batch_ids")
+    return out
+
+
+HipNode.exec_device = _node_exec_device
+HipNode.wait = _node_wait
+HipNode.exec_batch_ids = _node_exec_batch_ids
 
 
 def _gen_args(alphabet, plant):

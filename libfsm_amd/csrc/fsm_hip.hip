@@ -1395,13 +1395,11 @@ fail:
 	return -1;
 }
 
-extern "C" int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dc,
-	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
-	int mode, uint32_t *d_id_out, void *hip_stream)
+static int ids_device(fsm_hip_dfa *d, const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	int mode, uint32_t *d_id_out, void *hip_stream, const BatchHint &hint)
 {
-	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
 	if (d == nullptr || d_id_out == nullptr || (mode != FSM_HIP_IDS_EARLIEST && mode != FSM_HIP_IDS_RET && mode != FSM_HIP_IDS_ERROR) ||
-	    (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	    (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	if (ensure_ids(d) != 0) return -1;
 	if (mode == FSM_HIP_IDS_ERROR) {
 		/* AMBIG_ERROR: an end state with more than one id is refused (print/c.c:67-72 fails the
@@ -1413,35 +1411,97 @@ extern "C" int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dc,
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
-	a.stride = stride;
-	a.len = d_len;
+	a.stride = d_off ? 0 : stride;
+	a.len = d_off ? nullptr : d_len;
+	a.off = d_off;
 	a.n = n;
 	a.fin2 = mode == FSM_HIP_IDS_EARLIEST ? d->d_fin_earliest : d->d_fin_ret;
 	a.out2 = d_id_out;
-	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream), hint);
+}
+
+extern "C" int fsm_hip_exec_batch_ids_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	int mode, uint32_t *d_id_out, void *hip_stream)
+{
+	return ids_device(const_cast<fsm_hip_dfa *>(dc), d_base, stride, d_len, nullptr, n, mode, d_id_out, hip_stream, BatchHint());
+}
+
+extern "C" int fsm_hip_exec_batch_ids_offsets_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	int mode, uint32_t *d_id_out, void *hip_stream)
+{
+	if (n != 0 && d_off == nullptr) { errno = EINVAL; return -1; }
+	return ids_device(const_cast<fsm_hip_dfa *>(dc), d_base, 0, nullptr, d_off, n, mode, d_id_out, hip_stream, BatchHint());
+}
+
+/* what the host fronts know about their batch (launch_walk picks the kernel from it) */
+static BatchHint host_hint(size_t in_bytes, const uint32_t *len, const uint64_t *off, size_t n)
+{
+	BatchHint hint;
+	hint.bytes = in_bytes;
+	if (n == 0) return hint;
+	if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
+		uint64_t sum = 0;
+		for (size_t i = 0; i < n; i++) sum += len[i];
+		hint.short_mean = sum / n < 96u;
+	} else if (off != nullptr) {
+		hint.short_mean = in_bytes / n < 96u;
+	}
+	return hint;
+}
+
+static int check_host_batch(const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n, size_t *in_bytes)
+{
+	if (off != nullptr) {
+		for (size_t i = 0; i < n; i++)
+			if (off[i + 1] < off[i]) return -1;
+		*in_bytes = n ? (size_t)off[n] : 0;
+		if (*in_bytes != 0 && base == nullptr) return -1;
+		return 0;
+	}
+	if (n != 0 && base == nullptr && stride != 0) return -1;
+	if (len != nullptr)
+		for (size_t i = 0; i < n; i++)
+			if (len[i] > stride) return -1;
+	*in_bytes = n * stride;
+	return 0;
+}
+
+static int ids_host(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n,
+	int mode, uint32_t *id_out)
+{
+	size_t in_bytes = 0;
+	if (d == nullptr || id_out == nullptr || check_host_batch(base, stride, len, off, n, &in_bytes) != 0) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	if (ids_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n, mode,
+	               hc.dev<uint32_t>(p_out), hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	return hc.end();
 }
 
 extern "C" int fsm_hip_exec_batch_ids(const struct fsm_hip_dfa *d,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	int mode, uint32_t *id_out)
 {
-	if (d == nullptr || id_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
-	if (n == 0) return 0;
-	if (len != nullptr)
-		for (size_t i = 0; i < n; i++)
-			if (len[i] > stride) { errno = EINVAL; return -1; }
-	DevGuard dg(d->device);
-	if (!dg.ok()) { errno = ENODEV; return -1; }
-	HostCall hc(d);
-	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
-	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
-	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
-	if (hc.begin() != 0) return -1;
-	if (fsm_hip_exec_batch_ids_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n, mode,
-	                                  hc.dev<uint32_t>(p_out), hc.d->hs) != 0) return -1;
-	return hc.end();
+	return ids_host(d, base, stride, len, nullptr, n, mode, id_out);
+}
+
+extern "C" int fsm_hip_exec_batch_ids_offsets(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	int mode, uint32_t *id_out)
+{
+	if (n != 0 && off == nullptr) { errno = EINVAL; return -1; }
+	return ids_host(d, base, 0, nullptr, off, n, mode, id_out);
 }
 
 extern "C" int fsm_hip_ids_conflict(const struct fsm_hip_dfa *dc, fsm_state_t *state)
@@ -1507,19 +1567,18 @@ extern "C" int fsm_hip_state_is_absorbing(const struct fsm_hip_dfa *d, uint32_t 
 	return d->plan.old2new[state] >= d->plan.abs_min ? 1 : 0;
 }
 
-extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
-	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
-	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+static int resume_device(fsm_hip_dfa *d, const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
 {
-	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
-	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	if (ensure_resume(d) != 0) return -1;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
-	a.stride = stride;
-	a.len = d_len;
+	a.stride = d_off ? 0 : stride;
+	a.len = d_off ? nullptr : d_len;
+	a.off = d_off;
 	a.n = n;
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
@@ -1527,31 +1586,59 @@ extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
 	a.enc_of = d->d_enc_of;
 	a.orig_of = d->d_orig_of;
 	a.nstates = d->plan.nstates;
-	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream), hint);
+}
+
+extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	return resume_device(const_cast<fsm_hip_dfa *>(dc), d_base, stride, d_len, nullptr, n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+extern "C" int fsm_hip_exec_batch_resume_offsets_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	if (n != 0 && d_off == nullptr) { errno = EINVAL; return -1; }
+	return resume_device(const_cast<fsm_hip_dfa *>(dc), d_base, 0, nullptr, d_off, n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+static int resume_host(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n,
+	uint32_t *state_io, uint32_t *end_out)
+{
+	size_t in_bytes = 0;
+	if (d == nullptr || state_io == nullptr || check_host_batch(base, stride, len, off, n, &in_bytes) != 0) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_st = hc.add(HostCall::INOUT, state_io, state_io, n * sizeof(uint32_t));
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	if (resume_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
+	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	return hc.end();
 }
 
 extern "C" int fsm_hip_exec_batch_resume(const struct fsm_hip_dfa *d,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *state_io, uint32_t *end_out)
 {
-	if (d == nullptr || state_io == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
-	if (n == 0) return 0;
-	if (len != nullptr)
-		for (size_t i = 0; i < n; i++)
-			if (len[i] > stride) { errno = EINVAL; return -1; }
-	DevGuard dg(d->device);
-	if (!dg.ok()) { errno = ENODEV; return -1; }
-	HostCall hc(d);
-	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
-	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
-	const int p_st = hc.add(HostCall::INOUT, state_io, state_io, n * sizeof(uint32_t));
-	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
-	if (hc.begin() != 0) return -1;
-	if (fsm_hip_exec_batch_resume_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-	                                     hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs) != 0) return -1;
-	return hc.end();
+	return resume_host(d, base, stride, len, nullptr, n, state_io, end_out);
+}
+
+extern "C" int fsm_hip_exec_batch_resume_offsets(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *state_io, uint32_t *end_out)
+{
+	if (n != 0 && off == nullptr) { errno = EINVAL; return -1; }
+	return resume_host(d, base, 0, nullptr, off, n, state_io, end_out);
 }
 
 /* ------------------------------------------------------------------ */
@@ -1574,18 +1661,18 @@ extern "C" uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *d, unsigned bit)
 	return d->plan.eager_ids[bit];
 }
 
-extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
-	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
-	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream)
+static int eager_device(const struct fsm_hip_dfa *d, const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream, const BatchHint &hint)
 {
-	if (d == nullptr || d_eager_out == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (d == nullptr || d_eager_out == nullptr || (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	if (d->plan.emask.empty()) {
 		/* no state emits anything: the answer is all zeros, the walk is the plain one */
 		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
 		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
-		return fsm_hip_exec_batch_device(d, d_base, stride, d_len, n, d_end_out, nullptr, hip_stream);
+		if (d_off != nullptr) return exec_offsets_device(d, d_base, d_off, n, d_end_out, nullptr, hip_stream, hint);
+		return exec_stride_device(d, d_base, stride, d_len, n, d_end_out, nullptr, hip_stream, hint);
 	}
 	if (d->plan.eager_words > 1) {
 		/* wide sets are OR-ed in place by the kernel: start from zero */
@@ -1594,34 +1681,63 @@ extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
 	}
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
-	a.stride = stride;
-	a.len = d_len;
+	a.stride = d_off ? 0 : stride;
+	a.len = d_off ? nullptr : d_len;
+	a.off = d_off;
 	a.n = n;
 	a.end_out = d_end_out;
 	a.eager_out = d_eager_out;
-	const bool fast = d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream));
+	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream), hint);
+}
+
+extern "C" int fsm_hip_exec_batch_eager_device(const struct fsm_hip_dfa *d,
+	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	return eager_device(d, d_base, stride, d_len, nullptr, n, d_end_out, d_eager_out, hip_stream, BatchHint());
+}
+
+extern "C" int fsm_hip_exec_batch_eager_offsets_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	if (n != 0 && d_off == nullptr) { errno = EINVAL; return -1; }
+	return eager_device(d, d_base, 0, nullptr, d_off, n, d_end_out, d_eager_out, hip_stream, BatchHint());
+}
+
+static int eager_host(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *eager_out)
+{
+	size_t in_bytes = 0;
+	if (d == nullptr || eager_out == nullptr || check_host_batch(base, stride, len, off, n, &in_bytes) != 0) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
+	if (hc.begin() != 0) return -1;
+	if (eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
+	                 hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	return hc.end();
 }
 
 extern "C" int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *d,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *eager_out)
 {
-	if (d == nullptr || eager_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
-	if (n == 0) return 0;
-	if (len != nullptr)
-		for (size_t i = 0; i < n; i++)
-			if (len[i] > stride) { errno = EINVAL; return -1; }
-	DevGuard dg(d->device);
-	if (!dg.ok()) { errno = ENODEV; return -1; }
-	HostCall hc(d);
-	const int p_in = hc.add(HostCall::IN, base, nullptr, n * stride, 32);
-	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
-	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
-	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
-	if (hc.begin() != 0) return -1;
-	if (fsm_hip_exec_batch_eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
-	                                    hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs) != 0) return -1;
-	return hc.end();
+	return eager_host(d, base, stride, len, nullptr, n, end_out, eager_out);
+}
+
+extern "C" int fsm_hip_exec_batch_eager_offsets(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *eager_out)
+{
+	if (n != 0 && off == nullptr) { errno = EINVAL; return -1; }
+	return eager_host(d, base, 0, nullptr, off, n, end_out, eager_out);
 }

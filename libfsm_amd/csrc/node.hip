@@ -22,6 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -57,14 +60,52 @@ static void rccl_resolve()
 	R.state = R.CommInitAll && R.CommDestroy && R.AllGather && R.AllReduce && R.GroupStart && R.GroupEnd ? 1 : -1;
 }
 
+/* one parked host thread per device (but device 0's shard, which the calling thread drives): created with the node,
+ * woken per call -- a batch of a few thousand inputs is a 20 us walk, a thread spawn + join per call was longer */
+struct node_worker {
+	std::thread th;
+	std::mutex m;
+	std::condition_variable cv;
+	const std::function<int(int)> *job = nullptr;
+	int err = 0;
+	bool done = true, quit = false;
+};
+
 struct fsm_hip_node {
 	std::vector<int> dev;
 	std::vector<fsm_hip_dfa *> dfa;
-	std::vector<hipStream_t> stream;
+	std::vector<hipStream_t> stream;             /* per device: the walk */
+	std::vector<hipStream_t> cstream;            /* per device: the collective of an asynchronous call */
+	std::vector<hipEvent_t> walked;              /* per device: walk done -> collective may start */
+	std::vector<hipEvent_t> gathered;            /* per device and slot [2k + slot]: that call's collective is done */
 	std::vector<unsigned long long *> d_count;   /* one u64 per device */
 	std::vector<ncclComm_t> comm;                /* empty: exchange by peer copies */
+	std::vector<std::unique_ptr<node_worker>> workers;   /* [k] drives device k, k >= 1 */
+	int aslot = 0;                               /* which of the two count slots / gathered events the next call uses */
+	bool async_pending = false;                  /* an asynchronous call's collective may still be running */
+	bool async_count = false;                    /* ... and it reduces a match count into d_count[] */
 	std::mutex mu;                               /* one batch at a time per node */
 };
+
+static void worker_main(fsm_hip_node *nd, size_t k)
+{
+	node_worker &w = *nd->workers[k];
+	(void)hipSetDevice(nd->dev[k]);
+	std::unique_lock<std::mutex> lk(w.m);
+	for (;;) {
+		w.cv.wait(lk, [&] { return w.quit || w.job != nullptr; });
+		if (w.quit) return;
+		const std::function<int(int)> *job = w.job;
+		lk.unlock();
+		errno = 0;
+		const int e = (*job)((int)k) != 0 ? (errno ? errno : EIO) : 0;
+		lk.lock();
+		w.err = e;
+		w.job = nullptr;
+		w.done = true;
+		w.cv.notify_all();
+	}
+}
 
 /* accepted inputs of a bitmap slice: one atomic per wavefront */
 __global__ void __launch_bounds__(256)
@@ -82,10 +123,24 @@ extern "C" void fsm_hip_node_free(struct fsm_hip_node *nd)
 	if (nd == nullptr) return;
 	int prev = -1;
 	(void)hipGetDevice(&prev);
+	for (auto &w : nd->workers) {
+		if (!w) continue;
+		{ std::lock_guard<std::mutex> lk(w->m); w->quit = true; }
+		w->cv.notify_all();
+		if (w->th.joinable()) w->th.join();
+	}
+	for (size_t k = 0; k < nd->dev.size(); k++) {          /* an asynchronous call may still be in flight */
+		(void)hipSetDevice(nd->dev[k]);
+		if (k < nd->stream.size() && nd->stream[k]) (void)hipStreamSynchronize(nd->stream[k]);
+		if (k < nd->cstream.size() && nd->cstream[k]) (void)hipStreamSynchronize(nd->cstream[k]);
+	}
 	for (size_t k = 0; k < nd->comm.size(); k++)
 		if (nd->comm[k] != nullptr) (void)R.CommDestroy(nd->comm[k]);
 	for (size_t k = 0; k < nd->dev.size(); k++) {
 		(void)hipSetDevice(nd->dev[k]);
+		if (k < nd->cstream.size() && nd->cstream[k]) (void)hipStreamDestroy(nd->cstream[k]);
+		if (k < nd->walked.size() && nd->walked[k]) (void)hipEventDestroy(nd->walked[k]);
+		for (size_t q = 2 * k; q < 2 * k + 2 && q < nd->gathered.size(); q++) if (nd->gathered[q]) (void)hipEventDestroy(nd->gathered[q]);
 		if (k < nd->stream.size() && nd->stream[k]) (void)hipStreamDestroy(nd->stream[k]);
 		if (k < nd->d_count.size() && nd->d_count[k]) (void)hipFree(nd->d_count[k]);
 		if (k < nd->dfa.size()) fsm_hip_dfa_free(nd->dfa[k]);
@@ -120,11 +175,28 @@ extern "C" struct fsm_hip_node *fsm_hip_node_create(const struct fsm_hip_dfa_des
 		nd->dfa.push_back(d);
 		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { err = EIO; break; }
 		nd->stream.push_back(s);
+		hipStream_t cs = nullptr;
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { err = EIO; break; }
+		nd->cstream.push_back(cs);
+		if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess) { err = EIO; break; }
+		nd->walked.push_back(e0);
+		if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) { err = EIO; break; }
+		nd->gathered.push_back(e1);
+		e1 = nullptr;
+		if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) { err = EIO; break; }
+		nd->gathered.push_back(e1);
 		if (hipMalloc((void **)&c, 16) != hipSuccess) { err = ENOMEM; break; }
 		nd->d_count.push_back(c);
 	}
 	if (prev >= 0) (void)hipSetDevice(prev);
 	if (err != 0) { fsm_hip_node_free(nd); errno = err; return nullptr; }
+	nd->workers.resize(nd->dev.size());
+	for (size_t k = 1; k < nd->dev.size(); k++) {
+		nd->workers[k].reset(new (std::nothrow) node_worker());
+		if (!nd->workers[k]) { fsm_hip_node_free(nd); errno = ENOMEM; return nullptr; }
+		nd->workers[k]->th = std::thread(worker_main, nd, k);
+	}
 	/* RCCL communicators: only for a list of distinct devices */
 	bool distinct = true;
 	for (size_t i = 0; i < nd->dev.size(); i++)
@@ -174,21 +246,24 @@ extern "C" void fsm_hip_node_shard(const struct fsm_hip_node *nd, size_t n, int 
 	if (count) *count = c;
 }
 
-/* run fn(k) on one host thread per device; returns 0 or the first errno */
-template <class F>
-static int per_device(fsm_hip_node *nd, F fn)
+/* run fn(k) on device k's parked thread (k >= 1) and fn(0) on the calling thread; returns 0 or the first errno */
+static int per_device(fsm_hip_node *nd, const std::function<int(int)> &fn)
 {
 	const size_t g = nd->dev.size();
-	std::vector<int> err(g, 0);
-	std::vector<std::thread> th;
-	th.reserve(g);
-	for (size_t k = 1; k < g; k++)
-		th.emplace_back([&, k] { errno = 0; if (fn((int)k) != 0) err[k] = errno ? errno : EIO; });
+	for (size_t k = 1; k < g; k++) {
+		node_worker &w = *nd->workers[k];
+		{ std::lock_guard<std::mutex> lk(w.m); w.err = 0; w.done = false; w.job = &fn; }
+		w.cv.notify_all();
+	}
 	errno = 0;
-	if (fn(0) != 0) err[0] = errno ? errno : EIO;   /* shard 0 on the calling thread */
-	for (auto &t : th) t.join();
-	for (size_t k = 0; k < g; k++)
-		if (err[k] != 0) { errno = err[k]; return -1; }
+	int first = fn(0) != 0 ? (errno ? errno : EIO) : 0;   /* shard 0 on the calling thread */
+	for (size_t k = 1; k < g; k++) {
+		node_worker &w = *nd->workers[k];
+		std::unique_lock<std::mutex> lk(w.m);
+		w.cv.wait(lk, [&] { return w.done; });
+		if (first == 0 && w.err != 0) first = w.err;
+	}
+	if (first != 0) { errno = first; return -1; }
 	return 0;
 }
 
@@ -231,82 +306,197 @@ extern "C" int fsm_hip_node_exec_batch_offsets(struct fsm_hip_node *nd,
 	});
 }
 
+/* accepted inputs of the whole batch after an exchange: device 0's reduced count (RCCL) or the sum of the devices' */
+static int read_count(fsm_hip_node *nd, int slot, unsigned long long *total)
+{
+	const size_t g = nd->dev.size();
+	*total = 0;
+	for (size_t k = 0; k < (nd->comm.empty() ? g : 1); k++) {
+		unsigned long long c = 0;
+		(void)hipSetDevice(nd->dev[k]);
+		if (hipMemcpy(&c, nd->d_count[k] + slot, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+		*total += c;
+	}
+	return 0;
+}
+
+static int sync_all(fsm_hip_node *nd)
+{
+	bool ok = true;
+	for (size_t k = 0; k < nd->dev.size(); k++) {
+		(void)hipSetDevice(nd->dev[k]);
+		ok = hipStreamSynchronize(nd->stream[k]) == hipSuccess && ok;
+		ok = hipStreamSynchronize(nd->cstream[k]) == hipSuccess && ok;
+	}
+	return ok ? 0 : -1;
+}
+
+extern "C" int fsm_hip_node_wait(struct fsm_hip_node *nd, uint64_t *match_count)
+{
+	if (nd == nullptr) { errno = EINVAL; return -1; }
+	std::lock_guard<std::mutex> lk(nd->mu);
+	int prev = -1, rc = 0;
+	(void)hipGetDevice(&prev);
+	if (sync_all(nd) != 0) { errno = EIO; rc = -1; }
+	if (rc == 0 && match_count != nullptr) {
+		unsigned long long t = 0;
+		if (!nd->async_pending || !nd->async_count) { errno = EINVAL; rc = -1; }       /* nothing counted */
+		else if (read_count(nd, nd->aslot ^ 1, &t) != 0) { errno = EIO; rc = -1; }
+		else *match_count = t;
+	}
+	nd->async_pending = false;
+	if (prev >= 0) (void)hipSetDevice(prev);
+	return rc;
+}
+
+extern "C" int fsm_hip_node_exec_device(struct fsm_hip_node *nd, const struct fsm_hip_node_batch *b, size_t n,
+	uint64_t *match_count, int async)
+{
+	if (nd == nullptr || b == nullptr || b->d_base == nullptr || (b->d_off == nullptr && b->stride == 0) ||
+	    (b->d_off != nullptr && b->d_len != nullptr) || ((match_count != nullptr || b->want_count) && b->d_bitmap_all == nullptr) ||
+	    (b->d_id_out != nullptr && b->ids_mode != FSM_HIP_IDS_EARLIEST && b->ids_mode != FSM_HIP_IDS_RET && b->ids_mode != FSM_HIP_IDS_ERROR) ||
+	    (async && match_count != nullptr)) { errno = EINVAL; return -1; }
+	const size_t g = nd->dev.size();
+	if (b->d_bitmap_all != nullptr)
+		for (size_t k = 0; k < g; k++)
+			if (b->d_bitmap_all[k] == nullptr) { errno = EINVAL; return -1; }   /* every device takes part in the exchange */
+	if (n == 0) { if (match_count) *match_count = 0; return 0; }
+	std::lock_guard<std::mutex> lk(nd->mu);
+	const size_t wpd = words_per_dev(nd, n);
+	const bool count = match_count != nullptr || b->want_count;
+	const int slot = nd->aslot;
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	/* 1. every device walks its shard on its own stream, driven by its own host thread */
+	int rc = per_device(nd, [&](int k) -> int {
+		size_t first, cnt;
+		fsm_hip_node_shard(nd, n, k, &first, &cnt);
+		if (hipSetDevice(nd->dev[(size_t)k]) != hipSuccess) { errno = ENODEV; return -1; }
+		hipStream_t s = nd->stream[(size_t)k];
+		/* this slot's buffers were last used two asynchronous calls ago: their collective must be over */
+		if (hipStreamWaitEvent(s, nd->gathered[2 * (size_t)k + (size_t)slot], 0) != hipSuccess) { errno = EIO; return -1; }
+		uint64_t *slice = b->d_bitmap_all ? b->d_bitmap_all[k] + (size_t)k * wpd : nullptr;
+		if (slice != nullptr && cnt < wpd * 64 &&
+		    hipMemsetAsync(slice, 0, wpd * sizeof(uint64_t), s) != hipSuccess) { errno = EIO; return -1; }
+		fsm_hip_dfa *d = nd->dfa[(size_t)k];
+		uint32_t *e_out = b->d_end_out ? b->d_end_out[k] : nullptr;
+		if (cnt != 0) {
+			int r = 0;
+			if (b->d_eager_out != nullptr && b->d_eager_out[k] != nullptr) {
+				if (b->d_off != nullptr) r = fsm_hip_exec_batch_eager_offsets_device(d, b->d_base[k], b->d_off[k], cnt, e_out, b->d_eager_out[k], s);
+				else r = fsm_hip_exec_batch_eager_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, e_out, b->d_eager_out[k], s);
+				e_out = nullptr;   /* delivered */
+			}
+			if (r == 0 && b->d_id_out != nullptr && b->d_id_out[k] != nullptr) {
+				if (b->d_off != nullptr) r = fsm_hip_exec_batch_ids_offsets_device(d, b->d_base[k], b->d_off[k], cnt, b->ids_mode, b->d_id_out[k], s);
+				else r = fsm_hip_exec_batch_ids_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, b->ids_mode, b->d_id_out[k], s);
+			}
+			if (r == 0 && (e_out != nullptr || slice != nullptr)) {
+				if (b->d_off != nullptr) r = fsm_hip_exec_batch_offsets_device(d, b->d_base[k], b->d_off[k], cnt, e_out, slice, s);
+				else r = fsm_hip_exec_batch_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, e_out, slice, s);
+			}
+			if (r != 0) return -1;
+		}
+		if (count) {
+			if (hipMemsetAsync(nd->d_count[(size_t)k] + slot, 0, sizeof(unsigned long long), s) != hipSuccess) { errno = EIO; return -1; }
+			hipLaunchKernelGGL(count_bits_kernel, dim3(256), dim3(256), 0, s, slice, (uint64_t)wpd, nd->d_count[(size_t)k] + slot);
+			if (hipGetLastError() != hipSuccess) { errno = EIO; return -1; }
+		}
+		if (hipEventRecord(nd->walked[(size_t)k], s) != hipSuccess) { errno = EIO; return -1; }
+		return 0;
+	});
+	const int rc_errno = errno;
+	/* 2. the only exchange, on the devices' second streams (an asynchronous call's exchange runs under the next call's
+	 * walk): every device gets every slice of the bitmap; the counts are summed */
+	bool ok = rc == 0;
+	for (size_t k = 0; k < g && ok; k++) {
+		(void)hipSetDevice(nd->dev[k]);
+		ok = hipStreamWaitEvent(nd->cstream[k], nd->walked[k], 0) == hipSuccess;
+	}
+	if (ok && !nd->comm.empty()) {
+		if (b->d_bitmap_all != nullptr) {
+			ok = ok && R.GroupStart() == 0;
+			for (size_t k = 0; k < g && ok; k++)
+				ok = R.AllGather(b->d_bitmap_all[k] + k * wpd, b->d_bitmap_all[k], wpd, 5 /* ncclUint64 */, nd->comm[k], nd->cstream[k]) == 0;
+			ok = R.GroupEnd() == 0 && ok;
+		}
+		if (ok && count) {
+			ok = ok && R.GroupStart() == 0;
+			for (size_t k = 0; k < g && ok; k++)
+				ok = R.AllReduce(nd->d_count[k] + slot, nd->d_count[k] + slot, 1, 5 /* ncclUint64 */, 0 /* ncclSum */, nd->comm[k], nd->cstream[k]) == 0;
+			ok = R.GroupEnd() == 0 && ok;
+		}
+	} else if (ok && b->d_bitmap_all != nullptr) {
+		/* no RCCL (or a device list with repeats): the same exchange as peer-to-peer copies of the slices */
+		for (size_t k = 0; k < g && ok; k++) {
+			(void)hipSetDevice(nd->dev[k]);
+			for (size_t j = 0; j < g && ok; j++) {
+				if (j == k || b->d_bitmap_all[j] == b->d_bitmap_all[k]) continue;
+				ok = hipMemcpyPeerAsync(b->d_bitmap_all[j] + k * wpd, nd->dev[j], b->d_bitmap_all[k] + k * wpd, nd->dev[k], wpd * sizeof(uint64_t), nd->cstream[k]) == hipSuccess;
+			}
+		}
+	}
+	for (size_t k = 0; k < g && ok; k++) {
+		(void)hipSetDevice(nd->dev[k]);
+		ok = hipEventRecord(nd->gathered[2 * k + (size_t)slot], nd->cstream[k]) == hipSuccess;
+	}
+	nd->aslot ^= 1;
+	nd->async_pending = true;
+	nd->async_count = count;
+	unsigned long long total = 0;
+	if (!ok || !async) {
+		/* a failed call, like a synchronous one, returns with nothing in flight: the caller may free its buffers */
+		if (sync_all(nd) != 0) ok = false;
+		nd->async_pending = false;
+		if (ok && match_count != nullptr && read_count(nd, slot, &total) != 0) ok = false;
+	}
+	if (prev >= 0) (void)hipSetDevice(prev);
+	if (!ok) { errno = rc != 0 && rc_errno ? rc_errno : EIO; return -1; }
+	if (match_count != nullptr) *match_count = total;
+	return 0;
+}
+
 extern "C" int fsm_hip_node_exec_batch_device(struct fsm_hip_node *nd,
 	const void *const *d_base, size_t stride, size_t n,
 	uint32_t *const *d_end_out, uint64_t *const *d_bitmap_all, uint64_t *match_count)
 {
-	if (nd == nullptr || d_base == nullptr || stride == 0 || (match_count != nullptr && d_bitmap_all == nullptr)) { errno = EINVAL; return -1; }
-	if (n == 0) { if (match_count) *match_count = 0; return 0; }
+	struct fsm_hip_node_batch b;
+	memset(&b, 0, sizeof b);
+	b.d_base = d_base;
+	b.stride = stride;
+	b.d_end_out = d_end_out;
+	b.d_bitmap_all = d_bitmap_all;
+	if (nd == nullptr || d_base == nullptr || stride == 0) { errno = EINVAL; return -1; }
+	return fsm_hip_node_exec_device(nd, &b, n, match_count, 0);
+}
+
+/* host-pointer ids / eager over the whole node: every device's own host front on its shard, results in place */
+extern "C" int fsm_hip_node_exec_batch_ids(struct fsm_hip_node *nd,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, int mode, uint32_t *id_out)
+{
+	if (nd == nullptr || id_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
 	std::lock_guard<std::mutex> lk(nd->mu);
-	const size_t g = nd->dev.size(), wpd = words_per_dev(nd, n);
-	int prev = -1;
-	(void)hipGetDevice(&prev);
-	/* 1. every device walks its shard on its own stream, driven by its own host thread */
-	int rc = per_device(nd, [&](int k) {
+	return per_device(nd, [&](int k) -> int {
 		size_t first, count;
 		fsm_hip_node_shard(nd, n, k, &first, &count);
-		if (hipSetDevice(nd->dev[(size_t)k]) != hipSuccess) { errno = ENODEV; return -1; }
-		hipStream_t s = nd->stream[(size_t)k];
-		uint64_t *slice = d_bitmap_all ? d_bitmap_all[k] + (size_t)k * wpd : nullptr;
-		if (slice != nullptr && count < wpd * 64 &&
-		    hipMemsetAsync(slice, 0, wpd * sizeof(uint64_t), s) != hipSuccess) { errno = EIO; return -1; }
-		if (count != 0 &&
-		    fsm_hip_exec_batch_device(nd->dfa[(size_t)k], d_base[k], stride, nullptr, count,
-		                              d_end_out ? d_end_out[k] : nullptr, slice, s) != 0) return -1;
-		if (match_count != nullptr) {
-			if (hipMemsetAsync(nd->d_count[(size_t)k], 0, sizeof(unsigned long long), s) != hipSuccess) { errno = EIO; return -1; }
-			hipLaunchKernelGGL(count_bits_kernel, dim3(256), dim3(256), 0, s, slice, (uint64_t)wpd, nd->d_count[(size_t)k]);
-			if (hipGetLastError() != hipSuccess) { errno = EIO; return -1; }
-		}
-		return 0;
+		if (count == 0) return 0;
+		return fsm_hip_exec_batch_ids(nd->dfa[(size_t)k], base + first * stride, stride, len ? len + first : nullptr, count, mode, id_out + first);
 	});
-	/* 2. the only exchange: every device gets every slice of the bitmap; the counts are summed */
-	unsigned long long total = 0;
-	if (rc == 0 && !nd->comm.empty()) {
-		bool ok = true;
-		if (d_bitmap_all != nullptr) {
-			ok = ok && R.GroupStart() == 0;
-			for (size_t k = 0; k < g && ok; k++)
-				ok = R.AllGather(d_bitmap_all[k] + k * wpd, d_bitmap_all[k], wpd, 5 /* ncclUint64 */, nd->comm[k], nd->stream[k]) == 0;
-			ok = R.GroupEnd() == 0 && ok;
-		}
-		if (ok && match_count != nullptr) {
-			ok = ok && R.GroupStart() == 0;
-			for (size_t k = 0; k < g && ok; k++)
-				ok = R.AllReduce(nd->d_count[k], nd->d_count[k], 1, 5 /* ncclUint64 */, 0 /* ncclSum */, nd->comm[k], nd->stream[k]) == 0;
-			ok = R.GroupEnd() == 0 && ok;
-		}
-		for (size_t k = 0; k < g; k++) {
-			(void)hipSetDevice(nd->dev[k]);
-			ok = hipStreamSynchronize(nd->stream[k]) == hipSuccess && ok;
-		}
-		if (ok && match_count != nullptr) {
-			(void)hipSetDevice(nd->dev[0]);
-			ok = hipMemcpy(&total, nd->d_count[0], sizeof total, hipMemcpyDeviceToHost) == hipSuccess;
-		}
-		if (!ok) { errno = EIO; rc = -1; }
-	} else if (rc == 0) {
-		/* no RCCL (or a device list with repeats): the same exchange as peer-to-peer copies of the slices */
-		bool ok = true;
-		for (size_t k = 0; k < g; k++) {
-			(void)hipSetDevice(nd->dev[k]);
-			ok = hipStreamSynchronize(nd->stream[k]) == hipSuccess && ok;
-		}
-		for (size_t k = 0; k < g && ok; k++) {
-			if (match_count != nullptr) {
-				unsigned long long c = 0;
-				(void)hipSetDevice(nd->dev[k]);
-				ok = hipMemcpy(&c, nd->d_count[k], sizeof c, hipMemcpyDeviceToHost) == hipSuccess && ok;
-				total += c;
-			}
-			for (size_t j = 0; j < g && ok && d_bitmap_all != nullptr; j++) {
-				if (j == k || d_bitmap_all[j] == d_bitmap_all[k]) continue;
-				ok = hipMemcpyPeer(d_bitmap_all[j] + k * wpd, nd->dev[j], d_bitmap_all[k] + k * wpd, nd->dev[k], wpd * sizeof(uint64_t)) == hipSuccess;
-			}
-		}
-		if (!ok) { errno = EIO; rc = -1; }
-	}
-	if (prev >= 0) (void)hipSetDevice(prev);
-	if (rc == 0 && match_count != nullptr) *match_count = total;
-	return rc;
+}
+
+extern "C" int fsm_hip_node_exec_batch_eager(struct fsm_hip_node *nd,
+	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, uint32_t *end_out, uint64_t *eager_out)
+{
+	if (nd == nullptr || eager_out == nullptr || (n != 0 && base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	std::lock_guard<std::mutex> lk(nd->mu);
+	const size_t W = fsm_hip_eager_words(nd->dfa[0]);
+	return per_device(nd, [&](int k) -> int {
+		size_t first, count;
+		fsm_hip_node_shard(nd, n, k, &first, &count);
+		if (count == 0) return 0;
+		return fsm_hip_exec_batch_eager(nd->dfa[(size_t)k], base + first * stride, stride, len ? len + first : nullptr, count,
+		                                end_out ? end_out + first : nullptr, eager_out + first * W);
+	});
 }

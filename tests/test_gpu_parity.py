@@ -377,8 +377,9 @@ def test_config0_full_size_vs_reference(hip):
 
 
 def test_config5_aho_corasick_100k_literals(hip):
-    """BASELINE configs[4]: re_strings over 1e5 literals (~3e5 states, table >> LDS): the
-    HBM/L2-resident layout, checked against the oracle walker and, on a few inputs, fsm_exec."""
+    """BASELINE configs[4]: re_strings over 1e5 literals (~3e5 states, table >> LDS): the HBM/L2-resident layouts,
+    checked against the oracle walker on 2e4 inputs, against the reference's fsm_exec loop (its per-call isdfa sweep
+    hoisted: ~2 MB/s here) on 1e4 of them, and against the literal fsm_exec (~3 s per call) on 5."""
     _need_ref()
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
@@ -408,6 +409,8 @@ def test_config5_aho_corasick_100k_literals(hip):
     assert (want != NO).sum() >= 10000
     ret, e5 = f.exec_stride(rows[:5])  # literal fsm_exec sweeps all 3e5 states per call
     assert np.array_equal(e5, want[:5])
+    hret, hend = f.exec_hoisted_stride(rows[:10000])      # exec.c's own loop, sweep hoisted
+    assert np.array_equal(hend, want[:10000]) and np.array_equal(hret == 1, want[:10000] != NO)
     for layout in (hip.LAYOUT_GLOBAL, hip.LAYOUT_SPARSE, hip.LAYOUT_AUTO):
         dfa = hip.HipDfa(flat, layout)
         assert dfa.info()["layout_name"] == {hip.LAYOUT_GLOBAL: "global", hip.LAYOUT_SPARSE: "sparse", hip.LAYOUT_AUTO: "sparse"}[layout]
@@ -415,6 +418,7 @@ def test_config5_aho_corasick_100k_literals(hip):
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
             end, _ = dfa.exec_batch(rows)
             assert np.array_equal(end, want), (layout, mode)
+            assert np.array_equal(end[:10000], hend), (layout, mode)     # HIP vs the reference's loop, directly
         for e in set(int(x) for x in want[:200] if x != NO):
             assert np.array_equal(dfa.endids(e), f.endids(e))
         dfa.close()

@@ -696,7 +696,7 @@ def test_fsm_H(hip, tmp_path):
 # multi-device front (C ABI): one replica per device, one host thread per device
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], "all"])
 def test_node_front_shards_and_gathers(hip, devices):
     """fsm_hip_node_*: the batch is split into contiguous shards of whole bitmap words, one per replica, each
     driven by its own host thread.  This box has one GPU, so [0] exercises the RCCL path (a communicator of one:
@@ -706,11 +706,15 @@ def test_node_front_shards_and_gathers(hip, devices):
     import torch
     import bench
     from oracle.pyoracle import Oracle
+    if devices == "all":      # every GPU the box shows: RCCL with more than one rank, the moment such a box runs this
+        if torch.cuda.device_count() < 2:
+            pytest.skip("one GPU")
+        devices = list(range(torch.cuda.device_count()))
     g = Golden(os.path.join(GOLDEN, "c3.npz"))
     o = Oracle(g.flat)
     node = hip.HipNode(g.flat, devices)
     assert node.ndev == len(devices)
-    assert node.uses_rccl() == (len(devices) == 1)
+    assert node.uses_rccl() == (len(set(devices)) == len(devices))
     rng = np.random.RandomState(len(devices))
     # shards: contiguous, whole words, cover [0, n)
     for n in (1, 63, 64, 65, 1000, 100_003):
@@ -740,13 +744,17 @@ def test_node_front_shards_and_gathers(hip, devices):
     W = node.bitmap_words(n)
     for k in range(node.ndev):
         f, c = node.shard(n, k)
-        b = torch.empty((max(c, 1), L), dtype=torch.uint8, device="cuda")
+        dev = f"cuda:{devices[k]}"
+        torch.cuda.set_device(devices[k])
+        b = torch.empty((max(c, 1), L), dtype=torch.uint8, device=dev)
         if c:
             bench.generate(hip, "c3", b.data_ptr(), c, L, f)
         bufs.append(b)
-        ends.append(torch.full((max(c, 1),), -2, dtype=torch.int32, device="cuda"))
-        bms.append(torch.full((W,), -1, dtype=torch.int64, device="cuda"))
-    torch.cuda.synchronize()
+        ends.append(torch.full((max(c, 1),), -2, dtype=torch.int32, device=dev))
+        bms.append(torch.full((W,), -1, dtype=torch.int64, device=dev))
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    torch.cuda.set_device(0)
     cnt = node.exec_batch_device([b.data_ptr() for b in bufs], L, n, [e.data_ptr() for e in ends], [m.data_ptr() for m in bms], want_count=True)
     host = bench.generate_host(hip, "c3", n, L, 0)
     want = o.table_walk(host)

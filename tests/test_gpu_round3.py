@@ -221,3 +221,191 @@ def test_packed_kernel_large_batch_and_auto_choice(hip):
         assert np.array_equal(e[0].cpu().numpy().view(np.uint32)[idx], want)
         print(f"packed front n={n} lens={lo}..{hi - 1}: auto {total / ms[-1] / 1e6:.0f} GB/s, packed {total / ms[hip.IN_PACKED] / 1e6:.0f}, generic {total / ms[hip.IN_GENERIC] / 1e6:.0f}")
     dfa.close()
+
+
+# ---------------------------------------------------------------------------
+# the C-ABI matrix: ids / resume / eager over packed offsets, host and device pointers
+# ---------------------------------------------------------------------------
+
+def test_offsets_fronts_ids_resume_eager(hip):
+    """fsm_hip_exec_batch_{ids,resume,eager}_offsets[_device]: the packed form of the three fronts that only had the
+    fixed-stride form.  ids against the oracle's fsm_endid_get sets (EARLIEST / RET), resume by cutting every line in two
+    pieces (the state after piece 1 carried into piece 2 = the whole line's result), eager on every tests/eager_output
+    automaton against the golden id sets -- short lines (per-lane kernel) and long ones (ragged kernel), host and
+    device pointers."""
+    import torch
+    from common import eager_golden_paths
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(4)
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+
+    def line(k):
+        if rng.randint(3):
+            return bytes(a[rng.randint(0, len(a), k)])
+        p = pats[rng.randint(len(pats))]
+        return p[1:p.index(b"[")] + bytes(rng.randint(48, 58, max(1, k - 6)).astype(np.uint8)) + b"yz"
+
+    dfa = hip.HipDfa(g.flat)
+    sets = dfa.ret_sets()
+    for lo, hi, n in ((0, 60, 7000), (0, 700, 3000)):
+        strings = [line(rng.randint(lo, hi)) for _ in range(n)]
+        ret, want = o.exec_strings(strings)
+        assert (ret == 1).sum() > n // 10
+        base, off = _packed(strings)
+        d_base = torch.from_numpy(np.concatenate([base, np.zeros(1, np.uint8)])).cuda()
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        for mode in (1, 2):
+            ids = dfa.exec_offsets_ids(base, off, mode)
+            d_ids = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+            dfa.exec_offsets_device_front("ids", d_base.data_ptr(), d_off.data_ptr(), n, d_ids.data_ptr(), mode=mode)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ids)
+            assert (ids[want == NO] == NO).all()
+            for i in np.nonzero(want != NO)[0][:400]:
+                e = o.endids(int(want[i]))
+                if mode == 1:
+                    assert ids[i] == (int(e[0]) if len(e) else 0xFFFFFFFE)
+                else:
+                    assert np.array_equal(sets[ids[i]], e)
+        # resume: piece 1 = the first half of every line, piece 2 = the rest
+        cut = [rng.randint(0, len(s) + 1) for s in strings]
+        b1, o1 = _packed([s[:c] for s, c in zip(strings, cut)])
+        b2, o2 = _packed([s[c:] for s, c in zip(strings, cut)])
+        st, _ = dfa.exec_offsets_resume(b1, o1, np.full(n, hip.STATE_START, np.uint32))
+        st2, end2 = dfa.exec_offsets_resume(b2, o2, st)
+        assert np.array_equal(end2, want)
+        d_st = torch.from_numpy(st.view(np.int32)).cuda()
+        d_end = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+        d_b2 = torch.from_numpy(np.concatenate([b2, np.zeros(1, np.uint8)])).cuda()
+        d_o2 = torch.from_numpy(o2.view(np.int64)).cuda()
+        dfa.exec_offsets_device_front("resume", d_b2.data_ptr(), d_o2.data_ptr(), n, d_st.data_ptr(), d_end.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want) and np.array_equal(d_st.cpu().numpy().view(np.uint32), st2)
+    dfa.close()
+    # eager outputs: the golden automata, their own inputs packed (+ each input repeated to make long lines)
+    for path in eager_golden_paths()[:12]:
+        ge = Golden(path)
+        strs = ge.strings()
+        d = hip.HipDfa(ge.flat)
+        base, off = _packed(strs)
+        end, sets_ = d.exec_offsets_eager(base, off)
+        rows, lens = ge.padded_rows()
+        end_r, sets_r = d.exec_batch_eager(rows, lens)
+        assert np.array_equal(end, end_r)
+        for i in range(len(strs)):
+            assert np.array_equal(np.sort(sets_[i]), np.sort(ge.eager_of(i))), (path, i)
+            assert np.array_equal(np.sort(sets_[i]), np.sort(sets_r[i]))
+        d.close()
+
+
+# ---------------------------------------------------------------------------
+# multi-device front: descriptor form, asynchronous exchange, every visible device
+# ---------------------------------------------------------------------------
+
+def _node_device_lists(hip):
+    import torch
+    out = [[0], [0, 0]]
+    if torch.cuda.device_count() > 1:          # switches itself on the moment the box has more than one GPU
+        out.append(list(range(torch.cuda.device_count())))
+    return out
+
+
+def test_node_front_descriptor_lengths_offsets_ids_async(hip):
+    """fsm_hip_node_exec_device: device-resident shards with lengths, with packed offsets, with device-delivered ids; the
+    asynchronous form with two sets of buffers (step k's exchange under step k + 1's walk) and fsm_hip_node_wait; a
+    NULL bitmap entry is refused.  On [0] (RCCL, a communicator of one), [0, 0] (peer copies) and -- on a box with
+    several GPUs -- on all of them over RCCL."""
+    import torch
+    import bench
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g.flat)
+    for devices in _node_device_lists(hip):
+        node = hip.HipNode(g.flat, devices)
+        G = node.ndev
+        n, L = 100_037, 256
+        host = bench.generate_host(hip, "c3", n, L, 0)
+        rng = np.random.RandomState(G)
+        lens = np.where(rng.randint(0, 4, n) == 0, rng.randint(0, L + 1, n), L).astype(np.uint32)
+        ret_l, want_l = o.exec_stride(host, lens)
+        want = o.table_walk(host)
+        W = node.bitmap_words(n)
+        bufs, dlens, ends, ids, bms, bms2, doffs, packs = [], [], [], [], [], [], [], []
+        for k, dv in enumerate(devices):
+            f, c = node.shard(n, k)
+            dev = f"cuda:{dv}"
+            bufs.append(torch.from_numpy(host[f:f + max(c, 1)].copy()).to(dev) if c else torch.zeros((1, L), dtype=torch.uint8, device=dev))
+            dlens.append(torch.from_numpy(lens[f:f + max(c, 1)].view(np.int32).copy()).to(dev))
+            ends.append(torch.full((max(c, 1),), -2, dtype=torch.int32, device=dev))
+            ids.append(torch.full((max(c, 1),), -2, dtype=torch.int32, device=dev))
+            bms.append(torch.full((W,), -1, dtype=torch.int64, device=dev))
+            bms2.append(torch.full((W,), -1, dtype=torch.int64, device=dev))
+            # the shard once more as packed lines: the first lens[i] bytes of every row
+            rows_k = [bytes(host[i, :lens[i]]) for i in range(f, f + c)]
+            pb, po = _packed(rows_k) if c else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+            packs.append(torch.from_numpy(np.concatenate([pb, np.zeros(16, np.uint8)])).to(dev))
+            doffs.append(torch.from_numpy(po.view(np.int64).copy()).to(dev))
+        for dv in set(devices):
+            torch.cuda.synchronize(dv)
+        P = lambda ts: [t.data_ptr() for t in ts]          # noqa: E731
+
+        def gathered(ts):
+            return np.concatenate([ts[k][:node.shard(n, k)[1]].cpu().numpy().view(np.uint32) for k in range(G)])
+
+        # stride + lengths, ids (EARLIEST) and the bitmap + count in one call
+        cnt = node.exec_device(n, P(bufs), stride=L, d_len=P(dlens), d_end=P(ends), d_ids=P(ids), ids_mode=1, d_bitmap_all=P(bms), want_count=True)
+        assert np.array_equal(gathered(ends), want_l) and cnt == int((ret_l == 1).sum())
+        got_ids = gathered(ids)
+        for i in np.nonzero(want_l != NO)[0][:300]:
+            e = o.endids(int(want_l[i]))
+            assert got_ids[i] == (int(e[0]) if len(e) else 0xFFFFFFFE)
+        for k in range(G):
+            assert np.array_equal(bits(bms[k].cpu().numpy(), n), ret_l == 1), (devices, k)
+        # the same inputs as packed lines
+        for e_ in ends:
+            e_.fill_(-2)
+        node.exec_device(n, P(packs), d_off=P(doffs), d_end=P(ends), d_bitmap_all=P(bms2))
+        assert np.array_equal(gathered(ends), want_l)
+        assert np.array_equal(bits(bms2[0].cpu().numpy(), n), ret_l == 1)
+        # asynchronous: three steps alternating two bitmap sets; whole rows
+        for step in range(3):
+            node.exec_device(n, P(bufs), stride=L, d_end=P(ends), d_bitmap_all=P(bms if step % 2 == 0 else bms2), want_count=True, async_=True)
+        cnt = node.wait(want_count=True)
+        assert cnt == int((want != NO).sum())
+        assert np.array_equal(gathered(ends), want)
+        for k in range(G):
+            assert np.array_equal(bits(bms[k].cpu().numpy(), n), want != NO) and np.array_equal(bits(bms2[k].cpu().numpy(), n), want != NO)
+        # a NULL bitmap entry: refused, nothing launched
+        if G > 1:
+            with pytest.raises(OSError):
+                node.exec_device(n, P(bufs), stride=L, d_bitmap_all=[bms[0].data_ptr()] + [0] * (G - 1))
+        # host-pointer ids over the node
+        rows = host[:5000]
+        hid = node.exec_batch_ids(rows, 1)
+        d1 = hip.HipDfa(g.flat)
+        assert np.array_equal(hid, d1.exec_batch_ids(rows, 1))
+        d1.close()
+        node.close()
+
+
+def test_bench_one_rank_per_visible_gpu():
+    """bench.py launched the way the driver launches it for N > 1 -- torch.distributed.run, one rank per GPU, RCCL -- on
+    every GPU this box shows.  Skips itself on a one-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu
+    covers the plumbing there over gloo)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    ng = torch.cuda.device_count()
+    if ng < 2:
+        pytest.skip("one GPU: the RCCL path needs at least two")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ng), "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", str(ng), "--steps", "5", "--warmup", "2", "--workload", "c2",
+           "--inputs", "1048576"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == ng and r["value"] > 0 and abs(r["config"]["accepted_inputs"] - ng * 1048576 // 8) < 64 * ng

@@ -64,7 +64,10 @@ def main():
         summary["l2_per_launch"] = {k: sum(v) / len(v) for k, v in l2.items()}
         summary["l2_per_launch"]["input_bytes_per_launch"] = n * L
     json.dump(summary, open(out + "_rocprof_summary.json", "w"), indent=1)
-    json.dump({"n": n, "len": L, "hbm_bytes_per_launch": hbm, "kernel": walk["name"], "source": os.path.basename(out) + "_rocprof_summary.json"},
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench   # kernels_sha16(): the counters speak for the device sources they were taken from
+    json.dump({"n": n, "len": L, "hbm_bytes_per_launch": hbm, "kernel": walk["name"], "kernels_sha16": bench.kernels_sha16(),
+               "source": os.path.basename(out) + "_rocprof_summary.json"},
               open(os.path.join(os.path.dirname(out), f"pmc_{wl}.json"), "w"))
     print(json.dumps(summary["walk_kernel"]), json.dumps(summary["pmc"]["traffic_over_algorithmic"]))
 
