@@ -39,6 +39,14 @@ def bits(bm, n):
     return np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool)
 
 
+def _missing_integration(what):
+    """A missing integration binary: skip -- or fail when FSM_REQUIRE_INTEGRATION is set (a GPU box that is expected to
+    carry the prebuilt files: without this a clean checkout would quietly drop the SURVEY 8(a10) tests)."""
+    if os.environ.get("FSM_REQUIRE_INTEGRATION"):
+        pytest.fail(what + " and FSM_REQUIRE_INTEGRATION is set")
+    pytest.skip(what)
+
+
 def _need_ref():
     from oracle import pyoracle
     if not pyoracle.have_ref():
@@ -559,7 +567,7 @@ def test_retest_l_hip(hip, tmp_path):
     if not os.path.exists(exe):
         sh = subprocess.run(["sh", os.path.join(ROOT, "integration", "retest", "build.sh")], capture_output=True, text=True)
         if not os.path.exists(exe):
-            pytest.skip("integration/_build/retest not built (needs /root/reference at build time): " + sh.stderr[-300:])
+            _missing_integration("integration/_build/retest not built (needs /root/reference at build time): " + sh.stderr[-300:])
     lines, flip = retest_tst_lines()
     tst = tmp_path / "all.tst"
     tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
@@ -592,7 +600,7 @@ def test_reperf_l_hip(hip, tmp_path):
     from common import reperf_scr_lines
     exe = os.path.join(ROOT, "integration", "_build", "reperf")
     if not os.path.exists(exe):
-        pytest.skip("integration/_build/reperf not built (needs /root/reference at build time)")
+        _missing_integration("integration/_build/reperf not built (needs /root/reference at build time)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
 
     def go(impl, lines):
@@ -626,7 +634,7 @@ def test_reference_test_programs_on_the_hip_path(hip):
     from test_retest_patch import reference_test_programs
     progs = reference_test_programs()
     if len(progs) != 42:
-        pytest.skip("integration/_build/reftests not built (needs /root/reference at build time)")
+        _missing_integration("integration/_build/reftests not built (needs /root/reference at build time)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     total = eager = 0
     for exe in progs:
@@ -650,7 +658,7 @@ def test_re_H(hip, tmp_path):
     from test_retest_patch import RE_CASES
     exe = os.path.join(ROOT, "integration", "_build", "re")
     if not os.path.exists(exe):
-        pytest.skip("integration/_build/re not built (needs /root/reference at build time)")
+        _missing_integration("integration/_build/re not built (needs /root/reference at build time)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     for args, rc in RE_CASES:
         ref = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=120)
@@ -674,7 +682,7 @@ def test_fsm_H(hip, tmp_path):
     from test_retest_patch import FSM_CASES, FSM_DFA, FSM_NFA
     exe = os.path.join(ROOT, "integration", "_build", "fsm")
     if not os.path.exists(exe):
-        pytest.skip("integration/_build/fsm not built (needs /root/reference at build time)")
+        _missing_integration("integration/_build/fsm not built (needs /root/reference at build time)")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     dfa, nfa, txt = tmp_path / "d.fsm", tmp_path / "n.fsm", tmp_path / "t.txt"
     dfa.write_text(FSM_DFA)

@@ -409,3 +409,59 @@ def test_bench_one_rank_per_visible_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == ng and r["value"] > 0 and abs(r["config"]["accepted_inputs"] - ng * 1048576 // 8) < 64 * ng
+
+
+# ---------------------------------------------------------------------------
+# FSM_PRINT_HIP: the reference's rx(1) -> table file -> a libfsm-free matcher
+# ---------------------------------------------------------------------------
+
+def _integration_exe(*parts):
+    """An integration binary: built where /root/reference exists, prebuilt files elsewhere.  Missing: skip -- or fail
+    when FSM_REQUIRE_INTEGRATION is set (a GPU box that is expected to carry the prebuilt files)."""
+    exe = os.path.join(ROOT, "integration", "_build", *parts)
+    if not os.path.exists(exe):
+        if os.environ.get("FSM_REQUIRE_INTEGRATION"):
+            pytest.fail("%s missing and FSM_REQUIRE_INTEGRATION is set" % exe)
+        pytest.skip("%s not built (needs /root/reference at build time)" % exe)
+    return exe
+
+
+def test_rx_l_hip_into_hipgrep(hip, tmp_path):
+    """configs[2] end to end with the reference's own front: rx(1) -- rebuilt with integration/print/print_hip.patch --
+    compiles the 1 024 patterns of the C3 workload and prints the DFA with `-l hip`; examples/hipgrep.c (plain C, no
+    libfsm in the process) loads the file, matches 20 000 lines in one launch and prints line:end-ids.  The ids must be
+    what fsm_exec + fsm_endid_get give on the reference's own union of the same patterns."""
+    import subprocess
+    from oracle import pyoracle
+    rx = _integration_exe("print", "rx")
+    if not pyoracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    assert len(pats) == 1024
+    pf = tmp_path / "patterns"
+    pf.write_bytes(b"\n".join(pats) + b"\n")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([rx, "-u", "-l", "hip", str(pf)], capture_output=True, env=env, timeout=600)
+    assert out.returncode == 0 and out.stdout[:6] == b"FSMHIP", out.stderr[-500:]
+    table = tmp_path / "c3.fsmhip"
+    table.write_bytes(out.stdout)
+    rng = np.random.RandomState(8)
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    lines = []
+    for i in range(20000):
+        if i % 2:
+            p = pats[rng.randint(len(pats))]
+            lines.append(p[1:p.index(b"[")] + bytes(rng.randint(48, 58, rng.randint(1, 40)).astype(np.uint8)) + (b"x" if rng.randint(2) else b"yz"))
+        else:
+            lines.append(bytes(a[rng.randint(0, len(a), rng.randint(0, 50))]))
+    exe = str(tmp_path / "hipgrep")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "hipgrep.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "libfsm_amd"), "-lfsm_hip", "-Wl,-rpath," + os.path.join(ROOT, "libfsm_amd")])
+    out = subprocess.run([exe, str(table)], input=b"\n".join(lines) + b"\n", capture_output=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    f = pyoracle.RefFsm.union_res("pcre", pats, 0)
+    ret, end = f.exec_strings(lines)
+    want = [f"{i + 1}:" + ",".join(str(int(x)) for x in f.endids(int(end[i]))) for i in range(len(lines)) if ret[i] == 1]
+    assert out.stdout.decode().split() == want
+    assert len(want) >= 9000
