@@ -37,6 +37,8 @@ enum {
 	FSM_HIP_KNOB_PK_MEAN_MAX   = 18, /* auto: batches whose mean input length exceeds this go to the ragged kernel   */
 	FSM_HIP_KNOB_PK_DEBUG      = 19, /* measurement aid: bit mask of walk_packed parts switched off (results are WRONG):
 	                                  * 1 result stores, 4 input loads, 16 packed_finish (raw state codes stay)           */
+	FSM_HIP_KNOB_SPARSE_FAST   = 20, /* sparse layout, fixed-stride rows: 1 (default) the record is the walk state and a byte is
+	                                  * three straight-line record probes; 0 the chain loop over state ids (A/B measurement)   */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };

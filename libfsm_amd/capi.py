@@ -28,7 +28,7 @@ KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_
 KNOB_NOSKIP = 13
 KNOB_RAGGED_ALIGN = 14
 KNOB_DMA_BUFS = 15
-KNOB_PK_RMIN, KNOB_PK_RMAX, KNOB_PK_MEAN_MAX, KNOB_PK_DEBUG = 16, 17, 18, 19
+KNOB_PK_RMIN, KNOB_PK_RMAX, KNOB_PK_MEAN_MAX, KNOB_PK_DEBUG, KNOB_SPARSE_FAST = 16, 17, 18, 19, 20
 IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED, IN_PACKED = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

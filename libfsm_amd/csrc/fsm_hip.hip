@@ -81,6 +81,7 @@ struct fsm_hip_dfa {
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
 	int knob_pk_rmin = 7;        /* packed front: smallest row, log2 bytes */
 	int knob_pk_rmax = 0;        /* ... largest row, log2 bytes (<= 10); 0 = what leaves room for a full workgroup */
+	int knob_sparse_fast = 1;    /* sparse layout: entry-as-state walk (0: the id-as-state chain loop, for A/B runs) */
 	int knob_pk_debug = 0;       /* measurement aid: parts of walk_packed switched off (results are wrong) */
 	int knob_pk_mean_max = 192;  /* ... longest mean input length (bytes) walk_packed takes; longer: walk_ragged */
 	unsigned flags = 0;
@@ -478,6 +479,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		if (m >= 0) mode = m;
 	}
 	c.mode = mode;
+	c.sparse_fast = d->knob_sparse_fast;
 	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
@@ -995,6 +997,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_PK_RMIN: if (value < 7 || value > (int)FSMHIP_PK_RMAX) { errno = EINVAL; return -1; } d->knob_pk_rmin = value; break;
 	case FSM_HIP_KNOB_PK_RMAX: if (value != 0 && (value < 7 || value > (int)FSMHIP_PK_RMAX)) { errno = EINVAL; return -1; } d->knob_pk_rmax = value; break;
 	case FSM_HIP_KNOB_PK_DEBUG: d->knob_pk_debug = value; break;
+	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value != 0; break;
 	case FSM_HIP_KNOB_PK_MEAN_MAX: if (value < 0) { errno = EINVAL; return -1; } d->knob_pk_mean_max = value; break;
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;

@@ -5,6 +5,11 @@ namespace fsmhip {
 
 hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
+	if (pol == POL_SPARSE && eager == 0 && c.sparse_fast && c.mode == IN_DIRECT) {
+		/* fixed-stride rows, plain walk: the record is the state (SparseFastPol) */
+		walk_fn k = !c.prefetch && c.nb == 4 ? walk_direct_np<SparseFastPol, 4> : c.nb == 4 ? walk_direct<SparseFastPol, 4, 1> : walk_direct<SparseFastPol, 8, 1>;
+		return launch_fn(k, c, a, grid, block, s);
+	}
 	if (pol == POL_SPARSE) return launch_family<SparsePol>(eager, c, a, grid, block, s);
 	return launch_family<GlobPol>(eager, c, a, grid, block, s);
 }

@@ -21,6 +21,7 @@ struct LaunchCfg {
 	int seg;             /* LDS-DMA: 64 or 128 */
 	int prefetch;        /* direct: register double-buffer (0: <= 64 VGPRs, occupancy instead) */
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
+	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 };
 

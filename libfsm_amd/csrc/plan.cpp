@@ -407,7 +407,7 @@ try {
  * state's) on more than half the classes stays dense, so the form is never much larger than the
  * table and the result is the same for any choice.
  *
- * Records are 16 bytes {bits lo, bits hi, base | DENSE | CONSEC | FULLBASE, offset}; those of the states nearest the
+ * Records are 16 bytes {bits lo, bits hi, base (28 bits) | DENSE | CONSEC | FULLBASE | FASTMISS, offset}; those of the states nearest the
  * start state, and the dense rows among them, are mirrored in LDS (breadth-first numbering puts
  * the states a walk visits most first), the rest stays in HBM/L2.
  *
@@ -509,12 +509,65 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		}
 	}
 
+	/* which states live in LDS: the H nearest the start state (breadth-first numbering).  Half the LDS, so that two
+	 * 16-wave workgroups share a CU: the walk waits on gathers, and 32 resident waves measured 283 vs 220 GB/s with
+	 * all of LDS and 16 (profiles/r01_c5_sparse.txt) */
+	const uint32_t budget = lds_limit / 2u > 4096u ? lds_limit / 2u - 2048u : 0;
+	uint32_t H = 0, HD = 0;                                              /* records / dense rows in LDS */
+	{
+		uint64_t used = 64u + 512u;
+		for (uint32_t n = 0; n < N; n++) {
+			const uint64_t need = 16u + (base[n] == NONE ? (uint64_t)C * 4u : 0u);
+			if (used + need > budget) break;
+			used += need;
+			H++;
+			if (base[n] == NONE) HD++;
+		}
+	}
+	/* Short chains through LDS.  The walk evaluates a byte against a state's own record and, on a miss, against its
+	 * base's and that one's base's -- straight-line, from LDS (SparseFastPol, walk_kernels.h).  That is exact when the
+	 * third record owns every class (a full trie node: level 0), i.e. when the own record is at level <= 2 with
+	 *     level(full record) = 0,   level(n) = 1 + level(base(n)),   both bases among the H LDS records.
+	 * A deep state's natural base (its failure state) is itself deep: such a record is re-based onto the first record of
+	 * its base chain that is LDS-resident and at level <= 1, and the classes on which the skipped records differed from
+	 * that one become exceptions of its own (the result is the same for any choice of base).  A literal-set state then
+	 * costs an exception or two more, and a miss on it is three probes, never a walk through HBM. */
+	{
+		uint32_t nbits = 0;
+		for (uint32_t c = 0; c < C; c++) nbits += bit_of[c] != 0xff;
+		auto is_full = [&](uint32_t n, uint32_t b) {          /* n differs from b on every class that owns a bit */
+			const uint32_t *ra = row(n), *rb = row(b);
+			uint32_t k = 0;
+			for (uint32_t c = 0; c < C; c++) k += bit_of[c] != 0xff && ra[c] != rb[c];
+			return nbits != 0 && k == nbits;
+		};
+		std::vector<uint8_t> lvl(N, 99);                      /* dense rows and whatever hangs off them: never through */
+		for (uint32_t n : order) {
+			if (base[n] == NONE) continue;
+			if (!is_full(n, base[n])) {
+				uint32_t cand = base[n];
+				while (cand != NONE && (cand >= H || lvl[cand] > 1)) cand = base[cand];
+				if (cand != NONE && cand != n && cand != base[n]) {
+					const uint32_t k = diff(n, cand);
+					/* (a handful of exceptions at most: the list costs table bytes -- 4 per exception -- and a hit on a listed
+					 * class takes the general loop) */
+					bool ok = k <= 4u || consec_vs(n, cand);
+					const uint32_t *ra = row(n), *rb = row(cand);
+					for (uint32_t c = 0; c < C && ok; c++) ok = ra[c] == rb[c] || bit_of[c] != 0xff;   /* every exception owns a bit */
+					if (ok) { base[n] = cand; nexc[n] = k; }
+				}
+			}
+			if (is_full(n, base[n])) lvl[n] = 0;
+			else if (base[n] < H && lvl[base[n]] < 98) lvl[n] = (uint8_t)(lvl[base[n]] + 1);
+		}
+	}
+
 	/* CONSEC records: the targets of the exceptions are consecutive state ids in class (= bit) order.
 	 * Breadth-first numbering hands the children of a trie node consecutive ids, so on an Aho-Corasick
 	 * DFA every record with at least one exception qualifies: the walk then computes the next state as
 	 * first + rank(bit) and the exception list -- one dependent gather per hit -- is not stored at all. */
-	const uint32_t CONSEC = 0x40000000u, FULLBASE = 0x20000000u;
-	if (N >= FULLBASE) return ENOTSUP;
+	const uint32_t CONSEC = 0x40000000u, FULLBASE = 0x20000000u, FASTMISS = 0x10000000u;
+	if (N >= FASTMISS) return ENOTSUP;
 	std::vector<uint8_t> consec(N, 0);
 	for (uint32_t n = 0; n < N; n++) {
 		if (base[n] == NONE || nexc[n] == 0) continue;
@@ -530,25 +583,11 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 		consec[n] = ok;
 	}
 
-	/* sizes; which states live in LDS */
+	/* sizes */
 	uint64_t ndense = 0, ntot_exc = 0;
 	for (uint32_t n = 0; n < N; n++) { if (base[n] == NONE) ndense++; else if (!consec[n]) ntot_exc += nexc[n]; }
 	const uint64_t words = 16u + 128u + (uint64_t)N * 4u + ndense * C + ntot_exc;
 	if (words * 4u + 160u * 1024u >= 0xFFFFFFFFull) return ENOTSUP;
-	/* half the LDS, so that two 16-wave workgroups share a CU: the walk waits on gathers, and 32
-	 * resident waves measured 283 vs 220 GB/s with all of LDS and 16 (profiles/r01_c5_sparse.txt) */
-	const uint32_t budget = lds_limit / 2u > 4096u ? lds_limit / 2u - 2048u : 0;
-	uint32_t H = 0, HD = 0;                                              /* records / dense rows in LDS */
-	{
-		uint64_t used = 64u + 512u;
-		for (uint32_t n = 0; n < N; n++) {
-			const uint64_t need = 16u + (base[n] == NONE ? (uint64_t)C * 4u : 0u);
-			if (used + need > budget) break;
-			used += need;
-			H++;
-			if (base[n] == NONE) HD++;
-		}
-	}
 
 	std::vector<uint32_t> &img = p.sparse_img;
 	const uint32_t lds_dense_w = 16u + 128u, lds_rec_w = (lds_dense_w + HD * C + 3u) & ~3u;
@@ -605,6 +644,33 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 			if ((rb[0] | ((uint64_t)rb[1] << 32)) == all) { r[2] |= FULLBASE; nfullbase++; }
 		}
 	}
+	/* FASTMISS: every class this record does NOT own is answered by a CONSEC record within the next two levels of its
+	 * base chain, both among the LDS records -- what SparseFastPol's straight-line evaluation assumes (it checks this
+	 * flag, and CONSEC when the record itself owns the class, instead of re-deriving all that per byte). */
+	uint32_t nfastmiss = 0;
+	{
+		uint32_t nbits = 0;
+		for (uint32_t c = 0; c < C; c++) nbits += bit_of[c] != 0xff;
+		const uint64_t all = nbits >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << nbits) - 1u);
+		auto bits_of = [&](uint32_t n) { const uint32_t *r = &img[grec_w + (size_t)n * 4u]; return r[0] | ((uint64_t)r[1] << 32); };
+		for (uint32_t n = 0; n < N; n++) {
+			if (base[n] == NONE) continue;
+			const uint64_t need = all & ~bits_of(n);
+			bool ok = need == 0;
+			if (!ok) {
+				const uint32_t B = base[n];
+				if (B < H && base[B] != NONE) {
+					const uint64_t inB = need & bits_of(B), rest = need & ~bits_of(B);
+					ok = inB == 0 || consec[B];
+					if (ok && rest != 0) {
+						const uint32_t Cc = base[B];
+						ok = Cc < H && base[Cc] != NONE && consec[Cc] && (rest & ~bits_of(Cc)) == 0;
+					}
+				}
+			}
+			if (ok) { img[grec_w + (size_t)n * 4u + 2u] |= FASTMISS; nfastmiss++; }
+		}
+	}
 	for (uint32_t n = 0; n < H; n++) memcpy(&img[lds_rec_w + (size_t)n * 4u], &img[grec_w + (size_t)n * 4u], 16);
 	img[0] = 0x31525053u;   /* "SPR1" */
 	img[1] = H;
@@ -621,6 +687,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	img[12] = maxchain;
 	img[13] = nconsec;
 	img[14] = nfullbase;
+	img[15] = nfastmiss;
 	p.sparse_lds_bytes = lds_words * 4u;
 	p.layout = FSM_HIP_LAYOUT_SPARSE;
 	return 0;

@@ -601,7 +601,7 @@ struct SparsePol {
 			first = false;
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
 			const bool hit = (bits & sel) != 0u;
-			const uint32_t id = r.z & 0x1FFFFFFFu;
+			const uint32_t id = r.z & 0x0FFFFFFFu;
 			const bool dense = (r.z & 0x80000000u) != 0u;            /* a dense record has no bits */
 			const bool fb = !hit && hasbit && (r.z & 0x20000000u) != 0u;
 			uint32_t v = r.w + (uint32_t)__popcll(bits & below);
@@ -620,6 +620,100 @@ struct SparsePol {
 			live = !done;
 		}
 		return res;
+	}
+};
+
+/*
+ * SparseFastPol: SparsePol with the ENTRY AS THE STATE.  SparsePol carries a state id and begins every turn of its
+ * chain loop by loading the record of the id it holds: two or three dependent load -> wait -> ~30 vector + ~25 scalar
+ * instruction turns per input byte on a literal-set automaton (own record: a deep trie node, nearly always a miss;
+ * its base: the failure state; that one's base: a full shallow node), and the loop's control flow is scalar work of
+ * its own.  Here the walk state IS the current state's record {bits, base | flags, first} plus its id, fetched once
+ * when the state is entered, and a byte is evaluated in straight-line code against three records at once -- the own one
+ * (registers), its base's and that one's base's (two LDS reads; bases are nearly always among the H records nearest
+ * the start state, which live in LDS):
+ *     x = bits << (63 - bit)          bit 63 of x: the class's bit; popcount(x) - 1: its rank among the set bits below
+ *     hit   <=> x < 0 (signed);       next = first + popcount(x) - 1        (CONSEC records: children are consecutive ids)
+ * i.e. one 64-bit shift, two v_bcnt (the second adds `first - 1`), one sign test per record, then two selects.  A full
+ * base (every class's bit set: FULLBASE in SparsePol's terms) needs no special case: it simply always hits.
+ * Whether that is the whole story for a state is known when the table is planned (plan.cpp: records are re-based onto
+ * LDS-resident ancestors, FASTMISS says that every class a record does not own is answered by a CONSEC record within
+ * the next two levels), so one test and one wave vote per byte decide it; the lanes where it fails (a hit on a record
+ * that keeps an exception list, dense rows, classes without a bit) take SparsePol's general loop for that byte.  Used by the fixed-stride kernels on plain (non-eager) walks.
+ */
+struct SparseFastState {
+	uint32_t b0, b1;   /* the state's record: class bits */
+	uint32_t meta;     /* base | DENSE | CONSEC | FULLBASE */
+	uint32_t off;      /* first child / exception offset / dense row offset */
+	uint32_t id;
+};
+
+struct SparseFastPol : SparsePol {
+	typedef SparseFastState S;
+	typedef SparsePol::P P;
+	uint32_t nrec;     /* records exist for ids < nrec (= abs_min: absorbing states have none) */
+
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		SparsePol::setup(lds, a);
+		nrec = a.abs_min;
+	}
+	__device__ __forceinline__ S enter(uint32_t id) const
+	{
+		const uint32_t k = id < nrec ? id : 0u;        /* an absorbing state keeps its id and never looks at the record */
+		u32x4 r;
+		if (k < H) r = lrec[k]; else r = grec[k];       /* one flat load of a selected address (see SparsePol) */
+		S s = { r.x, r.y, r.z, r.w, id };
+		return s;
+	}
+	__device__ __forceinline__ S init(uint32_t code) const { return enter(code); }
+	__device__ __forceinline__ static uint32_t code(const S &s) { return s.id; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
+	__device__ __forceinline__ S next(const S &s, P p) const { return enter(SparsePol::next_t<false>(s.id, p)); }
+
+	/* one record against one class bit: does it own the class, and where does it lead (valid for CONSEC records) */
+	__device__ __forceinline__ static bool probe(uint32_t b0, uint32_t b1, uint32_t first, uint32_t sh, uint32_t &nxt)
+	{
+		const uint64_t x = (((uint64_t)b1 << 32) | b0) << sh;
+		nxt = (uint32_t)__builtin_popcount((uint32_t)x) + ((uint32_t)__builtin_popcount((uint32_t)(x >> 32)) + (first - 1u));
+		return (int32_t)(x >> 32) < 0;
+	}
+	__device__ __forceinline__ static bool consec(uint32_t meta) { return (meta & 0xC0000000u) == 0x40000000u; }
+
+	__device__ __forceinline__ S step_fast(const S &s, P p) const
+	{
+		const uint32_t sh = 63u - (p >> 8);                      /* (every class of the chunk owns a bit: walk16 checked) */
+		/* (the two base reads are unguarded: where the planner's FASTMISS flag is clear they may read anything -- an LDS read
+		 * cannot fault -- and the lane takes the general loop below) */
+		const uint32_t baseA = s.meta & 0x0FFFFFFFu;
+		const u32x4 rb = *(lds_rec_p)(uintptr_t)(lrec_lds + baseA * 16u);
+		const uint32_t baseB = rb.z & 0x0FFFFFFFu;
+		const u32x4 rc = *(lds_rec_p)(uintptr_t)(lrec_lds + baseB * 16u);
+		uint32_t nA, nB, nC;
+		const bool hA = probe(s.b0, s.b1, s.off, sh, nA), hB = probe(rb.x, rb.y, rb.w, sh, nB), hC = probe(rc.x, rc.y, rc.w, sh, nC);
+		(void)hC;
+		const bool live = s.id < nrec;
+		/* the record owns the class: its children must be consecutive ids; it does not: the planner vouches for the chain */
+		const bool good = (s.meta & (hA ? 0x40000000u : 0x10000000u)) != 0u || !live;
+		uint32_t n = hA ? nA : hB ? nB : nC;
+		if (!__all(good)) {
+			if (!good) n = SparsePol::next_t<true>(s.id, p);      /* the general chain loop, for these lanes only */
+		}
+		if (!live) n = s.id;
+		return enter(n);
+	}
+	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
+	{
+		uint32_t mx = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) mx = pre[k] > mx ? pre[k] : mx;
+		if (__all((mx >> 8) < 64u)) {
+#pragma unroll
+			for (int k = 0; k < 16; k++) st = step_fast(st, pre[k]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 16; k++) st = next(st, pre[k]);
+		}
 	}
 };
 
@@ -836,6 +930,11 @@ __device__ __forceinline__ LdsSelfState pick(bool c, const LdsSelfState &x, cons
 __device__ __forceinline__ CombSelfState pick(bool c, const CombSelfState &x, const CombSelfState &y)
 {
 	CombSelfState r = { c ? x.st : y.st, c ? x.sm : y.sm, c ? x.rng : y.rng };
+	return r;
+}
+__device__ __forceinline__ SparseFastState pick(bool c, const SparseFastState &x, const SparseFastState &y)
+{
+	SparseFastState r = { c ? x.b0 : y.b0, c ? x.b1 : y.b1, c ? x.meta : y.meta, c ? x.off : y.off, c ? x.id : y.id };
 	return r;
 }
 template <class Pol>

@@ -63,7 +63,7 @@ def decode_sparse(p, S1, lds_limit=160 * 1024):
             consec = (rec[:, 2] & 0x40000000) != 0                      # targets = first + rank: no list stored
             eval_ = np.where(consec, rec[:, 3] + pop, img[np.minimum(exo // 4 + rec[:, 3] + pop, len(img) - 1)])
             # FULLBASE: a miss resolves as first(base) + bit when the (LDS-resident, all-bits-set) base says so
-            bid = rec[:, 2] & 0x1FFFFFFF
+            bid = rec[:, 2] & 0x0FFFFFFF
             fullbase = ((rec[:, 2] & 0x20000000) != 0) & ~dense & ~sel & (b < 64)
             assert (bid[fullbase] < H).all()
             fval = lds[np.minimum(lro // 4 + bid * 4 + 3, len(lds) - 1)] + b
@@ -75,6 +75,47 @@ def decode_sparse(p, S1, lds_limit=160 * 1024):
             assert hops <= maxchain + 1
         got[n] = res
     return got
+
+
+def check_sparse_fast(p, got):
+    """SparseFastPol::step_fast (walk_kernels.h) for every record it may be used on: own record, base, base's base -- all
+    three read as the kernel reads them (the bases from the LDS mirror, unguarded) -- must give SparsePol's answer for every
+    class that owns a bit, whenever the kernel's own test lets the lane through (own hit: CONSEC; own miss: FASTMISS)."""
+    img = p.get("sparse").astype(np.int64)
+    H, HDE, ldo, lro, gro, gdo, exo, N, Cn = (int(x) for x in img[1:10])
+    pm = img[16:16 + 128]
+    pm = np.stack([pm & 0xffff, pm >> 16], axis=1).reshape(-1)
+    bit_b = pm >> 8
+    bytes_with_bit = np.nonzero(bit_b < 64)[0]
+    lds = img[:gro // 4]
+    nfast = 0
+
+    def rec_g(n):
+        return img[gro // 4 + n * 4: gro // 4 + n * 4 + 4]
+
+    def rec_l(n):      # an LDS read cannot fault: out of range reads garbage
+        o = lro // 4 + n * 4
+        return lds[o:o + 4] if o + 4 <= len(lds) else np.zeros(4, np.int64)
+
+    def probe(r, b):
+        bits = int(r[0]) | (int(r[1]) << 32)
+        return (bits >> b) & 1 == 1, int(r[3]) + bin(bits & ((1 << b) - 1)).count("1")
+
+    for n in range(N):
+        ra = rec_g(n)
+        rb = rec_l(int(ra[2]) & 0x0FFFFFFF)
+        rc = rec_l(int(rb[2]) & 0x0FFFFFFF)
+        for by in bytes_with_bit[:: max(1, len(bytes_with_bit) // 80)]:
+            b = int(bit_b[by])
+            hA, nA = probe(ra, b)
+            hB, nB = probe(rb, b)
+            hC, nC = probe(rc, b)
+            good = (int(ra[2]) & (0x40000000 if hA else 0x10000000)) != 0
+            if not good:
+                continue
+            nfast += 1
+            assert (nA if hA else nB if hB else nC) == got[n][by], (n, by)
+    return nfast, int(img[15])
 
 
 def decode_want(flat, p):
@@ -204,6 +245,7 @@ def check_plan(flat, layout):
             assert np.array_equal(emits[:S1 - 1], em[:S1 - 1] != 0)
     elif p.layout == LAYOUT_SPARSE:
         got = decode_sparse(p, S1)
+        check_sparse_fast(p, got)
     else:
         tab = p.get("glob_tab").astype(np.int64)
         st = np.arange(S1)[:, None] * Cn * 4
@@ -239,7 +281,12 @@ def test_auto_layout_choices(built):
     # breadth-first numbering makes every trie node's children consecutive: (nearly) no exception lists remain
     assert int(img[13]) > 0.9 * (int(img[8]) - int(img[10])) * 0.5 and int(img[11]) < 0.05 * pa.S1
     want = decode_want(ac, pa)
-    assert np.array_equal(decode_sparse(pa, pa.S1), want)
+    got = decode_sparse(pa, pa.S1)
+    assert np.array_equal(got, want)
+    # the straight-line walk (SparseFastPol) agrees wherever its own test lets a lane through (here the depth-1 nodes are
+    # not full -- not every 2-gram occurs -- so most misses need a fourth level and stay with the general loop)
+    nfast, nflag = check_sparse_fast(pa, got)
+    assert nfast > 0 and nflag > 0
 
 
 def test_sparse_fullbase_shortcut(built):
@@ -252,8 +299,15 @@ def test_sparse_fullbase_shortcut(built):
     ac = FlatDfa.from_strings(words, 2, list(range(len(words))))
     pa = Plan(ac, LAYOUT_SPARSE)
     img = pa.get("sparse")
-    assert int(img[14]) >= 16 and int(img[13]) > 0 and int(img[11]) == 0     # FULLBASE records, CONSEC records, no lists
-    assert np.array_equal(decode_sparse(pa, pa.S1), decode_want(ac, pa))
+    # FULLBASE records, CONSEC records; the only exception lists are those of deep records re-based onto shallow ones
+    assert int(img[14]) >= 16 and int(img[13]) > 0 and int(img[11]) < int(img[8])
+    got = decode_sparse(pa, pa.S1)
+    assert np.array_equal(got, decode_want(ac, pa))
+    # ... and with full depth-1 nodes every record's misses resolve within two more levels: FASTMISS (nearly) everywhere,
+    # deep records included (re-based onto LDS-resident ancestors): the straight-line walk takes (nearly) every byte
+    nfast, nflag = check_sparse_fast(pa, got)
+    nrec = int(img[8]) - int(img[10])
+    assert nflag >= 0.95 * nrec and nfast >= 0.85 * nrec * 4, (nfast, nflag, nrec)
 
 
 def test_wide_eager_sets(built):
