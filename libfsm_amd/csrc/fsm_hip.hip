@@ -385,6 +385,13 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 				a.ew_mask = d->d_ew_mask;
 			}
 		}
+		/* fin_index(): code / fin_div as a multiply where that is exact for every code the walk can produce */
+		a.fin_mul = 0;
+		if (a.fin_div > 1u) {
+			uint32_t maxcode = 0;
+			for (uint32_t n2 = 0; n2 < p.S1; n2++) maxcode = d->enc_host[n2] > maxcode ? d->enc_host[n2] : maxcode;
+			if ((uint64_t)maxcode * a.fin_div < ((uint64_t)1 << 32)) a.fin_mul = (uint32_t)((((uint64_t)1 << 32) / a.fin_div) + 1u);
+		}
 		a.tab = d->d_tab;
 		a.fin = d->d_fin;
 		a.btab = d->d_btab;
@@ -997,7 +1004,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_PK_RMIN: if (value < 7 || value > (int)FSMHIP_PK_RMAX) { errno = EINVAL; return -1; } d->knob_pk_rmin = value; break;
 	case FSM_HIP_KNOB_PK_RMAX: if (value != 0 && (value < 7 || value > (int)FSMHIP_PK_RMAX)) { errno = EINVAL; return -1; } d->knob_pk_rmax = value; break;
 	case FSM_HIP_KNOB_PK_DEBUG: d->knob_pk_debug = value; break;
-	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value != 0; break;
+	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value < 0 || value > 2 ? 1 : value; break;
 	case FSM_HIP_KNOB_PK_MEAN_MAX: if (value < 0) { errno = EINVAL; return -1; } d->knob_pk_mean_max = value; break;
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;

@@ -7,7 +7,7 @@ hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a
 {
 	if (pol == POL_SPARSE && eager == 0 && c.sparse_fast && c.mode == IN_DIRECT) {
 		/* fixed-stride rows, plain walk: the record is the state (SparseFastPol) */
-		walk_fn k = !c.prefetch && c.nb == 4 ? walk_direct_np<SparseFastPol, 4> : c.nb == 4 ? walk_direct<SparseFastPol, 4, 1> : walk_direct<SparseFastPol, 8, 1>;
+		walk_fn k = !c.prefetch && c.nb == 4 ? (c.sparse_fast == 2 ? walk_direct_np<SparseFastPol, 2> : walk_direct_np<SparseFastPol, 4>) : c.nb == 4 ? walk_direct<SparseFastPol, 4, 1> : walk_direct<SparseFastPol, 8, 1>;
 		return launch_fn(k, c, a, grid, block, s);
 	}
 	if (pol == POL_SPARSE) return launch_family<SparsePol>(eager, c, a, grid, block, s);

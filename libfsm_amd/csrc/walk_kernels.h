@@ -68,6 +68,7 @@ struct WalkArgs {
 	uint32_t        start;    /* encoded start state                                  */
 	uint32_t        abs_min;  /* encoded states >= abs_min are absorbing              */
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
+	uint32_t        fin_mul;  /* 0, or floor(2^32 / fin_div) + 1: then encoded state * fin_mul >> 32 is that quotient (fin_index()) */
 	uint32_t        early;    /* bit 0: retire a wavefront once every lane is absorbing;
 	                           * bit 1: absorbing lanes stop loading their input;
 	                           * bit 2: never skip a chunk (skip16 off: measurement aid) */
@@ -116,6 +117,16 @@ __device__ __forceinline__ uint32_t start_code(const WalkArgs &a, uint64_t i, bo
 	const uint32_t sid = a.state_io[i];
 	if (sid == FSMHIP_STATE_START) return a.start;
 	return a.enc_of[sid == FSMHIP_STATE_DEAD || sid >= a.nstates ? a.nstates : sid];
+}
+
+/* encoded state -> index of the per-state tables.  A division by a run-time value is ~30 vector instructions: nothing next
+ * to a 1 KiB input, 8 % of a 36-byte one.  Most layouts index by the code itself; the others by a multiply the host prepared
+ * (exact while code * fin_div < 2^32, which it checks) */
+__device__ __forceinline__ uint32_t fin_index(const WalkArgs &a, uint32_t code)
+{
+	if (a.fin_div == 1u) return code;
+	if (a.fin_mul != 0u) return __umulhi(code, a.fin_mul);
+	return code / a.fin_div;
 }
 
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_PACKED = 4 };
@@ -651,16 +662,10 @@ struct SparseFastState {
 struct SparseFastPol : SparsePol {
 	typedef SparseFastState S;
 	typedef SparsePol::P P;
-	uint32_t nrec;     /* records exist for ids < nrec (= abs_min: absorbing states have none) */
-
-	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
-	{
-		SparsePol::setup(lds, a);
-		nrec = a.abs_min;
-	}
+	/* records exist for ids < abs_min (absorbing states have none) */
 	__device__ __forceinline__ S enter(uint32_t id) const
 	{
-		const uint32_t k = id < nrec ? id : 0u;        /* an absorbing state keeps its id and never looks at the record */
+		const uint32_t k = id < abs_min ? id : 0u;     /* an absorbing state keeps its id and never looks at the record */
 		u32x4 r;
 		if (k < H) r = lrec[k]; else r = grec[k];       /* one flat load of a selected address (see SparsePol) */
 		S s = { r.x, r.y, r.z, r.w, id };
@@ -692,7 +697,7 @@ struct SparseFastPol : SparsePol {
 		uint32_t nA, nB, nC;
 		const bool hA = probe(s.b0, s.b1, s.off, sh, nA), hB = probe(rb.x, rb.y, rb.w, sh, nB), hC = probe(rc.x, rc.y, rc.w, sh, nC);
 		(void)hC;
-		const bool live = s.id < nrec;
+		const bool live = s.id < abs_min;
 		/* the record owns the class: its children must be consecutive ids; it does not: the planner vouches for the chain */
 		const bool good = (s.meta & (hA ? 0x40000000u : 0x10000000u)) != 0u || !live;
 		uint32_t n = hA ? nA : hB ? nB : nC;
@@ -1064,7 +1069,7 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 __device__ __forceinline__ void write_result(const WalkArgs &a, uint64_t word, uint64_t i, bool valid, uint32_t st)
 {
 	uint32_t end = FSMHIP_NO_MATCH;
-	const uint32_t idx = st / a.fin_div;
+	const uint32_t idx = fin_index(a, st);
 	if (valid) end = a.fin[idx];
 	if (valid && a.end_out != nullptr) a.end_out[i] = end;
 	if (valid && a.out2 != nullptr) a.out2[i] = a.fin2[idx];
@@ -1335,6 +1340,18 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
 
+/* 16 bytes of which [addr, limit) exist (out of line: the last step or two of a batch) */
+__device__ __noinline__ u32x4 load_chunk_edge(uint64_t addr, bool want, uint64_t limit, uint64_t safe)
+{
+	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;
+	if (!want) return *(glb_chunk_p)safe;
+	if (addr + 16u <= limit) return *(glb_chunk_p)addr;
+	uint32_t d[4] = {0u, 0u, 0u, 0u};
+	for (uint32_t k = 0; k < 15u && addr + k < limit; k++)
+		d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(addr)[k] << ((k & 3u) * 8u);
+	return u32x4{d[0], d[1], d[2], d[3]};
+}
+
 /*
  * One input per lane, 64 consecutive inputs per wavefront and step of a persistent loop.  The walk of a short input
  * (the lines retest / rx feed) is a few hundred cycles; what it waited for, in the first version of this kernel, were
@@ -1367,19 +1384,11 @@ walk_generic(const WalkArgs a)
 	const uint64_t limit = base + (a.off != nullptr ? a.off[a.n] : a.n * a.stride);
 	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);   /* 1 KiB that is always there: what a lane without a chunk reads */
 
-	/* 16 bytes at any address; [addr, limit) from byte loads where addr + 16 > limit */
-	auto load_chunk = [&](uint64_t addr, bool want) -> u32x4 {
-		const bool edge = want && addr + 16u > limit;
-		u32x4 x = *(glb_chunk_p)(want && !edge ? addr : safe);      /* unconditional: the loads of a step are counted, not waited for one by one */
-		if (__any(edge)) {
-			if (edge) {
-				uint32_t d[4] = {0u, 0u, 0u, 0u};
-				for (uint32_t k = 0; k < 15u && addr + k < limit; k++)
-					d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(addr)[k] << ((k & 3u) * 8u);
-				x = u32x4{d[0], d[1], d[2], d[3]};
-			}
-		}
-		return x;
+	/* 16 bytes at any address.  `edgy` (wave-uniform: some input of this step ends within 16 bytes of the batch's end --
+	 * the batch's last step or two) sends every load of the step through the out-of-line byte assembly */
+	auto load_chunk = [&](uint64_t addr, bool want, bool edgy) -> u32x4 {
+		if (edgy) return load_chunk_edge(addr, want, limit, safe);
+		return *(glb_chunk_p)(want ? addr : safe);      /* unconditional: the loads of a step are counted, not waited for one by one */
 	};
 
 	/* the offsets / lengths of a step's inputs, asked for one step ahead (clamped indices: the loads are unconditional) */
@@ -1408,9 +1417,10 @@ walk_generic(const WalkArgs a)
 		const uint64_t p0 = base + beg;
 		const uint64_t nchunks = (len + 15u) / 16u;
 		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
+		const bool edgy = __any(nchunks != 0 && p0 + 16u * nchunks > limit);
 		u32x4 wq[NC];
 #pragma unroll
-		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(p0 + 16u * j, j < nchunks);
+		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(p0 + 16u * j, j < nchunks, edgy);
 		/* the previous step's results: their fin[] lookup is in flight with this step's chunks */
 		if (pend) write_result(a, ptile, pi, pvalid, pcode);
 #pragma unroll
@@ -1428,10 +1438,10 @@ walk_generic(const WalkArgs a)
 			}
 		}
 		if (__any(nchunks > NC)) {
-			u32x4 w[1] = { load_chunk(p0 + 16u * NC, nchunks > NC) };
+			u32x4 w[1] = { load_chunk(p0 + 16u * NC, nchunks > NC, edgy) };
 			for (uint64_t c = NC; __any(c < nchunks); c++) {
 				if (c < nchunks) {
-					const u32x4 wn = load_chunk(p0 + 16u * (c + 1u), c + 1u < nchunks);   /* next chunk in flight */
+					const u32x4 wn = load_chunk(p0 + 16u * (c + 1u), c + 1u < nchunks, edgy);   /* next chunk in flight */
 					const uint64_t left = len - c * 16u;
 					if (__all(left >= 16u)) step16<Pol, 1>(pol, st, w);
 					else step16_part(pol, st[0], w[0], 0u, left < 16u ? (uint32_t)left : 16u);
@@ -1458,7 +1468,7 @@ walk_generic(const WalkArgs a)
  * is filled with atomic ORs and must have been cleared on the launch stream. */
 __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i, uint32_t st)
 {
-	const uint32_t idx = st / a.fin_div;
+	const uint32_t idx = fin_index(a, st);
 	const uint32_t end = a.fin[idx];
 	if (a.end_out != nullptr) a.end_out[i] = end;
 	if (a.out2 != nullptr) a.out2[i] = a.fin2[idx];

@@ -87,7 +87,7 @@ packed_finish(const WalkArgs a)
 	for (uint64_t word = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); word < nwords; word += nwaves) {
 		const uint64_t i = word * 64u + lane;
 		const bool valid = i < a.n;
-		const uint32_t idx = (valid ? a.pk_codes[i] : 0u) / a.fin_div;
+		const uint32_t idx = fin_index(a, valid ? a.pk_codes[i] : 0u);
 		const uint32_t end = valid ? a.fin[idx] : FSMHIP_NO_MATCH;
 		if (valid && a.end_out != nullptr) a.end_out[i] = end;
 		if (valid && a.out2 != nullptr) a.out2[i] = a.fin2[idx];
