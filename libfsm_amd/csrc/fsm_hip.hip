@@ -491,13 +491,19 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
 	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
-	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA 12
-	 * (launch.h eager_dma_threads), eager ragged / generic 8. */
+	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA on the 64-bit column
+	 * table 12 (launch.h eager_dma_threads), eager ragged / generic 8. */
 	int wmax = 16;
 	if (mode == IN_RAGGED) wmax = eager ? 8 : 12;
 	else if (eager && mode == IN_GENERIC) wmax = 8;
-	else if (eager && mode == IN_LDSDMA) wmax = 12;
+	else if (eager && mode == IN_LDSDMA) wmax = ((layout == FSM_HIP_LAYOUT_TINY && d->plan.tiny5_col.empty()) || layout == FSM_HIP_LAYOUT_COMB ||
+		                                            layout == FSM_HIP_LAYOUT_COMBSELF || layout == FSM_HIP_LAYOUT_LDSSELF) ? 12 : 16;   /* launch.h eager_dma_threads */
 	else if (layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA) wmax = 12;
+	/* the plain row table behind LDS-DMA: its walk keeps the LDS array ~85 % busy (two reads per byte, the table read
+	 * replayed for bank conflicts: profiles/r04f_pmc_eager_lds.txt); 14 waves measured 4.24 / 4.01 TB/s where 16 gave
+	 * 3.77 / 3.71 and 12 4.01 / 3.99 (354- and 1132-state tables, 8e6 x 1 KiB: profiles/r04h_eager_probe_8M.txt).  The
+	 * eager form of the same walk wants 16 (3.53 vs 3.33 at 14, 3.12 at 12). */
+	else if (layout == FSM_HIP_LAYOUT_LDS && mode == IN_LDSDMA && !eager) wmax = 14;
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16 &&
 	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA)) waves = d->knob_waves;   /* that kernel is compiled for 12 */

@@ -77,10 +77,16 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	return launch_fn(k, c, a, grid, block, s);
 }
 
-/* thread cap of the eager LDS-DMA kernel: 12 waves (<= 170 VGPRs): the chunk-level eager walk (EagerPol::walk16)
- * keeps the 16 lookups of a chunk live across its two passes next to the tile and the 64-bit id set, which
- * spilled 2-44 VGPRs under the 128 of a 16-wave workgroup */
-template <class Pol> struct eager_dma_threads { static constexpr int value = 768; };
+/* thread cap of the eager LDS-DMA kernel.  The chunk-level eager walk (EagerPol::walk16) keeps a chunk's 16 lookups live
+ * across its two passes next to the tile and the 64-bit id set: every layout now fits the 128 VGPRs of a 16-wave
+ * workgroup without spilling (96-127, tools/kernel_resources.py) except the 64-bit column table, the class comb and the two
+ * self-loop-mask layouts (a third register per state), which spill 10 there and stay at 12 waves (<= 170 VGPRs).  Round 2 ran all of them at 12 waves: 0.71 of the plain walk's rate
+ * on the lds layout, next to 12 / 16 = 0.75 (profiles/r02f_eager_probe.txt). */
+template <class Pol> struct eager_dma_threads { static constexpr int value = 1024; };
+template <> struct eager_dma_threads<TinyPol<uint64_t>> { static constexpr int value = 768; };
+template <> struct eager_dma_threads<CombPol> { static constexpr int value = 768; };       /* 10 spills at 1024, so do the next two */
+template <> struct eager_dma_threads<CombSelfPol> { static constexpr int value = 768; };
+template <> struct eager_dma_threads<LdsSelfPol> { static constexpr int value = 768; };
 
 /* eager-output walks: the policy wrapped; the register-set form also behind LDS-DMA (128-byte segments) */
 template <class EP, bool DMA, int DMAT>

@@ -256,6 +256,19 @@ struct Tiny5Pol {
 	__device__ __forceinline__ uint32_t next(uint32_t st, P v) const { return __builtin_amdgcn_ubfe(v, st, 5u); }
 };
 
+/*
+ * The lookup layouts without a self-loop mask (LdsPol, CombPol, Comb256Pol) are bound by the LDS array, not by latency:
+ * a wave's table read has 64 random addresses and is replayed for every bank conflict (profiles/r03r_pmc_c3t_comb256.txt:
+ * 6.3 LDS cycles per wave read where 2 are the conflict-free cost; SQ_LDS_IDX_ACTIVE = 81 % of the kernel's cycles per CU).
+ * A lane that has reached an absorbing state can no longer change state (fsm_exec stops pulling bytes at a missing edge,
+ * exec.c:133-138) but its reads still take part in those replays.  mask_absorbing(): such a lane sees its chunk as 16
+ * zero bytes -- delta(absorbing, b) is the state itself for every b -- so all the absorbing lanes of a wave read ONE
+ * address per state (a broadcast, no conflict).  One compare + four ANDs per chunk, nothing on the per-byte chain.  (A
+ * per-byte `if (absorbing) skip the read` was measured first: the exec-mask branches cost 27 %, profiles/r04d_absorbing_branch_per_byte_slower.txt.)
+ * (a.early & 8) switches the masking off for A/B runs.
+ */
+__device__ __forceinline__ uint32_t absorbing_limit(const WalkArgs &a) { return (a.early & 8u) ? 0xFFFFFFFFu : a.abs_min; }
+
 struct LdsPol {
 	static constexpr bool heavy_next = false;
 	typedef uint32_t P;
@@ -273,8 +286,9 @@ struct LdsPol {
 		bp = setup_btab(lds, a);
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		tab = lds + FSMHIP_BTAB_BYTES;
-		abs_min = a.abs_min;
+		abs_min = absorbing_limit(a);
 	}
+	__device__ __forceinline__ bool absorbing(S s) const { return s >= abs_min; }
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
@@ -352,8 +366,9 @@ struct CombPol {
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		comb = reinterpret_cast<const uint32_t *>(lds + FSMHIP_BTAB_BYTES);
 		dfl = comb + a.tab_bytes / 4u - 256u; /* image = comb[n], dflt[256] */
-		abs_min = a.abs_min;
+		abs_min = absorbing_limit(a);
 	}
+	__device__ __forceinline__ bool absorbing(S s) const { return s >= abs_min; }
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
@@ -376,6 +391,7 @@ struct Comb256Pol {
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	const uint32_t *comb;   /* LDS comb array indexed by row offset + byte: next << 16 | owner */
 	uint32_t dflt_e;        /* the default state in entry form */
+	uint32_t abs_e;         /* entries >= this lead to absorbing states (absorbing_limit() << 16) */
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return (tab_bytes + 15u) & ~15u; }
 	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
@@ -383,7 +399,10 @@ struct Comb256Pol {
 		copy_table(lds, a);
 		comb = reinterpret_cast<const uint32_t *>(lds);
 		dflt_e = a.dflt << 16;
+		const uint32_t lim = absorbing_limit(a);
+		abs_e = lim > 0xFFFFu ? 0xFFFFFFFFu : lim << 16;
 	}
+	__device__ __forceinline__ bool absorbing(S s) const { return s >= abs_e; }
 	__device__ __forceinline__ P pre(uint32_t b) const { return b; }
 	__device__ __forceinline__ S next(S s, P b) const
 	{
@@ -765,6 +784,8 @@ struct EagerPol : Pol {
 		return st;
 	}
 	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
+	template <class Q = Pol>
+	__device__ __forceinline__ auto absorbing(const S &st) const -> decltype(static_cast<const Q *>(nullptr)->absorbing(st.s)) { return Pol::absorbing(st.s); }
 	/* a chunk that changes no state emits nothing either */
 	template <class Q = Pol>
 	__device__ __forceinline__ auto skip16(const S &st, const P (&pre)[16]) const
@@ -789,23 +810,25 @@ struct EagerPol : Pol {
 		return st;
 	}
 	/* A whole 16-byte chunk at once.  Entering a state with outputs is rare (a pattern has just completed),
-	 * so the chunk is first walked as a plain chunk while one running maximum of (state - lo_end) notes
-	 * whether ANY of the 16 states entered lies outside [lo_end, hi_begin): 2 operations per byte instead
-	 * of the 4 + branch of next().  Only the lanes that did enter one re-walk the chunk byte by byte from
+	 * so the chunk is first walked as a plain chunk while one running MINIMUM of the states entered notes
+	 * whether any of them lies below lo_end (the non-absorbing states with outputs; v_min3: half an
+	 * operation per byte, where next() has 4 + a branch and the first form of this test -- a running maximum
+	 * of state - lo_end -- had 2); the states from hi_begin up are absorbing, so one of those was entered in
+	 * this chunk iff the chunk ENDS in it.  Only the lanes that did enter one re-walk the chunk byte by byte from
 	 * its first state with the exact per-byte rule.  A lane that starts the chunk in an absorbing state
 	 * cannot enter anything: its outputs were collected when it got there. */
 	template <class Q = Pol, class = typename std::enable_if<!Q::heavy_next>::type>
 	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
 	{
 		typename Pol::S s = st.s;
-		uint32_t m = 0;
+		uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			s = Pol::next(s, pre[k]);
-			const uint32_t d = Pol::code(s) - lo_end;
-			m = d > m ? d : m;
+			const uint32_t c = Pol::code(s);
+			m = c < m ? c : m;
 		}
-		if (m >= span && Pol::code(st.s) < abs_min_code) {
+		if ((m < lo_end || Pol::code(s) >= hi_begin) && Pol::code(st.s) < abs_min_code) {
 			S t = st;
 #pragma unroll
 			for (int k = 0; k < 16; k++) t = next(t, pre[k]);
@@ -870,6 +893,8 @@ struct EagerWidePol : Pol {
 	}
 	__device__ __forceinline__ static uint32_t code(const S &st) { return Pol::code(st.s); }
 	template <class Q = Pol>
+	__device__ __forceinline__ auto absorbing(const S &st) const -> decltype(static_cast<const Q *>(nullptr)->absorbing(st.s)) { return Pol::absorbing(st.s); }
+	template <class Q = Pol>
 	__device__ __forceinline__ auto skip16(const S &st, const P (&pre)[16]) const
 		-> decltype(static_cast<const Q *>(nullptr)->skip16(st.s, pre))
 	{
@@ -902,14 +927,14 @@ struct EagerWidePol : Pol {
 	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
 	{
 		typename Pol::S s = st.s;
-		uint32_t m = 0;
+		uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			s = Pol::next(s, pre[k]);
-			const uint32_t d = Pol::code(s) - lo_end;
-			m = d > m ? d : m;
+			const uint32_t c = Pol::code(s);
+			m = c < m ? c : m;
 		}
-		if (m >= hi_begin - lo_end && Pol::code(st.s) < abs_min_code) {
+		if ((m < lo_end || Pol::code(s) >= hi_begin) && Pol::code(st.s) < abs_min_code) {
 			S t = st;
 #pragma unroll
 			for (int k = 0; k < 16; k++) t = next(t, pre[k]);
@@ -1042,15 +1067,28 @@ __device__ __forceinline__ void walk_chunk(const Pol &pol, typename Pol::S &st, 
 	for (int k = 0; k < 16; k++) st = pol.next(st, pre[k]);
 }
 
+/* mask_absorbing (see absorbing_limit()): the chunk as a lane in an absorbing state gets to see it */
+template <class Pol>
+__device__ __forceinline__ auto mask_absorbing(const Pol &pol, const typename Pol::S &st, const u32x4 &w, int)
+	-> decltype(pol.absorbing(st), u32x4())
+{
+	const uint32_t m = pol.absorbing(st) ? 0u : 0xFFFFFFFFu;
+	return u32x4{w.x & m, w.y & m, w.z & m, w.w & m};
+}
+template <class Pol>
+__device__ __forceinline__ u32x4 mask_absorbing(const Pol &, const typename Pol::S &, const u32x4 &w, long) { return w; }
+
 template <class Pol, int ROWS>
 __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
 	if (ROWS == 1 && skip_chunk_raw(pol, st[0], w[0], 0)) return;
 	typename Pol::P pre[ROWS][16];
 #pragma unroll
-	for (int r = 0; r < ROWS; r++)
+	for (int r = 0; r < ROWS; r++) {
+		const u32x4 wm = mask_absorbing(pol, st[r], w[r], 0);
 #pragma unroll
-		for (int k = 0; k < 16; k++) pre[r][k] = pre_of(pol, w[r], k, 0);
+		for (int k = 0; k < 16; k++) pre[r][k] = pre_of(pol, wm, k, 0);
+	}
 	if (ROWS == 1) {
 		if (skip_chunk(pol, st[0], pre[0], 0)) return;
 		walk_chunk(pol, st[0], pre[0], 0);

@@ -21,8 +21,11 @@
  *     fsm_isend(state); else *end = state, return 1          src/libfsm/exec.c:85-167
  *   fsm_endid_count / fsm_endid_get (sorted unique ids,
  *     0 = buffer too small, 1 otherwise)                     src/libfsm/endids.c:653-755
- * Captures and eager outputs (exec.c:41-44, :126-144) are outside the
- * accelerated path and are not restated.
+ *   eager outputs: the ids attached to the start state and to every
+ *     state entered are delivered through the callback, in order
+ *     (oracle_exec_eager_stride below)                      src/libfsm/exec.c:126-144
+ * Captures (exec.c:41-44) are outside the accelerated path and are not
+ * restated.
  */
 #define _POSIX_C_SOURCE 200809L
 #include <errno.h>

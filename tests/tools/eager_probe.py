@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--len", type=int, default=1024)
     ap.add_argument("--layouts", default="0", help="comma list: 0 auto, 2 lds, 8 ldsself, 4 global")
+    ap.add_argument("--waves", default="0", help="comma list of KNOB_WAVES values (0 = the library's choice)")
     a = ap.parse_args()
     import torch
     import libfsm_amd as hip
@@ -45,8 +46,11 @@ def main():
             info = dfa.info()
             W = dfa.eager_words()
             sets = torch.zeros((n, W), dtype=torch.int64, device="cuda")
-            for name, fn in (("plain walk", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)),
-                             ("eager walk", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n, end.data_ptr(), sets.data_ptr()))):
+            for wv, (name, fn) in [(int(w), nf) for w in a.waves.split(",") for nf in (
+                    ("plain walk", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)),
+                    ("eager walk", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n, end.data_ptr(), sets.data_ptr())))]:
+                dfa.tune(hip.KNOB_WAVES, wv)
+                name = f"{name} waves={wv}"
                 ms = []
                 for _ in range(4):
                     fn()

@@ -98,6 +98,10 @@ def main():
             if a.set == "rows":  # one vs two inputs per lane (needs walk_direct<Pol,4,2> instantiated: profiles/r03b_*; rows=2 is ignored otherwise)
                 variants = [(-1, 0, 0, 0, 0, -1, 1), (hip.IN_DIRECT, 4, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 2, 16, 0, 0, 1), (hip.IN_DIRECT, 4, 2, 12, 0, 0, 1),
                             (hip.IN_DIRECT, 4, 2, 8, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1), (hip.IN_LDSDMA, 128, 1, 8, 0, 4, 1)]
+            if a.set == "c3t":  # round 3: which input path feeds a lookup chain that sits next to a 90 KB table
+                variants = [(-1, 0, 0, 0, 0, -1, 1), (hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_LDSDMA, 64, 1, 16, 0, 4, 1), (hip.IN_LDSDMA, 64, 1, 14, 0, 0, 1),
+                            (hip.IN_LDSDMA, 64, 1, 12, 0, 0, 1), (hip.IN_LDSDMA, 128, 1, 8, 0, 4, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 9),
+                            (hip.IN_DIRECT, 4, 1, 16, 0, 2, 1), (hip.IN_DIRECT, 8, 1, 14, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 12, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]
             if a.set == "dma":  # LDS-DMA staging next to an LDS table: how many waves fit / pay
                 variants = [(hip.IN_LDSDMA, 128, 1, w, b, m, 1) for w in (16, 14, 12, 10, 8) for b in (0, 1) for m in (0, 4)]
                 variants += [(hip.IN_LDSDMA, 64, 1, 16, 0, 0, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 2, 1), (hip.IN_DIRECT, 8, 1, 16, 0, 0, 1)]

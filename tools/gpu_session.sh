@@ -35,7 +35,11 @@ for step in "$@"; do
 	benchnode) FSM_BENCH_NODE_FRONT=1 FSM_BENCH_NODE_REPLICAS=2 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_benchnode.json 2> gpurun_out/${TAG}_benchnode.err; echo "benchnode rc=$?"; python -c "import json; r=json.loads(open('gpurun_out/${TAG}_benchnode.json').read().strip().splitlines()[-1]); print(r['value'], r.get('node_front'))" ;;
 	ragged) timeout 400 python tests/tools/ragged.py > gpurun_out/${TAG}_ragged.txt 2>&1; echo "ragged rc=$?"; tail -30 gpurun_out/${TAG}_ragged.txt ;;
 	c5)     timeout 400 python tests/tools/c5_probe.py --layout 7 --n 2000000 --variants "10=0,2=4;10=1,2=4;10=1,2=8;1=1" > gpurun_out/${TAG}_c5.txt 2>&1; echo "c5 rc=$?"; tail -12 gpurun_out/${TAG}_c5.txt ;;
-	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
+	c3tab)  for kv in 6=1 6=9 6=1; do timeout 300 python bench.py --workload c3t --steps 10 --warmup 2 --no-cpu-baseline --subs none --no-full-parity --knob $kv > gpurun_out/${TAG}_c3tab_$kv.json 2> gpurun_out/${TAG}_c3tab_$kv.err; python -c "import json; r=json.loads(open('gpurun_out/${TAG}_c3tab_$kv.json').read().strip().splitlines()[-1]); print('c3t knob $kv', r['value'], r['unit'], r['roofline']['achieved'], r.get('parity'))"; done ;;
+	eagerpmc) timeout 600 python tools/pmc_kernel.py --match walk_ldsdma --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" --out gpurun_out/${TAG}_eagerpmc.json -- python tests/tools/eager_probe.py --k 40 --layouts 0 --waves ${EAGER_WAVES:-0} > gpurun_out/${TAG}_eagerpmc.txt 2>&1; tail -70 gpurun_out/${TAG}_eagerpmc.txt ;;
+	c3tpmc) timeout 600 python tools/pmc_kernel.py --match walk_direct --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" --out gpurun_out/${TAG}_c3tpmc.json -- python bench.py --workload c3t --steps 2 --warmup 1 --no-cpu-baseline --subs none --no-full-parity --knob ${C3T_KNOB:-6=1} > gpurun_out/${TAG}_c3tpmc.txt 2>&1; tail -40 gpurun_out/${TAG}_c3tpmc.txt ;;
+	c3tsweep) timeout 400 python tests/tools/sweep.py --set c3t --workloads c3t --layouts ${C3T_LAYOUTS:-5} > gpurun_out/${TAG}_c3tsweep.txt 2>&1; echo "sweep rc=$?"; grep -v '^#' gpurun_out/${TAG}_c3tsweep.txt | tail -30 ;;
+	eager)  timeout 300 python tests/tools/eager_probe.py --layouts 0 --waves ${EAGER_WAVES:-0,12} > gpurun_out/${TAG}_eager.txt 2>&1; echo "eager rc=$?"; tail -12 gpurun_out/${TAG}_eager.txt ;;
 	sweep)  timeout 400 python tests/tools/sweep.py --set r2 --workloads c3,c2 > gpurun_out/${TAG}_sweep.txt 2>&1; echo "sweep rc=$?"; grep -v '^#' gpurun_out/${TAG}_sweep.txt | tail -80 ;;
 	prof)   for wl in c3 c2 c5; do
 	            L2=""; [ $wl = c5 ] && L2="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"
