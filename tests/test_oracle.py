@@ -101,6 +101,40 @@ def test_reference_vm_agrees_with_fsm_exec():
         assert np.array_equal(f.vm_match_stride(data, v), ret)
 
 
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_reference_vm_on_a_literal_set_automaton():
+    """Found by bench.py's C5 reference leg (round 3): on re_strings automata of a few thousand states the reference's
+    VM v2 stops agreeing with fsm_exec -- its encoder keeps the index into the far-branch address table in the
+    instruction's 16-bit dest field (src/libfsm/vm/v2.c:71, :129-131), which wraps beyond 65 535 far branches --
+    while v1 and the oracle agree.  v1 is therefore the VM baseline for configs[4]; v2's verdict is recorded, not
+    asserted (a fixed reference would agree)."""
+    import threading
+    out = {}
+
+    def work():
+        rng = np.random.RandomState(5)
+        alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-", np.uint8)
+        words = sorted(set(bytes(alpha[rng.randint(0, 64, rng.randint(4, 9))]) for _ in range(1000)))
+        f = RefFsm.re_strings(words, 0, True)
+        rows = alpha[rng.randint(0, 64, (1200, 128))].astype(np.uint8)
+        for i in range(0, len(rows), 4):
+            w = words[i % len(words)]
+            rows[i, -len(w):] = np.frombuffer(w, np.uint8)
+        ret, end = f.exec_hoisted_stride(rows)
+        o_ret, o_end = Oracle(f.flatten()).exec_stride(rows)
+        out.update(ret=ret, end=end, o_ret=o_ret, o_end=o_end, v1=f.vm_match_stride(rows, 1), v2=f.vm_match_stride(rows, 2))
+
+    threading.stack_size(1 << 29)
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    threading.stack_size(0)
+    assert int((out["ret"] == 1).sum()) >= 300
+    assert np.array_equal(out["o_ret"], out["ret"]) and np.array_equal(out["o_end"], out["end"])
+    assert np.array_equal(out["v1"] == 1, out["ret"] == 1)
+    print("reference VM v2 vs fsm_exec on this automaton:", "agree" if np.array_equal(out["v2"] == 1, out["ret"] == 1) else "MISMATCH")
+
+
 def test_oracle_eager_outputs_match_golden():
     """tests/eager_output/*.c (22 programs, 89 inputs): the oracle's restatement of exec.c:126-144
     emits exactly the ids the reference's callback received, and the union with the end state's
