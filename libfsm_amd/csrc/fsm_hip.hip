@@ -82,6 +82,7 @@ struct fsm_hip_dfa {
 	int knob_pk_rmin = 7;        /* packed front: smallest row, log2 bytes */
 	int knob_pk_rmax = 0;        /* ... largest row, log2 bytes (<= 10); 0 = what leaves room for a full workgroup */
 	int knob_sparse_fast = 1;    /* sparse layout: entry-as-state walk (0: the id-as-state chain loop, for A/B runs) */
+	bool sparse_fast_ok = true;  /* the record array sits inside one 4 GiB window (SparseFastPol::enter) */
 	int knob_pk_debug = 0;       /* measurement aid: parts of walk_packed switched off (results are wrong) */
 	int knob_pk_mean_max = 192;  /* ... longest mean input length (bytes) walk_packed takes; longer: walk_ragged */
 	unsigned flags = 0;
@@ -314,6 +315,12 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			a.abs_min = p.abs_min;
 			a.fin_div = 1;
 			d->table_lds = SparsePol::lds_bytes(a.tab_bytes);
+			{
+				/* SparseFastPol::enter builds a record's address from a 32-bit low half: the record array must not cross
+				 * a 4 GiB boundary (hipMalloc hands out 2 MiB-aligned blocks, the array is a few MB: practically never) */
+				const uint64_t g = reinterpret_cast<uint64_t>(t) + p.sparse_img[5], bytes = (uint64_t)p.S1 * 16u;
+				if ((g >> 32) != ((g + bytes) >> 32)) d->sparse_fast_ok = false;
+			}
 			break;
 		}
 		default:
@@ -486,7 +493,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		if (m >= 0) mode = m;
 	}
 	c.mode = mode;
-	c.sparse_fast = d->knob_sparse_fast;
+	c.sparse_fast = d->sparse_fast_ok ? d->knob_sparse_fast : 0;
 	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.

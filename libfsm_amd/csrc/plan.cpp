@@ -407,12 +407,12 @@ try {
  * state's) on more than half the classes stays dense, so the form is never much larger than the
  * table and the result is the same for any choice.
  *
- * Records are 16 bytes {bits lo, bits hi, base (28 bits) | DENSE | CONSEC | FULLBASE | FASTMISS, offset}; those of the states nearest the
+ * Records are 16 bytes {bits lo, bits hi, base (28 bits) | DENSE | CONSEC | FULLBASE | FAST, offset}; those of the states nearest the
  * start state, and the dense rows among them, are mirrored in LDS (breadth-first numbering puts
  * the states a walk visits most first), the rest stays in HBM/L2.
  *
  * Image (u32 words): hdr[16] | pmap u16[256] (byte -> class | bit << 8, bit 0xff = unmapped)
- *   | LDS dense rows | LDS records || all records | all dense rows | exceptions.
+ *   | LDS dense rows | LDS records || all records (one per state) | all dense rows | exceptions.
  * Everything before the || is copied to LDS by the kernel (Plan::sparse_lds_bytes).
  */
 static int build_sparse(Plan &p, uint32_t lds_limit)
@@ -566,8 +566,8 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	 * Breadth-first numbering hands the children of a trie node consecutive ids, so on an Aho-Corasick
 	 * DFA every record with at least one exception qualifies: the walk then computes the next state as
 	 * first + rank(bit) and the exception list -- one dependent gather per hit -- is not stored at all. */
-	const uint32_t CONSEC = 0x40000000u, FULLBASE = 0x20000000u, FASTMISS = 0x10000000u;
-	if (N >= FASTMISS) return ENOTSUP;
+	const uint32_t CONSEC = 0x40000000u, FULLBASE = 0x20000000u, FAST = 0x10000000u;
+	if (N >= FAST) return ENOTSUP;
 	std::vector<uint8_t> consec(N, 0);
 	for (uint32_t n = 0; n < N; n++) {
 		if (base[n] == NONE || nexc[n] == 0) continue;
@@ -586,13 +586,15 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	/* sizes */
 	uint64_t ndense = 0, ntot_exc = 0;
 	for (uint32_t n = 0; n < N; n++) { if (base[n] == NONE) ndense++; else if (!consec[n]) ntot_exc += nexc[n]; }
-	const uint64_t words = 16u + 128u + (uint64_t)N * 4u + ndense * C + ntot_exc;
+	const uint64_t words = 16u + 128u + (uint64_t)S1 * 4u + ndense * C + ntot_exc;
 	if (words * 4u + 160u * 1024u >= 0xFFFFFFFFull) return ENOTSUP;
 
 	std::vector<uint32_t> &img = p.sparse_img;
 	const uint32_t lds_dense_w = 16u + 128u, lds_rec_w = (lds_dense_w + HD * C + 3u) & ~3u;
 	const uint32_t lds_words = lds_rec_w + H * 4u;
-	const uint32_t grec_w = lds_words, gdense_w = grec_w + N * 4u;
+	/* one record per state, the absorbing ones included (no bits, FAST: never read by the chain loop, which tests
+	 * `state < abs_min` first; SparseFastPol enters a state by loading its record without that test) */
+	const uint32_t grec_w = lds_words, gdense_w = grec_w + S1 * 4u;
 	const uint64_t exc_w64 = (uint64_t)gdense_w + ndense * C;
 	const uint32_t exc_w = (uint32_t)exc_w64;
 	img.assign((size_t)(exc_w64 + ntot_exc), 0);
@@ -644,15 +646,22 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 			if ((rb[0] | ((uint64_t)rb[1] << 32)) == all) { r[2] |= FULLBASE; nfullbase++; }
 		}
 	}
-	/* FASTMISS: every class this record does NOT own is answered by a CONSEC record within the next two levels of its
-	 * base chain, both among the LDS records -- what SparseFastPol's straight-line evaluation assumes (it checks this
-	 * flag, and CONSEC when the record itself owns the class, instead of re-deriving all that per byte). */
+	/* FAST: every class (that owns a bit and) that this record does NOT own is answered by SparseFastPol's straight-line
+	 * step (walk_kernels.h) -- a hit on the record itself is, when the record is CONSEC (first + rank); a hit on one of
+	 * the few records that keep an exception list takes the general loop --: the class is answered
+	 * either by its base B -- an LDS-resident CONSEC record -- or, where B does not own the class either, by B's base C,
+	 * an LDS-resident CONSEC record that owns EVERY bit (rank = bit index: the answer is first(C) + bit, one 4-byte LDS
+	 * read of C's `first` word and an add -- no third popcount probe).  The step checks this one flag instead of
+	 * re-deriving all that per byte.  (first(base(B)) in an LDS word of its own next to each record, read beside B's
+	 * record instead of after it, was tried: 4 bytes per LDS record push 210 of the 4 096 depth-2 records of the
+	 * 1e5-literal automaton out of LDS and with them a third of the deep records out of FAST.) */
 	uint32_t nfastmiss = 0;
 	{
 		uint32_t nbits = 0;
 		for (uint32_t c = 0; c < C; c++) nbits += bit_of[c] != 0xff;
 		const uint64_t all = nbits >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << nbits) - 1u);
 		auto bits_of = [&](uint32_t n) { const uint32_t *r = &img[grec_w + (size_t)n * 4u]; return r[0] | ((uint64_t)r[1] << 32); };
+		auto full_consec = [&](uint32_t n) { return n < H && base[n] != NONE && consec[n] && bits_of(n) == all; };
 		for (uint32_t n = 0; n < N; n++) {
 			if (base[n] == NONE) continue;
 			const uint64_t need = all & ~bits_of(n);
@@ -662,15 +671,14 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 				if (B < H && base[B] != NONE) {
 					const uint64_t inB = need & bits_of(B), rest = need & ~bits_of(B);
 					ok = inB == 0 || consec[B];
-					if (ok && rest != 0) {
-						const uint32_t Cc = base[B];
-						ok = Cc < H && base[Cc] != NONE && consec[Cc] && (rest & ~bits_of(Cc)) == 0;
-					}
+					if (ok && rest != 0) ok = full_consec(base[B]);
 				}
 			}
-			if (ok) { img[grec_w + (size_t)n * 4u + 2u] |= FASTMISS; nfastmiss++; }
+			if (ok) { img[grec_w + (size_t)n * 4u + 2u] |= FAST; nfastmiss++; }
 		}
 	}
+	/* the absorbing states' records: no bits, FAST (the step's one flag test lets them through; it keeps their id) */
+	for (uint32_t n = N; n < S1; n++) img[grec_w + (size_t)n * 4u + 2u] = FAST;
 	for (uint32_t n = 0; n < H; n++) memcpy(&img[lds_rec_w + (size_t)n * 4u], &img[grec_w + (size_t)n * 4u], 16);
 	img[0] = 0x31525053u;   /* "SPR1" */
 	img[1] = H;

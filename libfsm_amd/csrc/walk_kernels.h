@@ -659,21 +659,24 @@ struct SparsePol {
  * instruction turns per input byte on a literal-set automaton (own record: a deep trie node, nearly always a miss;
  * its base: the failure state; that one's base: a full shallow node), and the loop's control flow is scalar work of
  * its own.  Here the walk state IS the current state's record {bits, base | flags, first} plus its id, fetched once
- * when the state is entered, and a byte is evaluated in straight-line code against three records at once -- the own one
- * (registers), its base's and that one's base's (two LDS reads; bases are nearly always among the H records nearest
- * the start state, which live in LDS):
+ * when the state is entered, and a byte is evaluated in straight-line code against the own record (registers), its
+ * base B's (one LDS read: bases are nearly always among the H records nearest the start state, which live in LDS) and,
+ * without reading it, B's base:
  *     x = bits << (63 - bit)          bit 63 of x: the class's bit; popcount(x) - 1: its rank among the set bits below
  *     hit   <=> x < 0 (signed);       next = first + popcount(x) - 1        (CONSEC records: children are consecutive ids)
- * i.e. one 64-bit shift, two v_bcnt (the second adds `first - 1`), one sign test per record, then two selects.  A full
- * base (every class's bit set: FULLBASE in SparsePol's terms) needs no special case: it simply always hits.
+ * i.e. one 64-bit shift, two v_bcnt (the second adds `first - 1`) and one sign test for each of the two records; where
+ * neither owns the class the answer is first(B's base) + bit -- B's base owns EVERY bit (a full trie node: rank = bit
+ * index), so it costs a 4-byte LDS read of its `first` word and an add.  (Round 3's first form evaluated the third record
+ * like the other two: a second 16-byte LDS read, a 64-bit shift, two v_bcnt and a sign test more per byte.)
  * Whether that is the whole story for a state is known when the table is planned (plan.cpp: records are re-based onto
- * LDS-resident ancestors, FASTMISS says that every class a record does not own is answered by a CONSEC record within
- * the next two levels), so one test and one wave vote per byte decide it; the lanes where it fails (a hit on a record
- * that keeps an exception list, dense rows, classes without a bit) take SparsePol's general loop for that byte.  Used by the fixed-stride kernels on plain (non-eager) walks.
+ * LDS-resident ancestors; FAST says that every class the record does not own is answered as above, CONSEC that a hit
+ * on it is first + rank), so one flag test and one wave vote per byte decide it; the lanes where it fails (a hit on a record
+ * that keeps an exception list, dense rows, classes without a bit) take SparsePol's general loop for that byte.  Used by
+ * the fixed-stride kernels on plain (non-eager) walks.
  */
 struct SparseFastState {
 	uint32_t b0, b1;   /* the state's record: class bits */
-	uint32_t meta;     /* base | DENSE | CONSEC | FULLBASE */
+	uint32_t meta;     /* base | DENSE | CONSEC | FULLBASE | FAST */
 	uint32_t off;      /* first child / exception offset / dense row offset */
 	uint32_t id;
 };
@@ -681,12 +684,24 @@ struct SparseFastState {
 struct SparseFastPol : SparsePol {
 	typedef SparseFastState S;
 	typedef SparsePol::P P;
-	/* records exist for ids < abs_min (absorbing states have none) */
+	typedef const uint32_t __attribute__((address_space(3))) *lds_w_p;
+	uint32_t lrec_lo, lrec_hi, grec_lo, grec_hi;   /* the two record arrays as flat addresses, halves apart (enter()) */
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		SparsePol::setup(lds, a);
+		const uint64_t l = reinterpret_cast<uint64_t>(lrec), g = reinterpret_cast<uint64_t>(grec);
+		lrec_lo = (uint32_t)l; lrec_hi = (uint32_t)(l >> 32);
+		grec_lo = (uint32_t)g; grec_hi = (uint32_t)(g >> 32);
+	}
+	/* every state has a record (the absorbing ones an all-zero one: plan.cpp), so a state is entered by ONE flat load of
+	 * `its array's base + 16 * id`.  The host guarantees that neither array crosses a 4 GiB boundary (fsm_hip.hip: the
+	 * knob falls back to SparsePol otherwise), so only the LOW half of the address depends on the id: a select + shift-add
+	 * for it, a select for the high half -- where a 64-bit select + 64-bit shift-add cost 8 vector operations per byte */
 	__device__ __forceinline__ S enter(uint32_t id) const
 	{
-		const uint32_t k = id < abs_min ? id : 0u;     /* an absorbing state keeps its id and never looks at the record */
-		u32x4 r;
-		if (k < H) r = lrec[k]; else r = grec[k];       /* one flat load of a selected address (see SparsePol) */
+		const bool in = id < H;
+		const uint32_t lo = (in ? lrec_lo : grec_lo) + id * 16u, hi = in ? lrec_hi : grec_hi;
+		const u32x4 r = *reinterpret_cast<const u32x4 *>(((uint64_t)hi << 32) | lo);
 		S s = { r.x, r.y, r.z, r.w, id };
 		return s;
 	}
@@ -695,35 +710,29 @@ struct SparseFastPol : SparsePol {
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, const S &) {}
 	__device__ __forceinline__ S next(const S &s, P p) const { return enter(SparsePol::next_t<false>(s.id, p)); }
 
-	/* one record against one class bit: does it own the class, and where does it lead (valid for CONSEC records) */
-	__device__ __forceinline__ static bool probe(uint32_t b0, uint32_t b1, uint32_t first, uint32_t sh, uint32_t &nxt)
-	{
-		const uint64_t x = (((uint64_t)b1 << 32) | b0) << sh;
-		nxt = (uint32_t)__builtin_popcount((uint32_t)x) + ((uint32_t)__builtin_popcount((uint32_t)(x >> 32)) + (first - 1u));
-		return (int32_t)(x >> 32) < 0;
-	}
-	__device__ __forceinline__ static bool consec(uint32_t meta) { return (meta & 0xC0000000u) == 0x40000000u; }
-
 	__device__ __forceinline__ S step_fast(const S &s, P p) const
 	{
-		const uint32_t sh = 63u - (p >> 8);                      /* (every class of the chunk owns a bit: walk16 checked) */
-		/* (the two base reads are unguarded: where the planner's FASTMISS flag is clear they may read anything -- an LDS read
-		 * cannot fault -- and the lane takes the general loop below) */
-		const uint32_t baseA = s.meta & 0x0FFFFFFFu;
-		const u32x4 rb = *(lds_rec_p)(uintptr_t)(lrec_lds + baseA * 16u);
-		const uint32_t baseB = rb.z & 0x0FFFFFFFu;
-		const u32x4 rc = *(lds_rec_p)(uintptr_t)(lrec_lds + baseB * 16u);
-		uint32_t nA, nB, nC;
-		const bool hA = probe(s.b0, s.b1, s.off, sh, nA), hB = probe(rb.x, rb.y, rb.w, sh, nB), hC = probe(rc.x, rc.y, rc.w, sh, nC);
-		(void)hC;
-		const bool live = s.id < abs_min;
-		/* the record owns the class: its children must be consecutive ids; it does not: the planner vouches for the chain */
-		const bool good = (s.meta & (hA ? 0x40000000u : 0x10000000u)) != 0u || !live;
-		uint32_t n = hA ? nA : hB ? nB : nC;
-		if (!__all(good)) {
-			if (!good) n = SparsePol::next_t<true>(s.id, p);      /* the general chain loop, for these lanes only */
+		const uint32_t bit = p >> 8, sh = 63u - bit;             /* (every class of the chunk owns a bit: walk16 checked) */
+		/* own record: x = bits << (63 - bit); bit 63 of x is the class's bit, popcount(x) - 1 its rank */
+		const uint64_t xA = (((uint64_t)s.b1 << 32) | s.b0) << sh;
+		const bool hA = (int32_t)(xA >> 32) < 0;
+		const uint32_t nA = (uint32_t)__builtin_popcount((uint32_t)xA) + ((uint32_t)__builtin_popcount((uint32_t)(xA >> 32)) + (s.off - 1u));
+		/* its base B, then first(B's base): unguarded -- where the planner's FAST flag is clear they may read anything (an
+		 * LDS read cannot fault) and the lane takes the general loop below */
+		const uint32_t B = s.meta & 0x0FFFFFFFu;
+		const u32x4 rb = *(lds_rec_p)(uintptr_t)(lrec_lds + B * 16u);
+		const uint32_t cf = *(lds_w_p)(uintptr_t)(lrec_lds + (rb.z & 0x0FFFFFFFu) * 16u + 12u);
+		const uint64_t xB = (((uint64_t)rb.y << 32) | rb.x) << sh;
+		const bool hB = (int32_t)(xB >> 32) < 0;
+		const uint32_t nB = (uint32_t)__builtin_popcount((uint32_t)xB) + ((uint32_t)__builtin_popcount((uint32_t)(xB >> 32)) + (rb.w - 1u));
+		uint32_t n = hA ? nA : hB ? nB : cf + bit;              /* B's base owns every bit: rank = bit index */
+		/* the record owns the class: its children must be consecutive ids (CONSEC); it does not: the planner vouches for
+		 * the rest (FAST).  (An absorbing state's record has no bits and FAST set: plan.cpp.) */
+		const uint32_t need = s.meta & (hA ? 0x40000000u : 0x10000000u);
+		if (__builtin_amdgcn_ballot_w64(need == 0u) != 0u) {
+			if (need == 0u) n = SparsePol::next_t<true>(s.id, p);   /* the general chain loop, for these lanes only */
 		}
-		if (!live) n = s.id;
+		if (s.id >= abs_min) n = s.id;
 		return enter(n);
 	}
 	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
@@ -731,7 +740,7 @@ struct SparseFastPol : SparsePol {
 		uint32_t mx = 0;
 #pragma unroll
 		for (int k = 0; k < 16; k++) mx = pre[k] > mx ? pre[k] : mx;
-		if (__all((mx >> 8) < 64u)) {
+		if (__builtin_amdgcn_ballot_w64((mx >> 8) >= 64u) == 0u) {
 #pragma unroll
 			for (int k = 0; k < 16; k++) st = step_fast(st, pre[k]);
 		} else {

@@ -78,9 +78,11 @@ def decode_sparse(p, S1, lds_limit=160 * 1024):
 
 
 def check_sparse_fast(p, got):
-    """SparseFastPol::step_fast (walk_kernels.h) for every record it may be used on: own record, base, base's base -- all
-    three read as the kernel reads them (the bases from the LDS mirror, unguarded) -- must give SparsePol's answer for every
-    class that owns a bit, whenever the kernel's own test lets the lane through (own hit: CONSEC; own miss: FASTMISS)."""
+    """SparseFastPol::step_fast (walk_kernels.h) for every record it may be used on: the own record, its base B's and
+    cf = first(base(B)) (B's base owning every bit) -- B and cf read as the kernel reads them (from the LDS mirror,
+    unguarded) -- must give SparsePol's answer for every class that owns a bit whenever the kernel's own test lets the lane
+    through (own hit: CONSEC; own miss: FAST).  The
+    absorbing states' records (no bits, FAST) exist so that a state is entered without a range test."""
     img = p.get("sparse").astype(np.int64)
     H, HDE, ldo, lro, gro, gdo, exo, N, Cn = (int(x) for x in img[1:10])
     pm = img[16:16 + 128]
@@ -97,24 +99,27 @@ def check_sparse_fast(p, got):
         o = lro // 4 + n * 4
         return lds[o:o + 4] if o + 4 <= len(lds) else np.zeros(4, np.int64)
 
+
     def probe(r, b):
         bits = int(r[0]) | (int(r[1]) << 32)
         return (bits >> b) & 1 == 1, int(r[3]) + bin(bits & ((1 << b) - 1)).count("1")
 
+    assert (gdo - gro) // 16 == p.S1, "one record per state"
+    for n in range(N, p.S1):
+        assert list(rec_g(n)) == [0, 0, 0x10000000, 0]
     for n in range(N):
         ra = rec_g(n)
-        rb = rec_l(int(ra[2]) & 0x0FFFFFFF)
-        rc = rec_l(int(rb[2]) & 0x0FFFFFFF)
+        B = int(ra[2]) & 0x0FFFFFFF
+        rb = rec_l(B)
+        cf = int(rec_l(int(rb[2]) & 0x0FFFFFFF)[3])
         for by in bytes_with_bit[:: max(1, len(bytes_with_bit) // 80)]:
             b = int(bit_b[by])
             hA, nA = probe(ra, b)
             hB, nB = probe(rb, b)
-            hC, nC = probe(rc, b)
-            good = (int(ra[2]) & (0x40000000 if hA else 0x10000000)) != 0
-            if not good:
+            if not int(ra[2]) & (0x40000000 if hA else 0x10000000):
                 continue
             nfast += 1
-            assert (nA if hA else nB if hB else nC) == got[n][by], (n, by)
+            assert (nA if hA else nB if hB else cf + b) == got[n][by], (n, by)
     return nfast, int(img[15])
 
 
