@@ -24,8 +24,9 @@ for step in "$@"; do
 	            echo "== n=$n waves=$w rmax=$x"; RAGGED_N=$n PK_WAVES=$w PK_RMAX=$x timeout 300 python tests/tools/ragged.py 2>&1 | grep "mode= 4 waves= 0"
 	        done > gpurun_out/${TAG}_pksweep.txt 2>&1; cat gpurun_out/${TAG}_pksweep.txt ;;
 	testgen) timeout 1200 python -m pytest tests -m gpu -x -q --timeout 600 -k "ragged or packed or batch_sizes or golden_vectors or fuzz or arena or unaligned or error_contracts or large_batch or resume or eager_outputs_golden or endids or c_program or retest_style" > gpurun_out/${TAG}_pytest_gen.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gen.log; grep -v "^  File\|^Extension" gpurun_out/${TAG}_pytest_gen.log | tail -25 ;;
-	c5ab)   timeout 500 python tests/tools/c5_probe.py --layout 7 --n 4000000 --variants "20=0;20=1;20=2;20=1,4=8;20=0" > gpurun_out/${TAG}_c5ab.txt 2>&1; echo "c5ab rc=$?"; tail -12 gpurun_out/${TAG}_c5ab.txt
+	c5ab)   timeout 500 python tests/tools/c5_probe.py --layout 7 --n 4000000 --variants "${C5_VARIANTS:-20=0;20=1;20=3;20=3,4=12;20=1}" > gpurun_out/${TAG}_c5ab.txt 2>&1; echo "c5ab rc=$?"; tail -12 gpurun_out/${TAG}_c5ab.txt
 	        timeout 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config5 or literal_set or aho_corasick" > gpurun_out/${TAG}_c5tests.log 2>&1; tail -3 gpurun_out/${TAG}_c5tests.log ;;
+	c5mem)  timeout 900 python tools/pmc_kernel.py --match walk_direct --sets "TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_GATE_EN1_sum GRBM_GUI_ACTIVE;TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum;TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCC_BUSY_avr TCC_TAG_STALL_sum" --out gpurun_out/${TAG}_c5mem.json -- python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --subs none --knob 20=${C5_SF:-1} > gpurun_out/${TAG}_c5mem.txt 2>&1; tail -40 gpurun_out/${TAG}_c5mem.txt ;;
 	c5pmc)  for sf in ${C5_SF:-0 1}; do timeout 600 python tools/pmc_kernel.py --match walk_direct --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE" --out gpurun_out/${TAG}_c5pmc_sf$sf.json -- python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --subs none --knob 20=$sf > gpurun_out/${TAG}_c5pmc_sf$sf.txt 2>&1; tail -45 gpurun_out/${TAG}_c5pmc_sf$sf.txt; done ;;
 	genpmc) export RAGGED_N=6000000 RAGGED_DISTS=${PK_DISTS:-short8-64} RAGGED_CASES=${PK_CASES:-c2:packed:2,c3:packed:2}
 	        timeout 600 python tools/pmc_kernel.py --match walk_generic --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" -- python tests/tools/ragged.py > gpurun_out/${TAG}_genpmc.txt 2>&1; tail -62 gpurun_out/${TAG}_genpmc.txt ;;
