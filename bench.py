@@ -602,7 +602,7 @@ def main():
                              if world > 1 else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
-            "roofline": {"bound": "hbm" if wl != "c5" else "valu (divergent chain loop); HBM figures for uniformity",
+            "roofline": {"bound": "hbm" if wl != "c5" else "l2-gather (record gathers in flight per CU); HBM figures for uniformity",
                          "achieved": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -621,9 +621,10 @@ def main():
             "note": "HBM bytes per launch from the recorded PMC passes (reads + the 4-byte results): ~1.00 means every input byte was still fetched",
         }
         if wl == "c5":
-            res["roofline"]["note"] = ("this walk is bound by the instructions of its divergent chain loop, not by HBM (DESIGN.md section 3; profiles/r04*_c5_pmc*; "
-                                       "profiles/r03j_c5_rocprof_summary.json: 0.33 L2 requests per input byte, 93.8 % hits, calibrated HBM traffic "
-                                       "1.81x algorithmic): the fraction of HBM peak is reported for uniformity only")
+            res["roofline"]["note"] = ("this walk is bound by the record gathers its vector-memory pipe keeps in flight, not by HBM (DESIGN.md section 3; "
+                                       "profiles/r04p_c5_memory_pipeline.txt: 0.33 L2 requests per input byte at 231 cycles, TA busy 80 %, stalled by the L1 56 %; "
+                                       "profiles/r04m_c5_pmc_*: 35 vector + 11 scalar instructions per wave byte-step; calibrated HBM traffic 1.8x algorithmic): "
+                                       "the fraction of HBM peak is reported for uniformity only")
         if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
             sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if wl == "c2" else 100_000)
             idx = sample_indices(n_, sample)
