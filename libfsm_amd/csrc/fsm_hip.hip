@@ -511,6 +511,10 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	 * 3.77 / 3.71 and 12 4.01 / 3.99 (354- and 1132-state tables, 8e6 x 1 KiB: profiles/r04h_eager_probe_8M.txt).  The
 	 * eager form of the same walk wants 16 (3.53 vs 3.33 at 14, 3.12 at 12). */
 	else if (layout == FSM_HIP_LAYOUT_LDS && mode == IN_LDSDMA && !eager) wmax = 14;
+	/* short inputs on the column tables: 12-wave workgroups (two per CU) measured 2.29 / 1.61 / 2.52 TB/s at 8-64 / 8-16 /
+	 * 32-128 bytes where 16 gave 2.05 / 1.32 / 2.26 (6e6 packed inputs, profiles/r04t_generic_waves.txt); the other
+	 * layouts keep 16 (combself: 1.47 vs 1.25) */
+	else if (layout == FSM_HIP_LAYOUT_TINY && mode == IN_GENERIC && !eager) wmax = 12;
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16 &&
 	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA)) waves = d->knob_waves;   /* that kernel is compiled for 12 */
