@@ -49,6 +49,9 @@ for step in "$@"; do
 	            tail -2 gpurun_out/${TAG}_prof_$wl.log
 	            rm -rf gpurun_out/${TAG}_prof_$wl/*/*.db gpurun_out/${TAG}_prof_$wl/*/*/*.db 2>/dev/null
 	        done ;;
+	profls) timeout 500 bash tools/profile.sh c3 $PWD/gpurun_out/${TAG}_prof_c3_loadskip --knob 6=3 > gpurun_out/${TAG}_prof_c3_loadskip.log 2>&1
+	        python tools/rocpd_summary.py gpurun_out/${TAG}_prof_c3_loadskip c3_loadskip gpurun_out/${TAG}_c3_loadskip >> gpurun_out/${TAG}_prof_c3_loadskip.log 2>&1
+	        tail -2 gpurun_out/${TAG}_prof_c3_loadskip.log; rm -rf gpurun_out/${TAG}_prof_c3_loadskip/*/*.db gpurun_out/${TAG}_prof_c3_loadskip/*/*/*.db 2>/dev/null ;;
 	calib)  cd /tmp; rocprofv3 --pmc FETCH_SIZE -d $OLDPWD/gpurun_out/${TAG}_calib/fetch -o f -- python $OLDPWD/tools/fetch_calib.py > $OLDPWD/gpurun_out/${TAG}_calib_run.txt 2>&1
 	        rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OLDPWD/gpurun_out/${TAG}_calib/req -o r -- python $OLDPWD/tools/fetch_calib.py >> $OLDPWD/gpurun_out/${TAG}_calib_run.txt 2>&1
 	        cd $OLDPWD; python tools/fetch_calib.py --read gpurun_out/${TAG}_calib/fetch gpurun_out/${TAG}_calib/req > gpurun_out/${TAG}_fetch_calib.json 2>&1; cat gpurun_out/${TAG}_fetch_calib.json | tail -12
