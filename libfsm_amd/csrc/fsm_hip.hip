@@ -479,7 +479,8 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 			c.seg = d->knob_seg == 64 ? 64 : 128;
 			if (stride % 128u != 0) c.seg = 64;
 			/* the eager kernels exist for 128-byte segments and register-held sets only (2.3 vs 1.1 TB/s for
-			 * those; wide sets measured 1.8 behind LDS-DMA vs 2.1 with per-lane loads: tests/tools/eager_probe.py) */
+			 * those; wide sets measured 1.8 behind LDS-DMA vs 2.1 with per-lane loads in round 2 and 2.53 vs 2.71 in round 3:
+			 * profiles/r04x_eager_wide_dma.txt) */
 			if (eager && (c.seg != 128 || eager == 2)) m = IN_DIRECT;
 		}
 		if (m == IN_DIRECT) {

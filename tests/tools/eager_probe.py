@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--len", type=int, default=1024)
     ap.add_argument("--layouts", default="0", help="comma list: 0 auto, 2 lds, 8 ldsself, 4 global")
     ap.add_argument("--waves", default="0", help="comma list of KNOB_WAVES values (0 = the library's choice)")
+    ap.add_argument("--modes", default="-1", help="comma list of KNOB_INPUT_MODE values (-1 = the library's choice, 1 = LDS-DMA, 0 = per-lane loads)")
     a = ap.parse_args()
     import torch
     import libfsm_amd as hip
@@ -46,11 +47,12 @@ def main():
             info = dfa.info()
             W = dfa.eager_words()
             sets = torch.zeros((n, W), dtype=torch.int64, device="cuda")
-            for wv, (name, fn) in [(int(w), nf) for w in a.waves.split(",") for nf in (
+            for md, wv, (name, fn) in [(int(m), int(w), nf) for m in a.modes.split(",") for w in a.waves.split(",") for nf in (
                     ("plain walk", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)),
                     ("eager walk", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n, end.data_ptr(), sets.data_ptr())))]:
                 dfa.tune(hip.KNOB_WAVES, wv)
-                name = f"{name} waves={wv}"
+                dfa.tune(hip.KNOB_INPUT_MODE, md)
+                name = f"{name} mode={md} waves={wv}"
                 ms = []
                 for _ in range(4):
                     fn()
