@@ -55,7 +55,7 @@ def main():
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves or int(os.environ.get("PK_WAVES", 0)))
-                for kn, ev in ((hip.KNOB_PK_RMIN, "PK_RMIN"), (hip.KNOB_PK_RMAX, "PK_RMAX"), (hip.KNOB_PK_MEAN_MAX, "PK_MEAN_MAX"), (hip.KNOB_PK_DEBUG, "PK_DEBUG")):
+                for kn, ev in ((hip.KNOB_PK_RMIN, "PK_RMIN"), (hip.KNOB_PK_RMAX, "PK_RMAX"), (hip.KNOB_PK_MEAN_MAX, "PK_MEAN_MAX"), (hip.KNOB_PK_DEBUG, "PK_DEBUG"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP")):
                     if os.environ.get(ev):
                         dfa.tune(kn, int(os.environ[ev]))
                 ms = []
