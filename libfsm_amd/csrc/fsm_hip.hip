@@ -399,6 +399,8 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			for (uint32_t n2 = 0; n2 < p.S1; n2++) maxcode = d->enc_host[n2] > maxcode ? d->enc_host[n2] : maxcode;
 			if ((uint64_t)maxcode * a.fin_div < ((uint64_t)1 << 32)) a.fin_mul = (uint32_t)((((uint64_t)1 << 32) / a.fin_div) + 1u);
 		}
+		/* the spare class of the self-loop-mask layouts (plan.cpp sets bit 31 in every mask when there are <= 31 classes) */
+		a.ident_class = ((p.layout == FSM_HIP_LAYOUT_COMBSELF || p.layout == FSM_HIP_LAYOUT_LDSSELF) && p.C <= 31u) ? 31u : 0xFFFFFFFFu;
 		a.tab = d->d_tab;
 		a.fin = d->d_fin;
 		a.btab = d->d_btab;

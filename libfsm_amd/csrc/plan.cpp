@@ -287,6 +287,7 @@ try {
 			for (uint32_t c = 0; c < C; c++)
 				if (p.dense[(size_t)n * C + c] == n) m |= 1u << c;
 			if (n >= p.abs_min) m = 0xFFFFFFFFu;
+			if (C <= 31u) m |= 0x80000000u;   /* class 31 = "no byte": a self-loop of every state (walk_kernels.h step16_part) */
 			p.comb_smask[p.comb_off[n]] = m;
 			/* the self-loop bytes as one range, if they are one ([0-9]+, [a-z]*, .*, an absorbing state) */
 			int lo = -1, hi = -1, runs = 0;
@@ -329,6 +330,7 @@ try {
 				if (c < C && t == n) m |= 1u << c;
 			}
 			if (n >= p.abs_min) m = 0xFFFFFFFFu;
+			if (C <= 31u) m |= 0x80000000u;   /* class 31 = "no byte": a self-loop of every state */
 			p.lds_tab[(size_t)n * rw + Cpad] = (uint16_t)(m & 0xffffu);
 			p.lds_tab[(size_t)n * rw + Cpad + 1] = (uint16_t)(m >> 16);
 		}

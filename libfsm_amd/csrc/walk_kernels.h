@@ -69,6 +69,8 @@ struct WalkArgs {
 	uint32_t        abs_min;  /* encoded states >= abs_min are absorbing              */
 	uint32_t        fin_div;  /* fin index = encoded state / fin_div                  */
 	uint32_t        fin_mul;  /* 0, or floor(2^32 / fin_div) + 1: then encoded state * fin_mul >> 32 is that quotient (fin_index()) */
+	uint32_t        ident_class; /* self-loop-mask layouts with <= 31 classes: 31, the class that is a self-loop of EVERY state
+	                           * (what the bytes beyond an input's end are given: step16_part); else >= 32 */
 	uint32_t        early;    /* bit 0: retire a wavefront once every lane is absorbing;
 	                           * bit 1: absorbing lanes stop loading their input;
 	                           * bit 2: never skip a chunk (skip16 off: measurement aid) */
@@ -314,6 +316,7 @@ struct LdsSelfPol {
 	const uint8_t *bp;
 	const unsigned char *tab;
 	uint32_t smoff;   /* offset of the mask inside a row */
+	uint32_t ident;   /* WalkArgs::ident_class */
 	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -323,6 +326,7 @@ struct LdsSelfPol {
 		copy_table(lds + FSMHIP_BTAB_BYTES, a);
 		tab = lds + FSMHIP_BTAB_BYTES;
 		smoff = a.fin_div - 4u;   /* fin_div = row bytes */
+		ident = a.ident_class;
 		skip_on = !(a.early & 4u);
 	}
 	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
@@ -434,6 +438,7 @@ struct CombSelfPol {
 	const uint16_t *rng16;  /* LDS: self-loop byte range lo | hi << 8 by row offset      */
 	const uint32_t *smask0; /* global: smask by row offset (only to seed a walk)        */
 	uint32_t start, start_sm;
+	uint32_t ident;         /* WalkArgs::ident_class */
 	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -448,6 +453,7 @@ struct CombSelfPol {
 		smask0 = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.tab_bytes);
 		start = a.start;
 		start_sm = smask0[a.start];
+		ident = a.ident_class;
 		skip_on = !(a.early & 4u);
 	}
 	/* every input starts from the start state unless it is resumed: its mask is fetched once per
@@ -1364,6 +1370,30 @@ __device__ __forceinline__ u32x4 fill_invalid(const u32x4 &w, uint32_t lo, uint3
 
 /* 16 bytes of which only [lo, lo + cnt) belong to the input: the policy's chunk-level skip tests first
  * (on the filled chunk), then 16 predicated steps */
+/* The self-loop-mask layouts with a spare class (ident_class = 31, bit 31 set in every state's mask): the bytes that do not
+ * belong to the input are given THAT class -- a self-loop of every state -- and the chunk is then an ordinary one: the
+ * class-level skip vote, 16 unpredicated steps.  One select per byte in the state-independent part instead of a compare +
+ * a select per state register per byte on the dependent chain.  (The raw-byte range test runs first, on the filled chunk,
+ * as before: on C3's inputs it skips most tails outright.) */
+template <class Pol>
+__device__ __forceinline__ auto step16_part_ident(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t lo, uint32_t cnt, int)
+	-> decltype(pol.ident, bool())
+{
+	if (pol.ident >= 32u) return false;
+	typename Pol::P pre[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const typename Pol::P c = pre_of(pol, w, k, 0);
+		pre[k] = ((uint32_t)k - lo) < cnt ? c : (typename Pol::P)pol.ident;
+	}
+	if (skip_chunk(pol, st, pre, 0)) return true;
+#pragma unroll
+	for (int k = 0; k < 16; k++) st = pol.next(st, pre[k]);
+	return true;
+}
+template <class Pol>
+__device__ __forceinline__ bool step16_part_ident(const Pol &, typename Pol::S &, const u32x4 &, uint32_t, uint32_t, long) { return false; }
+
 template <class Pol>
 __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st, const u32x4 &w0, uint32_t lo, uint32_t cnt)
 {
@@ -1372,6 +1402,7 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 		w = fill_invalid(w0, lo, cnt);
 		if (skip_chunk_raw(pol, st, w, 0)) return;
 	}
+	if (step16_part_ident(pol, st, w0, lo, cnt, 0)) return;
 	typename Pol::P pre[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) pre[k] = pre_of(pol, w, k, 0);

@@ -222,6 +222,8 @@ def check_plan(flat, layout):
             bits = (sm[off][:, None] >> np.arange(Cn)[None, :]) & 1
             assert np.array_equal(bits[~absorbing].astype(bool), loops[~absorbing])
             assert (sm[off][absorbing] == 0xFFFFFFFF).all()
+            if Cn <= 31:   # the spare class 31 ("no byte": what step16_part gives the bytes beyond an input's end) loops everywhere
+                assert ((sm[off] >> 31) & 1).all()
             # self-loop BYTE range for the SWAR chunk test: exactly the state's self-loop bytes, or "none"
             rng = p.get("comb_rng").astype(np.int64)[off]
             lo, hi = rng & 0xff, rng >> 8
