@@ -37,8 +37,10 @@ enum {
 	FSM_HIP_KNOB_PK_MEAN_MAX   = 18, /* auto: batches whose mean input length exceeds this go to the ragged kernel   */
 	FSM_HIP_KNOB_PK_DEBUG      = 19, /* measurement aid: bit mask of walk_packed parts switched off (results are WRONG):
 	                                  * 1 result stores, 4 input loads, 16 packed_finish (raw state codes stay)           */
-	FSM_HIP_KNOB_SPARSE_FAST   = 20, /* sparse layout, fixed-stride rows: 1 (default) the record is the walk state and a byte is
-	                                  * three straight-line record probes; 0 the chain loop over state ids (A/B measurement)   */
+	FSM_HIP_KNOB_SPARSE_FAST   = 20, /* sparse layout, fixed-stride rows: 3 (default where the automaton has a lazy form) states beyond the
+	                                  * LDS set are entered without their record, a Bloom filter in LDS says when to fetch it
+	                                  * (walk_lazy.h); 1 (default otherwise) the record is the walk state and a byte is three
+	                                  * straight-line record probes; 0 the chain loop over state ids (A/B measurement)   */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };
@@ -73,7 +75,8 @@ enum {
 	FSM_HIP_PLAN_EW_WORD     = 20, /* u32[] */
 	FSM_HIP_PLAN_EW_MASK     = 21, /* u64[] */
 	FSM_HIP_PLAN_TINY5_COL   = 22, /* u32[256], <= 6 states: 5-bit fields of 5 * next state */
-	FSM_HIP_PLAN_COMB_RNG    = 23  /* u16[] by comb row offset: self-loop byte range lo | hi << 8 (0x0080: none) */
+	FSM_HIP_PLAN_COMB_RNG    = 23, /* u16[] by comb row offset: self-loop byte range lo | hi << 8 (0x0080: none) */
+	FSM_HIP_PLAN_LAZY        = 24  /* u32[] image of the sparse layout's lazy form (plan.cpp build_lazy); empty: the automaton has none */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

@@ -33,6 +33,7 @@ struct fsm_hip_dfa {
 	void *d_tab = nullptr;
 	uint32_t *d_fin = nullptr;
 	uint32_t *d_btab = nullptr;
+	uint32_t *d_lazy = nullptr;                      /* sparse layout: the lazy image (plan.cpp build_lazy), if the automaton has one */
 	/* device end-id delivery (built on first use) */
 	std::vector<uint32_t> fin_host;                 /* copy of the fin table uploaded to d_fin */
 	uint32_t *d_fin_earliest = nullptr, *d_fin_ret = nullptr;
@@ -321,6 +322,14 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 				const uint64_t g = reinterpret_cast<uint64_t>(t) + p.sparse_img[5], bytes = (uint64_t)p.S1 * 16u;
 				if ((g >> 32) != ((g + bytes) >> 32)) d->sparse_fast_ok = false;
 			}
+			if (p.lazy_lds_bytes != 0 && p.lazy_lds_bytes <= d->lds_limit) {
+				HIP_TRY(upload(&d->d_lazy, p.lazy_img));
+				a.lazy = d->d_lazy;
+				/* the default where it pays: few states beyond the LDS set whose own record sends hits the exact way
+				 * (img[10]) or that carry nothing (img[9]) -- on the 1e5-literal automaton 4.5 % of them, deep in the trie */
+				const uint64_t deep = p.abs_min > p.lazy_img[1] ? p.abs_min - p.lazy_img[1] : 0;
+				if (((uint64_t)p.lazy_img[9] + p.lazy_img[10]) * 10u <= deep) d->knob_sparse_fast = 3;
+			}
 			break;
 		}
 		default:
@@ -425,6 +434,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_tab) (void)hipFree(d->d_tab);
 	if (d->d_fin) (void)hipFree(d->d_fin);
 	if (d->d_btab) (void)hipFree(d->d_btab);
+	if (d->d_lazy) (void)hipFree(d->d_lazy);
 	if (d->d_fin_earliest) (void)hipFree(d->d_fin_earliest);
 	if (d->d_fin_ret) (void)hipFree(d->d_fin_ret);
 	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
@@ -451,7 +461,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* per_lane: take walk_generic unless a knob says otherwise -- the inputs average < 96 bytes (walk_ragged works in
  * 128-byte segments: 0.7-1.2 vs 1.5-2.1 TB/s at 8-64 bytes, profiles/r03t_*); huge: the batch may hold an input the
  * ragged kernel's 32-bit piece count cannot (>= 2^36 bytes) */
-static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false)
+static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false, bool resumed = false)
 {
 	LaunchCfg c;
 	const uint32_t layout = d->plan.layout;
@@ -495,8 +505,21 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		}
 		if (m >= 0) mode = m;
 	}
+	c.sparse_fast = d->sparse_fast_ok ? d->knob_sparse_fast : (d->knob_sparse_fast == 3 ? 3 : 0);
+	c.lazy_abs = 0;
+	if (mode == IN_DIRECT && layout == FSM_HIP_LAYOUT_SPARSE && !eager && !resumed && d->d_lazy != nullptr && d->knob_sparse_fast == 3 &&
+	    (stride / 16u) % 4u == 0) {
+		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
+		c.mode = IN_LAZY;
+		c.lazy_abs = d->plan.lazy_img[11] != 0;
+		c.nb = 4;
+		c.waves = 16;
+		c.lds = d->plan.lazy_lds_bytes;
+		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
+		return c;
+	}
+	if (c.sparse_fast == 3) c.sparse_fast = d->sparse_fast_ok ? 1 : 0;
 	c.mode = mode;
-	c.sparse_fast = d->sparse_fast_ok ? d->knob_sparse_fast : 0;
 	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
@@ -600,9 +623,9 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (a.n == 0) return 0;
 	const int eager = a.eager_out == nullptr ? 0 : a.eager_words > 1 ? 2 : 1;
 	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : a.off == nullptr ? (uint64_t)a.n * a.stride : 0;
-	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36));
+	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr);
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	uint64_t nblocks = (ntiles + c.waves - 1) / c.waves;
+	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
@@ -1024,7 +1047,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_PK_RMIN: if (value < 7 || value > (int)FSMHIP_PK_RMAX) { errno = EINVAL; return -1; } d->knob_pk_rmin = value; break;
 	case FSM_HIP_KNOB_PK_RMAX: if (value != 0 && (value < 7 || value > (int)FSMHIP_PK_RMAX)) { errno = EINVAL; return -1; } d->knob_pk_rmax = value; break;
 	case FSM_HIP_KNOB_PK_DEBUG: d->knob_pk_debug = value; break;
-	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value < 0 || value > 2 ? 1 : value; break;
+	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value < 0 || value > 3 ? (d->d_lazy ? 3 : 1) : value; break;
 	case FSM_HIP_KNOB_PK_MEAN_MAX: if (value < 0) { errno = EINVAL; return -1; } d->knob_pk_mean_max = value; break;
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
@@ -1092,6 +1115,7 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB_FIN: *data = p.comb_fin.data(); *count = p.comb_fin.size(); return 0;
 	case FSM_HIP_PLAN_GLOB_TAB: *data = p.glob_tab.data(); *count = p.glob_tab.size(); return 0;
 	case FSM_HIP_PLAN_SPARSE: *data = p.sparse_img.data(); *count = p.sparse_img.size(); return 0;
+	case FSM_HIP_PLAN_LAZY: *data = p.lazy_img.data(); *count = p.lazy_img.size(); return 0;
 	case FSM_HIP_PLAN_COMB256: *data = p.comb256.data(); *count = p.comb256.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_OFF: *data = p.comb256_off.data(); *count = p.comb256_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB256_FIN: *data = p.comb256_fin.data(); *count = p.comb256_fin.size(); return 0;

@@ -1,10 +1,16 @@
 /* kern_glob.hip -- walk kernels of the policies whose table stays in HBM / L2; see launch.h */
 #include "launch.h"
+#include "walk_lazy.h"
 
 namespace fsmhip {
 
 hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
+	if (pol == POL_SPARSE && eager == 0 && c.mode == IN_LAZY) {
+		/* fixed-stride rows, plain walk, an automaton with a lazy form: states beyond the LDS set are entered without their record */
+		walk_fn k = c.lazy_abs ? walk_lazy<true> : walk_lazy<false>;
+		return launch_fn(k, c, a, grid, block, s);
+	}
 	if (pol == POL_SPARSE && eager == 0 && c.sparse_fast && c.mode == IN_DIRECT) {
 		/* fixed-stride rows, plain walk: the record is the state (SparseFastPol) */
 		walk_fn k = !c.prefetch && c.nb == 4 ? (c.sparse_fast == 2 ? walk_direct_np<SparseFastPol, 2> : walk_direct_np<SparseFastPol, 4>) : c.nb == 4 ? walk_direct<SparseFastPol, 4, 1> : walk_direct<SparseFastPol, 8, 1>;

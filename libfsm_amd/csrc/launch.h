@@ -15,13 +15,14 @@
 namespace fsmhip {
 
 struct LaunchCfg {
-	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED | IN_PACKED */
+	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED | IN_PACKED | IN_LAZY */
 	int nb;              /* direct: 16-byte chunks in flight per lane (4 or 8) */
 	int waves, blocks_per_cu;
 	int seg;             /* LDS-DMA: 64 or 128 */
 	int prefetch;        /* direct: register double-buffer (0: <= 64 VGPRs, occupancy instead) */
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
+	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 };
 

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <unordered_map>
 
@@ -30,6 +32,7 @@ uint32_t lds_bytes_btab() { return 256u; }
 static int build_comb(Plan &p, uint32_t max_entries, bool bytewise);
 
 static int build_sparse(Plan &p, uint32_t lds_limit);
+static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const std::vector<uint32_t> &base);
 
 int build_plan(const fsm_hip_dfa_desc *d, unsigned flags, uint32_t lds_limit, Plan &p)
 try {
@@ -700,7 +703,281 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
 	img[15] = nfastmiss;
 	p.sparse_lds_bytes = lds_words * 4u;
 	p.layout = FSM_HIP_LAYOUT_SPARSE;
+	build_lazy(p, lds_limit, bit_of, base);
 	return 0;
+}
+
+/*
+ * The LAZY form of the sparse layout (walk_lazy.h): a second, self-contained image for the fixed-stride plain walk.
+ *
+ * build_sparse's walk fetches the 16-byte record of every state it enters; on a literal-set automaton two thirds of
+ * those fetches come from LDS (the H records nearest the start state) and one third -- the first level that no longer
+ * fits -- is an L2 gather whose only use, 98 % of the time, is to learn "no exception on this byte": 0.33 L2 requests
+ * per input byte, which is what bounds that walk (profiles/r04p_c5_memory_pipeline.txt).  Here a state beyond the LDS
+ * set is entered WITHOUT its record.  The walk carries (id, E): E = id for an LDS-resident state, else the LDS-resident
+ * record "behind" it (on an Aho-Corasick automaton: the deepest LDS-resident node on its failure chain,
+ * fail(n) = delta(fail(p), c), src/libre/ac.c:229-241), derived by arithmetic from the step that entered the state.
+ * A byte is answered by E's record unless the state's own record excepts it; whether it may is asked of a bit array
+ * in LDS keyed by (id, class) -- a one-hash Bloom filter over the exceptions of the states [H, F) -- and only a set
+ * bit (a true exception, 2 % of the steps of such a state on the 1e5-literal automaton, or a false positive) costs
+ * the gather of the state's own record.  States from F up are always fetched (they are entered rarely: one has to
+ * take a true exception to get there).
+ *
+ * LDS fast record of state e < H, 16 bytes {bits, fm1, cf63}: for a class with bit b
+ *     delta(e, class) = fm1 + popcount(bits << (63 - b))     if bit b of bits is set (targets are consecutive ids),
+ *                     = cf63 - (63 - b)  (= X + b)           otherwise,
+ * X being the most frequent value of `target - b` over the state's row (a trie node whose failure state owns every
+ * child: X = first child of that state).  A result with bit 31 set is a SENTINEL: the kernel then takes that byte
+ * through build_sparse's exact records (fm1 = 0x80000000 when the excepted targets are not consecutive).
+ * What the walk carries into a state m >= H entered from (id, E) on class c is rep = ev >= H ? cf(E) + b : ev, with
+ * ev = E's answer on c.  The planner follows every reachable state with exactly that rule (car[]); a state reached
+ * with two different values, or through the exact path, is served by the exact path only (its own record says
+ * "except everything": bits = ~0, fm1 = sentinel), and the own record of every other state m >= H lists the classes
+ * on which its row differs from car[m]'s answers -- so the result is delta for ANY automaton, by construction, and
+ * tests/test_plan.py re-derives that for every reachable (state, carried record, byte).
+ *
+ * Image (u32 words): hdr[16] | LDS part: sh[256] at LDS address 0 (byte -> 63 - bit, or 0x80000000 | a shift that
+ * hits nothing for bytes whose class owns no bit), filter[fwords], records[H + 1] (the last one all-sentinel: Z)
+ * | own records, 16 bytes per state {bits, base, stride} | car[S1].
+ */
+static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const std::vector<uint32_t> &base)
+{
+	p.lazy_img.clear();
+	p.lazy_lds_bytes = 0;
+	const uint32_t S1 = p.S1, C = p.C, N = p.abs_min, SENT = 0x80000000u, NONE = 0xFFFFFFFFu;
+	if (!p.emask.empty() || S1 >= (1u << 24)) return;          /* plain walks only */
+	auto row = [&](uint32_t n) { return &p.dense[(size_t)n * C]; };
+	uint32_t nbits = 0, cls_of_bit[64];
+	for (uint32_t c = 0; c < C; c++)
+		if (bit_of[c] != 0xff) { cls_of_bit[bit_of[c]] = c; nbits++; }
+	if (nbits == 0) return;
+	struct FRec { uint64_t bits; uint32_t fm1, cf63; };
+	auto popc = [](uint64_t v) { return (uint32_t)__builtin_popcountll(v); };
+
+	/* 1. the LDS set: the longest prefix of states (breadth-first from the start state) whose excepted targets are
+	 * consecutive ids, and whose X + b stays inside the set for every bit b */
+	const uint32_t room = lds_limit > 1024u + 16384u + 32u ? lds_limit - 1024u - 16384u - 32u : 0u;
+	const uint32_t Hcap = room / 16u;
+	std::vector<FRec> LR;
+	std::vector<uint64_t> need;
+	std::vector<uint32_t> Xof;
+	for (uint32_t n = 0; n < N && n < Hcap; n++) {
+		const uint32_t *rn = row(n);
+		/* candidates for X, best first: what the state's base (on a literal set: its failure state f) answers on the class
+		 * of bit 0 -- when f's row is linear (a trie node with every child) X + b is then delta(f, b), the failure state of
+		 * the child on b: exactly what that child should carry --, then the values of target - b by how many classes vote
+		 * for them.  The first one whose exceptions have consecutive targets is taken. */
+		uint32_t cand[65], cnt[65], nc = 0;
+		if (n < base.size() && base[n] != NONE && base[n] < N) { cand[0] = row(base[n])[cls_of_bit[0]]; cnt[0] = 0xFFFFFFFFu; nc = 1; }
+		for (uint32_t b = 0; b < nbits; b++) {
+			const uint32_t v = rn[cls_of_bit[b]] - b;
+			uint32_t k = 0;
+			while (k < nc && cand[k] != v) k++;
+			if (k == nc) { cand[nc] = v; cnt[nc++] = 0; }
+			if (cnt[k] != 0xFFFFFFFFu) cnt[k]++;
+		}
+		bool found = false;
+		FRec r = { 0, 0, 0 };
+		uint32_t X = 0;
+		for (uint32_t round = 0; round < nc && !found; round++) {
+			uint32_t best = 0;
+			for (uint32_t k = 1; k < nc; k++) if (cnt[k] > cnt[best]) best = k;
+			if (cnt[best] == 0) break;
+			X = cand[best];
+			cnt[best] = 0;
+			r.bits = 0;
+			r.cf63 = X + 63u;
+			uint32_t first = NONE, k = 0;
+			bool consec = true;
+			for (uint32_t b = 0; b < nbits; b++) {
+				const uint32_t t = rn[cls_of_bit[b]];
+				if (t == X + b) continue;
+				r.bits |= (uint64_t)1 << b;
+				if (first == NONE) first = t;
+				if (t != first + k) consec = false;
+				k++;
+			}
+			r.fm1 = k == 0 ? 0u : first - 1u;
+			found = consec && !(r.fm1 & SENT) && !(r.cf63 & SENT) && X + nbits >= X;
+		}
+		if (!found) break;
+		LR.push_back(r);
+		Xof.push_back(X);
+		need.push_back((uint64_t)X + nbits);   /* X + b < H for every b */
+	}
+	uint32_t H = 0;
+	{
+		uint64_t mx = 0;
+		std::vector<uint64_t> pm(LR.size() + 1, 0);
+		for (size_t n = 0; n < LR.size(); n++) { mx = need[n] > mx ? need[n] : mx; pm[n + 1] = mx; }
+		for (size_t h = LR.size(); h > 0; h--)
+			if (pm[h] <= h) { H = (uint32_t)h; break; }
+	}
+	if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "build_lazy: nbits=%u LR=%zu H=%u start=%u N=%u Hcap=%u\n", nbits, LR.size(), H, p.start, N, Hcap);
+	if (H == 0 || p.start >= H) return;
+	LR.resize(H);
+	uint32_t fwords = 4096;
+	while ((uint64_t)fwords * 2u * 4u + ((uint64_t)H + 1u) * 16u + 1024u <= lds_limit) fwords *= 2u;
+	if ((uint64_t)fwords * 4u + ((uint64_t)H + 1u) * 16u + 1024u > lds_limit) return;
+	const uint32_t Z = H;
+
+	auto evalF = [&](uint32_t e, uint32_t b) -> uint32_t {
+		const FRec &r = LR[e];
+		if ((r.bits >> b) & 1u) return r.fm1 + popc(r.bits & (((uint64_t)2 << b) - 1u));
+		return r.cf63 - (63u - b);
+	};
+	auto cfbF = [&](uint32_t e, uint32_t b) -> uint32_t { return LR[e].cf63 - (63u - b); };
+	/* the own record of a state s >= H that carries e: the classes on which its row differs from e's answers */
+	/* ... as {bits, base, stride}: the k-th exception (in bit order, k from 1) leads to base + k * stride.  That covers the
+	 * children of a trie node (consecutive ids: stride 1) and ANY record with two exceptions -- the usual shape of a deep
+	 * literal-set node whose failure state is itself beyond the LDS set: one child of its own, one inherited --; base =
+	 * sentinel where the targets are no such progression (a hit then takes the exact path) */
+	auto make_deep = [&](uint32_t s, uint32_t e, uint64_t &bits, uint32_t &fm1, uint32_t &stride) {
+		stride = 0;
+		if (e == Z) { bits = ~(uint64_t)0; fm1 = SENT; return; }
+		bits = 0;
+		uint32_t t0 = 0, k = 0;
+		int64_t d = 1;
+		bool ok = true;
+		const uint32_t *rs = row(s);
+		for (uint32_t b = 0; b < nbits; b++) {
+			const uint32_t f = evalF(e, b);
+			if (f & SENT) continue;                 /* the step sees the sentinel and takes the exact path whatever this record says */
+			const uint32_t t = rs[cls_of_bit[b]];
+			if (t == f) continue;
+			bits |= (uint64_t)1 << b;
+			if (k == 0) t0 = t;
+			else if (k == 1) d = (int64_t)t - (int64_t)t0;
+			if ((int64_t)t != (int64_t)t0 + (int64_t)k * d || t < H) ok = false;    /* (a target inside the LDS set would have to carry itself) */
+			k++;
+		}
+		if (d == 0 || d >= (1 << 22) || d <= -(1 << 22)) ok = false;
+		if (k == 0) { fm1 = 0; return; }
+		if (!ok) { fm1 = SENT; return; }
+		stride = (uint32_t)(int32_t)d;
+		fm1 = t0 - stride;
+	};
+
+	/* 2. what each state beyond the LDS set carries, by the kernel's own rule, over everything reachable.  A state entered
+	 * through the exact path (a sentinel step) is GIVEN its record by the kernel -- word 3 of its own record, car[] -- so
+	 * only the straight-line entries constrain car[]; a state they reach with two different values gets Z (its own record
+	 * then excepts everything: all its steps are exact ones). */
+	std::vector<uint32_t> car(S1, NONE), sugg(S1, NONE);
+	std::vector<uint8_t> seen(S1, 0), inq(S1, 0);
+	std::vector<uint32_t> q, deferred;
+	bool abs_reach = false;
+	seen[p.start] = 1; inq[p.start] = 1; q.push_back(p.start);
+	for (;;) {
+		while (!q.empty()) {
+			const uint32_t s = q.back();
+			q.pop_back();
+			inq[s] = 0;
+			const uint32_t es = s < H ? s : car[s];
+			uint64_t sb = 0;
+			uint32_t sfm1 = 0, sstr = 0;
+			if (s >= H) make_deep(s, es, sb, sfm1, sstr);
+			const uint32_t *rs = row(s);
+			for (uint32_t c = 0; c < C; c++) {
+				const uint32_t m = rs[c], b = bit_of[c];
+				if (m >= N) { abs_reach = true; continue; }   /* absorbing: the kernel keeps the id, nothing is carried */
+				if (m < H) {
+					if (!seen[m]) { seen[m] = 1; inq[m] = 1; q.push_back(m); }
+					continue;
+				}
+				bool exact = true;
+				uint32_t cr = Z;
+				if (b != 0xff && es != Z) {
+					const uint32_t f = evalF(es, b);
+					const bool own = s >= H && ((sb >> b) & 1u);
+					if (!(f & SENT)) {
+						cr = f >= H ? cfbF(es, b) : f;
+						exact = own && sfm1 == SENT;
+					}
+				}
+				if (exact) {
+					/* entered through the exact path: takes whatever car[m] turns out to be; failing a straight-line entry,
+					 * what one would have carried here (so that the states below a record with scattered exceptions
+					 * still walk the fast way) */
+					if (cr != Z && sugg[m] == NONE) sugg[m] = cr;
+					if (!seen[m]) { seen[m] = 1; deferred.push_back(m); }
+					else if (car[m] == NONE) deferred.push_back(m);
+					continue;
+				}
+				seen[m] = 1;
+				if (car[m] == NONE) { car[m] = cr; inq[m] = 1; q.push_back(m); }
+				else if (car[m] != cr && car[m] != Z) { car[m] = Z; if (!inq[m]) { inq[m] = 1; q.push_back(m); } }
+			}
+		}
+		/* states only ever entered through the exact path so far */
+		bool any = false;
+		for (uint32_t m : deferred)
+			if (car[m] == NONE) { car[m] = sugg[m] != NONE ? sugg[m] : Z; inq[m] = 1; q.push_back(m); any = true; }
+		deferred.clear();
+		if (!any) break;
+	}
+
+	/* 3. the image */
+	const uint32_t sh_off = 0, filt_off = 1024u, rec_off = filt_off + fwords * 4u, lds_bytes = rec_off + (H + 1u) * 16u;
+	const uint32_t lds_w = lds_bytes / 4u, grec_w = (16u + lds_w + 3u) & ~3u;
+	std::vector<uint32_t> &img = p.lazy_img;
+	const size_t car_w = (size_t)grec_w + (size_t)S1 * 4u;
+	img.assign(car_w + S1, 0);
+	uint32_t *L = &img[16];
+	for (uint32_t n = 0; n < H; n++) {
+		uint32_t *r = L + rec_off / 4u + n * 4u;
+		r[0] = (uint32_t)LR[n].bits; r[1] = (uint32_t)(LR[n].bits >> 32); r[2] = LR[n].fm1; r[3] = LR[n].cf63;
+	}
+	{
+		uint32_t *r = L + rec_off / 4u + Z * 4u;     /* Z: no bits, every answer a sentinel */
+		r[0] = r[1] = 0; r[2] = SENT; r[3] = SENT + 63u;
+	}
+	for (unsigned v = 0; v < 256; v++) {
+		const uint32_t b = bit_of[p.cls[v]];
+		L[sh_off / 4u + v] = b != 0xff ? 63u - b : (SENT | ((63u - nbits) & 63u));   /* bit 31: the kernel ORs a chunk's 16 entries into its sentinel test */
+	}
+	uint32_t nzstates = 0, nsent = 0;
+	for (uint32_t s = H; s < N; s++) {
+		uint64_t bits;
+		uint32_t fm1, stride;
+		make_deep(s, car[s] == NONE ? Z : car[s], bits, fm1, stride);
+		uint32_t *r = &img[grec_w + (size_t)s * 4u];
+		r[0] = (uint32_t)bits; r[1] = (uint32_t)(bits >> 32); r[2] = fm1; r[3] = stride;
+		img[car_w + s] = car[s] == NONE ? Z : car[s];   /* what the state carries: read by the kernel after an exact step into it */
+		if (car[s] == Z) nzstates++;
+		else if (fm1 == SENT) nsent++;
+	}
+	/* the filter: the exceptions of the states [H, F), as many states as keep it under ~0.22 keys per bit */
+	uint64_t nkeys = 0;
+	uint32_t F = H;
+	const uint64_t fbits = (uint64_t)fwords * 32u, budget = fbits * 22u / 100u;
+	for (uint32_t s = H; s < N; s++) {
+		const uint32_t *r = &img[grec_w + (size_t)s * 4u];
+		const uint64_t bits = r[0] | ((uint64_t)r[1] << 32);
+		const uint32_t k = popc(bits);
+		if (nkeys + k > budget) break;
+		for (uint32_t b = 0; b < 64; b++) {
+			if (!((bits >> b) & 1u)) continue;
+			L[filt_off / 4u + (s & (fwords - 1u))] |= 1u << ((63u - b) & 31u);   /* one word per state id, bit sh % 32 (walk_lazy.h) */
+		}
+		nkeys += k;
+		F = s + 1u;
+	}
+	img[0] = 0x31595a4cu;   /* "LZY1" */
+	img[1] = H;
+	img[2] = F;
+	img[3] = fwords;
+	img[4] = rec_off;
+	img[5] = filt_off;
+	img[6] = lds_bytes;
+	img[7] = grec_w * 4u;
+	img[8] = (uint32_t)nkeys;
+	img[9] = nzstates;
+	img[10] = nsent;
+	img[11] = abs_reach ? 1u : 0u;
+	img[12] = nbits;
+	img[13] = S1;
+	img[14] = (uint32_t)(car_w * 4u);
+	p.lazy_lds_bytes = lds_bytes;
 }
 
 /*

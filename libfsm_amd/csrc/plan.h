@@ -88,6 +88,10 @@ struct Plan {
 	/* SPARSE: base-row records (see build_sparse in plan.cpp); states are plain renumbered ids */
 	std::vector<uint32_t> sparse_img;
 	uint32_t sparse_lds_bytes = 0;    /* leading part of the image that the kernel mirrors in LDS */
+	/* SPARSE, lazy form (plan.cpp build_lazy, walk_lazy.h): a second image for the fixed-stride plain walk in which a
+	 * state beyond the LDS set is entered without fetching its record; empty when the automaton has none */
+	std::vector<uint32_t> lazy_img;
+	uint32_t lazy_lds_bytes = 0;
 };
 
 /* Returns 0 or an errno value (EINVAL, ENOMEM, ENOTSUP for a forced layout

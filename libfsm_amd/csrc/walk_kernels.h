@@ -107,6 +107,8 @@ struct WalkArgs {
 	/* two kernels launched for one batch, the choice made on the device: return at once if *skip_flag == skip_when */
 	const uint32_t *skip_flag;
 	uint32_t        skip_when;
+	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy */
+	const void     *lazy;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu
@@ -131,7 +133,7 @@ __device__ __forceinline__ uint32_t fin_index(const WalkArgs &a, uint32_t code)
 	return code / a.fin_div;
 }
 
-enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_PACKED = 4 };
+enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_PACKED = 4, IN_LAZY = 5 };
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
 #define FSMHIP_BTAB_BYTES 256u

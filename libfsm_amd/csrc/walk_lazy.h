@@ -1,0 +1,273 @@
+/*
+ * walk_lazy.h -- gfx950 device code: the LAZY walk of the sparse layout (plan.cpp build_lazy).
+ *
+ * The table of a 1e5-literal Aho-Corasick automaton (BASELINE configs[4]: ~1e6 states) does not fit LDS, and
+ * SparseFastPol (walk_kernels.h) -- the record of every state entered is fetched, from LDS for the ~4 000 states
+ * nearest the start state, by a 16-byte L2 gather for the rest -- is bound by those gathers: 0.33 L2 requests per
+ * input byte keep the vector memory pipe 80 % busy (profiles/r04p_c5_memory_pipeline.txt), and 98 % of them only
+ * confirm that the state has no exception on the next byte.  Here a state beyond the LDS set is entered WITHOUT its
+ * record:
+ *   - the walk state is (id, E): E = id for an LDS-resident state, else the LDS-resident record whose answers the
+ *     state inherits (on a literal set: the deepest LDS-resident node on its failure chain, ac.c:229-241), obtained
+ *     by arithmetic in the step that entered the state;
+ *   - a byte is answered by E's 16-byte LDS record {bits, fm1, cf63}: exception (bit set) -> fm1 + rank, else
+ *     cf63 - sh (= X + bit: the planner's most frequent target of the row); one 64-bit shift, two v_bcnt, a select;
+ *   - whether the state's OWN record excepts the byte is asked of a one-hash Bloom filter in LDS keyed by
+ *     (id, class) -- 64 KiB of bits for the ~1e5 exceptions of the ~8e4 depth-3 nodes: 17 % false positives -- and
+ *     only a set bit costs the gather of the own record (a buffer load whose offset is pushed out of range for the
+ *     other lanes: they get zeros, i.e. "no exception", and make no memory request);
+ *   - any answer with bit 31 set is a SENTINEL (non-consecutive targets, a class without a bit, a state reached in
+ *     two ways...): the 16-byte chunk is then re-walked for those lanes with the exact records of build_sparse in
+ *     device memory.  The planner proves the rest (plan.cpp, tests/test_plan.py).
+ * One workgroup of 16 waves per CU next to a 131 KiB table (64 KiB filter + 4 162 records + the byte map), TWO inputs
+ * per lane for the instruction-level parallelism the second workgroup used to give; per-lane 16-byte input loads,
+ * four chunks per row in flight (as walk_direct_np).  Fixed-stride rows, plain (non-eager, non-resumed) walks.
+ */
+#ifndef FSM_HIP_WALK_LAZY_H
+#define FSM_HIP_WALK_LAZY_H
+
+#include "walk_kernels.h"
+
+namespace fsmhip {
+
+#define FSMHIP_LAZY_SH_BYTES 1024u      /* sh[256] sits at LDS address 0, the filter right behind it */
+
+/* one exact step through build_sparse's records in DEVICE memory (no LDS mirror, the FULLBASE shortcut not taken:
+ * the chain simply goes on to the base) */
+__device__ __forceinline__ uint32_t sparse_next_global(const uint32_t *img, uint32_t st, uint32_t byte, uint32_t abs_min)
+{
+	const uint16_t *pm = reinterpret_cast<const uint16_t *>(img + 16);
+	const unsigned char *g = reinterpret_cast<const unsigned char *>(img);
+	const u32x4 *grec = reinterpret_cast<const u32x4 *>(g + img[5]);
+	const uint32_t *gdense = reinterpret_cast<const uint32_t *>(g + img[6]);
+	const uint32_t *exc = reinterpret_cast<const uint32_t *>(g + img[7]);
+	const uint32_t p = pm[byte], cls = p & 0xffu, bit = p >> 8;
+	const bool hasbit = bit < 64u;
+	const uint64_t sel = hasbit ? (uint64_t)1 << (bit & 63u) : 0u, below = hasbit ? sel - 1u : 0u;
+	uint32_t res = st;
+	bool live = st < abs_min;
+	while (live) {
+		const u32x4 r = grec[st];
+		const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
+		const bool hit = (bits & sel) != 0u, dense = (r.z & 0x80000000u) != 0u;
+		uint32_t v = r.w + (uint32_t)__popcll(bits & below);
+		if (dense) v = gdense[r.w + cls];
+		else if (hit && !(r.z & 0x40000000u)) v = exc[v];
+		const bool done = hit || dense;
+		res = done ? v : res;
+		st = r.z & 0x0FFFFFFFu;
+		live = !done;
+	}
+	return res;
+}
+
+struct LazyCtx {
+	uint32_t H, F, fmask, recbase, abs_min;
+	__amdgpu_buffer_rsrc_t own;     /* the own records, 16 bytes per state: out-of-range offsets read zeros */
+};
+
+typedef const u32x4 __attribute__((address_space(3))) *lazy_rec_p;
+typedef const uint32_t __attribute__((address_space(3))) *lazy_u32_p;
+
+/* popcount(x) + acc as ONE v_bcnt_u32_b32 (its second operand is an addend); without the barrier the compiler
+ * re-associates two of them into v_bcnt, v_bcnt, v_add3 */
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+	uint32_t r = (uint32_t)__builtin_popcount(x) + acc;
+	__asm__("" : "+v"(r));
+	return r;
+}
+
+/* rank + first - 1 of the class's bit in a record {bits, fm1}, and whether the bit is set.  bits << sh moves the class's bit
+ * to bit 63 and the bits below it above it: the hit is a sign test of the high word, the rank a popcount.  (The barrier keeps
+ * the sign test a 32-bit compare: as the 64-bit compare the compiler prefers it drags wait states behind it.) */
+__device__ __forceinline__ bool lazy_probe(uint32_t b0, uint32_t b1, uint32_t fm1, uint32_t sh, uint32_t &n)
+{
+	const uint64_t x = (((uint64_t)b1 << 32) | b0) << (sh & 63u);
+	uint32_t hi = (uint32_t)(x >> 32);
+	__asm__("" : "+v"(hi));
+	n = bcnt_acc((uint32_t)x, bcnt_acc(hi, fm1));
+	return (int32_t)hi < 0;
+}
+
+/* The walk state of one input: the state's id, the LDS record E that answers for it, and -- prepared by the step that
+ * entered the state, off the critical path -- what the own-record question needs: the filter word of the state the LDS
+ * answer led to, whether that state lies beyond the LDS set (D), and whether the own record must be fetched whatever the
+ * filter says (A: ids from F up, and every state entered through an own-record exception, whose id was not known when the
+ * filter word was read -- its own record is the authority either way). */
+struct LazyState {
+	uint32_t id, E, fw;
+	bool A, D;
+};
+
+__device__ __forceinline__ LazyState lazy_enter(const LazyCtx &cx, uint32_t id, uint32_t E)
+{
+	LazyState s;
+	s.id = id;
+	s.E = E;
+	s.fw = *(lazy_u32_p)(uintptr_t)(((id << 2) & cx.fmask) + FSMHIP_LAZY_SH_BYTES);
+	s.A = id >= cx.F;
+	s.D = id >= cx.H;
+	return s;
+}
+
+/* One byte of one input.  All boolean logic is between compares (lane masks in SGPRs, combined by the scalar unit);
+ * written over 0 / 1 integers the compiler does it with vector selects.  The dependent chain from one own-record gather to
+ * the next is: shift, sign test, (scalar or), select of the offset -- the filter word of the next state was read for the
+ * LDS answer `ev` while the gather was in flight. */
+template <bool ABS>
+__device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint32_t sh, uint32_t &bacc)
+{
+	const u32x4 rb = *(lazy_rec_p)(uintptr_t)(cx.recbase + s.E * 16u);
+	/* the own record, for the lanes that may have an exception here: the others' offset is out of range (zeros, no request).
+	 * The filter: one 32-bit word per state id (modulo the filter's size), bit sh % 32 of it */
+	const bool pos = s.A | (s.D & (__builtin_amdgcn_ubfe(s.fw, sh, 1u) != 0u));   /* (no short circuit) */
+	const uint32_t off = pos ? s.id << 4 : 0xFFFFFFF0u;
+	const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(cx.own, (int)off, 0, 0);
+	/* E's answer */
+	uint32_t nB, nA;
+	const bool hB = lazy_probe(rb.x, rb.y, rb.z, sh, nB);
+	const uint32_t cfb = rb.w - sh;
+	const uint32_t ev = hB ? nB : cfb;
+	const bool evD = (int32_t)ev >= (int32_t)cx.H;
+	uint32_t rep = evD ? cfb : ev;
+	const uint32_t fwn = *(lazy_u32_p)(uintptr_t)(((ev << 2) & cx.fmask) + FSMHIP_LAZY_SH_BYTES);
+	const bool evA = ev >= cx.F;
+	/* the own record's {bits, base, stride}: the k-th exception leads to base + k * stride (an exception of a state beyond
+	 * the LDS set leads beyond the LDS set: plan.cpp) */
+	const bool hA = lazy_probe(g.x, g.y, 0u, sh, nA);
+	nA = (uint32_t)(__mul24((int)nA, (int)g.w) + (int)g.z);
+	uint32_t m = hA ? nA : ev;
+	if (ABS) {
+		const bool ab = s.id >= cx.abs_min;
+		m = ab ? s.id : m;
+		rep = ab ? s.E : rep;
+	}
+	bacc |= m | rep;
+	s.id = m;
+	s.E = rep;
+	s.fw = fwn;
+	s.A = evA | hA;
+	s.D = evD;
+}
+
+/* byte k (run-time) of a chunk */
+__device__ __forceinline__ uint32_t byte_dyn(const u32x4 &w, uint32_t k)
+{
+	const uint32_t d = k < 8u ? (k < 4u ? w.x : w.y) : (k < 12u ? w.z : w.w);
+	return (d >> ((k & 3u) * 8u)) & 0xffu;
+}
+
+/* the exact re-walk of a chunk, from the state (id, E) it began in, for the lanes that met a sentinel in it */
+template <bool ABS>
+__device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *simg, const uint32_t *car, uint32_t &id, uint32_t &E, const u32x4 &w)
+{
+#pragma unroll 1
+	for (uint32_t k = 0; k < 16u; k++) {
+		const uint32_t byte = byte_dyn(w, k);
+		const uint32_t sh = *(lazy_u32_p)(uintptr_t)(byte * 4u);
+		LazyState c = lazy_enter(cx, id, E);
+		uint32_t b = 0;
+		lazy_step<ABS>(cx, c, sh, b);
+		if ((int32_t)(b | sh) < 0) {
+			/* the exact step; what a state beyond the LDS set carries comes from plan.cpp's car[] */
+			c.id = sparse_next_global(simg, id, byte, cx.abs_min);
+			c.E = c.id < cx.H ? c.id : car[c.id];
+		}
+		id = c.id;
+		E = c.E;
+	}
+}
+
+template <bool ABS>
+__global__ void __launch_bounds__(1024)
+walk_lazy(const WalkArgs a)
+{
+	constexpr int NB = 4;
+	extern __shared__ __align__(16) unsigned char lds[];
+	const uint32_t *lz = static_cast<const uint32_t *>(a.lazy);
+	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
+	const uint32_t *car = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(lz) + lz[14]);   /* what a state beyond the LDS set carries */
+	LazyCtx cx;
+	/* wave-uniform, and known to be: the header words are read through the scalar unit's eyes */
+	cx.H = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[1]);
+	cx.F = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[2]);
+	cx.fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[3] - 1u) << 2));
+	cx.recbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[4]);
+	cx.abs_min = a.abs_min;
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(lz + 16);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+		const uint32_t nv = lz[6] / 16u;
+		for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) dst[i] = src[i];
+	}
+	/* LDS addresses are formed from table-relative offsets: the dynamic segment must start at LDS address 0 */
+	if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
+	{
+		/* a buffer resource in VGPRs costs a waterfall loop per load: make every word of it a scalar */
+		const uint64_t ob = reinterpret_cast<uint64_t>(lz) + lz[7];
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32));
+		const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lz[13] * 16u));
+		cx.own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)nrec, 0x00020000);
+	}
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+	const uint64_t ntiles = (a.n + 127u) / 128u;
+	const uint32_t ngroups = (uint32_t)(a.stride / 16u) / NB;   /* host guarantees divisibility */
+
+	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
+		uint64_t i[2];
+		const u32x4 *q[2];
+		LazyState st[2];
+#pragma unroll
+		for (int r = 0; r < 2; r++) {
+			i[r] = tile * 128u + (uint32_t)r * 64u + lane;
+			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
+			st[r] = lazy_enter(cx, a.start, a.start);      /* the start state is LDS-resident (plan.cpp) */
+		}
+		for (uint32_t g = 0; g < ngroups; g++) {
+			u32x4 cur[NB][2];
+#pragma unroll
+			for (int j = 0; j < NB; j++)
+#pragma unroll
+				for (int r = 0; r < 2; r++) cur[j][r] = q[r][g * NB + j];
+#pragma unroll
+			for (int j = 0; j < NB; j++) {
+				uint32_t sh[2][16];
+#pragma unroll
+				for (int r = 0; r < 2; r++)
+#pragma unroll
+					for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], k) * 4u);
+				const uint32_t sid[2] = { st[0].id, st[1].id }, sE[2] = { st[0].E, st[1].E };
+				/* a byte whose class owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too */
+				uint32_t bacc[2] = { 0u, 0u };
+#pragma unroll
+				for (int r = 0; r < 2; r++)
+#pragma unroll
+					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+#pragma unroll
+					for (int r = 0; r < 2; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
+				if (__builtin_amdgcn_ballot_w64((int32_t)(bacc[0] | bacc[1]) < 0) != 0u) {
+#pragma unroll
+					for (int r = 0; r < 2; r++) {
+						if ((int32_t)bacc[r] < 0) {
+							uint32_t cid = sid[r], cE = sE[r];
+							lazy_careful<ABS>(cx, simg, car, cid, cE, cur[j][r]);
+							st[r] = lazy_enter(cx, cid, cE);
+						}
+					}
+				}
+			}
+			if (ABS && (a.early & 1u) && __all(st[0].id >= a.abs_min && st[1].id >= a.abs_min)) break;
+		}
+#pragma unroll
+		for (int r = 0; r < 2; r++) write_result(a, tile * 2u + (uint32_t)r, i[r], i[r] < a.n, st[r].id);
+	}
+}
+
+} // namespace fsmhip
+
+#endif

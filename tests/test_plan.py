@@ -401,3 +401,149 @@ def test_layouts_on_reference_fsm_corpus(built):
         for L in (0,) + tuple(ALL_LAYOUTS):
             held += bool(check_plan(flat, L))
     assert held > 4 * len(c)
+
+
+# ---- the lazy form of the sparse layout (plan.cpp build_lazy, walk_lazy.h) ---------------------------------
+
+SENT = 0x80000000
+
+
+def lazy_decode(p):
+    img = p.get("lazy").astype(np.int64)
+    if img.size == 0:
+        return None
+    assert img[0] == 0x31595a4c
+    H, F, fwords, rec_off, filt_off, lds_bytes, grec_off = (int(x) for x in img[1:8])
+    assert filt_off == 1024 and rec_off == filt_off + 4 * fwords and lds_bytes == rec_off + 16 * (H + 1) <= 160 * 1024
+    assert fwords & (fwords - 1) == 0 and int(img[13]) == p.S1
+    L = img[16:16 + lds_bytes // 4]
+    sh = L[:256]
+    filt = L[filt_off // 4: filt_off // 4 + fwords]
+    rec = L[rec_off // 4:].reshape(H + 1, 4)
+    own = img[grec_off // 4: grec_off // 4 + 4 * p.S1].reshape(p.S1, 4)
+    car = img[int(img[14]) // 4: int(img[14]) // 4 + p.S1]
+    return dict(H=H, F=F, fwords=fwords, sh=sh, filt=filt, rec=rec, own=own, car=car, abs_reach=int(img[11]), nkeys=int(img[8]), nz=int(img[9]), nsent=int(img[10]))
+
+
+def lazy_probe(b0, b1, fm1, sh):
+    """walk_lazy.h lazy_probe: (hit, first - 1 + rank + 1) of the class's bit in {bits, fm1}"""
+    x = (((b1 << 32) | b0) << (sh & 63)) & 0xFFFFFFFFFFFFFFFF
+    return (x >> 63) & 1 == 1, (bin(x).count("1") + fm1) & 0xFFFFFFFF
+
+
+def lazy_step(z, abs_min, sid, E, sh, use_abs):
+    """one byte of walk_lazy.h lazy_step on state (id, E): returns (m, rep, sentinel); the own record is consulted
+    exactly when the kernel's `pos` says so (ids >= F, or the filter bit of (id, sh % 32))"""
+    H, F = z["H"], z["F"]
+    rb = z["rec"][E] if E <= H else np.zeros(4, np.int64)
+    hB, nB = lazy_probe(int(rb[0]), int(rb[1]), int(rb[2]), sh)
+    cfb = (int(rb[3]) - sh) & 0xFFFFFFFF
+    ev = nB if hB else cfb
+    s32 = lambda v: v - (1 << 32) if v & SENT else v
+    evD = s32(ev) >= H
+    rep = cfb if evD else ev
+    pos = sid >= F or (sid >= H and (int(z["filt"][sid & (z["fwords"] - 1)]) >> (sh & 31)) & 1)
+    m = ev
+    if pos and sid < len(z["own"]):
+        g = z["own"][sid]
+        hA, pc = lazy_probe(int(g[0]), int(g[1]), 0, sh)      # {bits, base, stride}: the k-th exception leads to base + k * stride
+        if hA:
+            stride = int(g[3]) - (1 << 32) if int(g[3]) & SENT else int(g[3])
+            m = (int(g[2]) + pc * stride) & 0xFFFFFFFF
+    if use_abs and sid >= abs_min:
+        m, rep = sid, E
+    return m, rep, bool((m | rep | sh) & SENT)
+
+
+def check_lazy(p, want, max_pairs=None):
+    """Every reachable (state, carried record) pair of the lazy walk, every byte: the kernel's step -- sentinel -> the exact
+    path (here: the dense table), after which the state carries what the planner's car[] says -- lands on delta(state, byte).  A state may be reached
+    with several carried records only if its steps do not depend on them (the planner then makes its own record except
+    everything); the pairs are followed one by one, so that is checked too."""
+    z = lazy_decode(p)
+    if z is None:
+        return None
+    H, N = z["H"], p.abs_min
+    assert p.start < H
+    use_abs = bool(z["abs_reach"])
+    seen = {(p.start, p.start)}
+    todo = [(p.start, p.start)]
+    nfast = nsent = nsent_bit = 0
+    while todo:
+        s, E = todo.pop()
+        if s >= N:
+            continue
+        for by in range(256):
+            sh = int(z["sh"][by]) & 0xFFFFFFFF
+            m, rep, sent = lazy_step(z, N, s, E, sh, use_abs)
+            t = int(want[s][by])
+            if sent:
+                nsent += 1
+                nsent_bit += not (sh & SENT)
+                m, rep = t, (t if t < H else int(z["car"][t]))            # the exact path; a state beyond the LDS set is handed what it carries
+            else:
+                nfast += 1
+                assert m == t, (s, E, by, m, t)
+                assert rep <= H
+            if m >= N:
+                assert use_abs, "an absorbing state is reachable: the kernel variant that tests for it must be the one launched"
+                continue
+            if m < H:
+                assert rep == m, (s, by, m, rep)
+            if (m, rep) not in seen:
+                seen.add((m, rep))
+                todo.append((m, rep))
+        if max_pairs and len(seen) > max_pairs:
+            break
+    states = len({s for s, _ in seen})
+    return dict(H=H, F=z["F"], states=states, pairs=len(seen), fast=nfast, sentinel=nsent, sentinel_bit=nsent_bit, nkeys=z["nkeys"], nz=z["nz"])
+
+
+def test_lazy_form_of_literal_sets(built):
+    """The lazy walk's image for literal sets of several shapes: full depth-1 / depth-2 levels (the shape of configs[4]),
+    sparse ones, anchored and unanchored: exact on every reachable (state, carried, byte)."""
+    rng = np.random.RandomState(23)
+    shapes = [(b"abcd", 400, 3, 9, 2), (b"abcdefgh", 3000, 4, 10, 2), (b"abcdefghijklmnop", 4000, 5, 9, 0),
+              (b"abcdefghijklmnopqrstuvwxyz0123456789", 3000, 6, 12, 2), (b"ab", 60, 2, 8, 2)]
+    seen_lazy = 0
+    for alpha_b, nw, lo, hi, flags in shapes:
+        alpha = np.frombuffer(alpha_b, np.uint8)
+        words = sorted(set(bytes(alpha[rng.randint(0, len(alpha), rng.randint(lo, hi + 1))]) for _ in range(nw)))
+        ac = FlatDfa.from_strings(words, flags, list(range(len(words))))
+        pa = Plan(ac, LAYOUT_SPARSE, lds_limit=64 * 1024 if len(alpha_b) <= 8 else 0)
+        want = decode_want(ac, pa)
+        r = check_lazy(pa, want)
+        if r is None:
+            continue
+        seen_lazy += 1
+        assert r["states"] >= r["H"]
+        # where the first levels are full the straight-line path takes (nearly) every byte
+        # (sentinel_bit: sentinel steps on bytes of the alphabet; the others take the exact path by design)
+        print(alpha_b, r)
+    assert seen_lazy >= 3
+
+
+def test_lazy_form_on_random_dfas(built):
+    """Literal-set automata with a few per cent of their transitions rewired at random (still DFAs, no longer tries: states
+    entered in several ways, exceptions that are no progression, targets inside the LDS set ...): whatever the automaton,
+    the lazy image -- when the planner makes one -- is exact on every reachable (state, carried record, byte)."""
+    rng = np.random.RandomState(5)
+    made = 0
+    for trial in range(8):
+        alpha_b = [b"abcd", b"abcdefgh", b"abcdefghijkl"][trial % 3]
+        alpha = np.frombuffer(alpha_b, np.uint8)
+        words = sorted(set(bytes(alpha[rng.randint(0, len(alpha), rng.randint(3, 8))]) for _ in range(int(rng.randint(200, 1500)))))
+        ac = FlatDfa.from_strings(words, int(rng.choice([0, 2])), list(range(len(words))))
+        nt = ac.dense().astype(np.int64)
+        nt[nt == NO] = -1
+        S = ac.nstates
+        k = int(S * len(alpha_b) * rng.choice([0.002, 0.02, 0.1]))
+        ss, cc = rng.randint(0, S, k), alpha[rng.randint(0, len(alpha), k)]
+        nt[ss, cc] = rng.randint(0, S, k)
+        if trial % 4 == 3:
+            nt[rng.randint(0, S, 5)] = -1                      # a few states without edges: DEAD becomes reachable
+        flat = FlatDfa.from_dense(nt, ac.start, ac.is_end)
+        pa = Plan(flat, LAYOUT_SPARSE, lds_limit=int(rng.choice([48, 160])) * 1024)
+        r = check_lazy(pa, decode_want(flat, pa))
+        made += r is not None
+    assert made >= 4
