@@ -22,7 +22,7 @@ enum {
 	                                  * 4 packed (packed offsets only: a lane owns a byte range and walks across input
 	                                  * boundaries; other fronts take their auto choice); -1 auto */
 	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
-	FSM_HIP_KNOB_ROWS          = 3,  /* retired (accepted, ignored)                                   */
+	FSM_HIP_KNOB_ROWS          = 3,  /* the lazy walk of the sparse layout: inputs per lane, 2 (default) or 3; ignored elsewhere */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
@@ -41,6 +41,7 @@ enum {
 	                                  * LDS set are entered without their record, a Bloom filter in LDS says when to fetch it
 	                                  * (walk_lazy.h); 1 (default otherwise) the record is the walk state and a byte is three
 	                                  * straight-line record probes; 0 the chain loop over state ids (A/B measurement)   */
+	FSM_HIP_KNOB_LAZY_DYN      = 21, /* the lazy walk: 1 (default) wavefronts claim their tiles from a device counter, 0 static striding */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };

@@ -34,6 +34,11 @@ struct fsm_hip_dfa {
 	uint32_t *d_fin = nullptr;
 	uint32_t *d_btab = nullptr;
 	uint32_t *d_lazy = nullptr;                      /* sparse layout: the lazy image (plan.cpp build_lazy), if the automaton has one */
+	uint32_t *d_lazy_ctr = nullptr;                  /* ... and a ring of tile counters: a launch zeroes and uses the next one (launches on
+	                                                  * several streams may be in flight; LAZY_CTRS of them never are) */
+	unsigned lazy_ctr_next = 0;
+	int knob_lazy_rows = 2;                          /* inputs per lane of the lazy walk (2 | 3) */
+	int knob_lazy_dyn = 1;                           /* the lazy walk's wavefronts claim their tiles from a counter (0: static striding) */
 	/* device end-id delivery (built on first use) */
 	std::vector<uint32_t> fin_host;                 /* copy of the fin table uploaded to d_fin */
 	uint32_t *d_fin_earliest = nullptr, *d_fin_ret = nullptr;
@@ -102,6 +107,8 @@ static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
 	d->proto.tab_bytes = (uint32_t)hot;
 	d->table_lds = GlobPol::lds_bytes((uint32_t)hot);
 }
+
+static const unsigned LAZY_CTRS = 64;
 
 static int hip_errno(hipError_t e)
 {
@@ -324,6 +331,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			}
 			if (p.lazy_lds_bytes != 0 && p.lazy_lds_bytes <= d->lds_limit) {
 				HIP_TRY(upload(&d->d_lazy, p.lazy_img));
+				HIP_TRY(hipMalloc((void **)&d->d_lazy_ctr, LAZY_CTRS * sizeof(uint32_t)));
 				a.lazy = d->d_lazy;
 				/* the default where it pays: few states beyond the LDS set whose own record sends hits the exact way
 				 * (img[10]) or that carry nothing (img[9]) -- on the 1e5-literal automaton 4.5 % of them, deep in the trie */
@@ -435,6 +443,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_fin) (void)hipFree(d->d_fin);
 	if (d->d_btab) (void)hipFree(d->d_btab);
 	if (d->d_lazy) (void)hipFree(d->d_lazy);
+	if (d->d_lazy_ctr) (void)hipFree(d->d_lazy_ctr);
 	if (d->d_fin_earliest) (void)hipFree(d->d_fin_earliest);
 	if (d->d_fin_ret) (void)hipFree(d->d_fin_ret);
 	if (d->d_enc_of) (void)hipFree(d->d_enc_of);
@@ -508,11 +517,12 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	c.sparse_fast = d->sparse_fast_ok ? d->knob_sparse_fast : (d->knob_sparse_fast == 3 ? 3 : 0);
 	c.lazy_abs = 0;
 	if (mode == IN_DIRECT && layout == FSM_HIP_LAYOUT_SPARSE && !eager && !resumed && d->d_lazy != nullptr && d->knob_sparse_fast == 3 &&
-	    (stride / 16u) % 4u == 0) {
+	    ((stride / 16u) % 4u == 0 || ((stride / 16u) % 2u == 0 && (d->knob_lazy_rows == 3 || d->knob_nb == 2)))) {
 		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
 		c.mode = IN_LAZY;
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
-		c.nb = 4;
+		c.lazy_rows = d->knob_lazy_rows == 3 && (stride / 16u) % 2u == 0 ? 3 : 2;
+		c.nb = c.lazy_rows == 3 || d->knob_nb == 2 ? 2 : 4;
 		c.waves = 16;
 		c.lds = d->plan.lazy_lds_bytes;
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
@@ -625,7 +635,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : a.off == nullptr ? (uint64_t)a.n * a.stride : 0;
 	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr);
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
+	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 64u * c.lazy_rows - 1u) / (64u * c.lazy_rows) + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
@@ -682,6 +692,10 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	}
 	/* the ragged kernel sets bitmap bits one input at a time */
 	if (e == hipSuccess && (!packed || both) && c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
+	if (e == hipSuccess && c.mode == IN_LAZY && d->knob_lazy_dyn && d->d_lazy_ctr != nullptr) {
+		a.tile_ctr = d->d_lazy_ctr + (md->lazy_ctr_next++ % LAZY_CTRS);
+		e = hipMemsetAsync(a.tile_ctr, 0, sizeof(uint32_t), s);
+	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
 	if (e == hipSuccess && packed) {
 		uint64_t fb = (a.n + 1u + 255u) / 256u;
@@ -1030,7 +1044,8 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
-	case FSM_HIP_KNOB_ROWS: break;   /* retired: two inputs per lane never helped (profiles/r01_sweep2*) */
+	case FSM_HIP_KNOB_ROWS: d->knob_lazy_rows = value == 3 ? 3 : 2; break;   /* (the other kernels: one input per lane; two never helped, profiles/r01_sweep2*) */
+	case FSM_HIP_KNOB_LAZY_DYN: d->knob_lazy_dyn = value != 0; break;
 	case FSM_HIP_KNOB_MASK: break;   /* retired: exec-masking absorbing lanes cost more than it saved */
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;

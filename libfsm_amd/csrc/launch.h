@@ -23,6 +23,7 @@ struct LaunchCfg {
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
+	int lazy_rows;       /* IN_LAZY: inputs per lane, 2 or 3 (3: two chunks per row in flight) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 };
 

@@ -107,8 +107,9 @@ struct WalkArgs {
 	/* two kernels launched for one batch, the choice made on the device: return at once if *skip_flag == skip_when */
 	const uint32_t *skip_flag;
 	uint32_t        skip_when;
-	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy */
+	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy; a zeroed tile counter, or NULL */
 	const void     *lazy;
+	uint32_t       *tile_ctr;
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu

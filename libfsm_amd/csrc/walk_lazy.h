@@ -179,11 +179,13 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 	}
 }
 
-template <bool ABS>
+/* ROWS inputs per lane (independent chains: the instruction-level parallelism a second workgroup per CU would give),
+ * NB 16-byte chunks per row in flight.  a.tile_ctr != NULL: the wavefronts claim their tiles of 64 * ROWS inputs from that
+ * counter (zeroed on the launch stream) instead of striding: the tail of the persistent grid balances to one tile. */
+template <bool ABS, int ROWS, int NB>
 __global__ void __launch_bounds__(1024)
 walk_lazy(const WalkArgs a)
 {
-	constexpr int NB = 4;
 	extern __shared__ __align__(16) unsigned char lds[];
 	const uint32_t *lz = static_cast<const uint32_t *>(a.lazy);
 	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
@@ -213,46 +215,60 @@ walk_lazy(const WalkArgs a)
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-	const uint64_t ntiles = (a.n + 127u) / 128u;
+	constexpr uint32_t TILE = 64u * ROWS;
+	const uint64_t ntiles = (a.n + TILE - 1u) / TILE;
 	const uint32_t ngroups = (uint32_t)(a.stride / 16u) / NB;   /* host guarantees divisibility */
 
-	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (uint64_t)gridDim.x * nw) {
-		uint64_t i[2];
-		const u32x4 *q[2];
-		LazyState st[2];
+	auto claim = [&](uint64_t prev) -> uint64_t {
+		if (a.tile_ctr == nullptr) return prev + (uint64_t)gridDim.x * nw;
+		uint32_t t = 0;
+		if (lane == 0) t = atomicAdd(a.tile_ctr, 1u);
+		return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+	};
+	uint64_t tile = a.tile_ctr == nullptr ? (uint64_t)blockIdx.x * nw + wave : claim(0);
+	for (; tile < ntiles; tile = claim(tile)) {
+		uint64_t i[ROWS];
+		const u32x4 *q[ROWS];
+		LazyState st[ROWS];
 #pragma unroll
-		for (int r = 0; r < 2; r++) {
-			i[r] = tile * 128u + (uint32_t)r * 64u + lane;
+		for (int r = 0; r < ROWS; r++) {
+			i[r] = tile * TILE + (uint32_t)r * 64u + lane;
 			q[r] = reinterpret_cast<const u32x4 *>(a.base + (i[r] < a.n ? i[r] : a.n - 1) * a.stride);
 			st[r] = lazy_enter(cx, a.start, a.start);      /* the start state is LDS-resident (plan.cpp) */
 		}
 		for (uint32_t g = 0; g < ngroups; g++) {
-			u32x4 cur[NB][2];
+			u32x4 cur[NB][ROWS];
 #pragma unroll
 			for (int j = 0; j < NB; j++)
 #pragma unroll
-				for (int r = 0; r < 2; r++) cur[j][r] = q[r][g * NB + j];
+				for (int r = 0; r < ROWS; r++) cur[j][r] = q[r][g * NB + j];
 #pragma unroll
 			for (int j = 0; j < NB; j++) {
-				uint32_t sh[2][16];
+				uint32_t sh[ROWS][16];
 #pragma unroll
-				for (int r = 0; r < 2; r++)
+				for (int r = 0; r < ROWS; r++)
 #pragma unroll
 					for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], k) * 4u);
-				const uint32_t sid[2] = { st[0].id, st[1].id }, sE[2] = { st[0].E, st[1].E };
+				uint32_t sid[ROWS], sE[ROWS], bacc[ROWS];
 				/* a byte whose class owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too */
-				uint32_t bacc[2] = { 0u, 0u };
 #pragma unroll
-				for (int r = 0; r < 2; r++)
+				for (int r = 0; r < ROWS; r++) {
+					sid[r] = st[r].id;
+					sE[r] = st[r].E;
+					bacc[r] = 0u;
 #pragma unroll
 					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
+				}
 #pragma unroll
 				for (int k = 0; k < 16; k++)
 #pragma unroll
-					for (int r = 0; r < 2; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
-				if (__builtin_amdgcn_ballot_w64((int32_t)(bacc[0] | bacc[1]) < 0) != 0u) {
+					for (int r = 0; r < ROWS; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
+				uint32_t ball = 0;
 #pragma unroll
-					for (int r = 0; r < 2; r++) {
+				for (int r = 0; r < ROWS; r++) ball |= bacc[r];
+				if (__builtin_amdgcn_ballot_w64((int32_t)ball < 0) != 0u) {
+#pragma unroll
+					for (int r = 0; r < ROWS; r++) {
 						if ((int32_t)bacc[r] < 0) {
 							uint32_t cid = sid[r], cE = sE[r];
 							lazy_careful<ABS>(cx, simg, car, cid, cE, cur[j][r]);
@@ -261,10 +277,15 @@ walk_lazy(const WalkArgs a)
 					}
 				}
 			}
-			if (ABS && (a.early & 1u) && __all(st[0].id >= a.abs_min && st[1].id >= a.abs_min)) break;
+			if (ABS && (a.early & 1u)) {
+				bool done = true;
+#pragma unroll
+				for (int r = 0; r < ROWS; r++) done = done && st[r].id >= a.abs_min;
+				if (__all(done)) break;
+			}
 		}
 #pragma unroll
-		for (int r = 0; r < 2; r++) write_result(a, tile * 2u + (uint32_t)r, i[r], i[r] < a.n, st[r].id);
+		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + (uint32_t)r, i[r], i[r] < a.n, st[r].id);
 	}
 }
 

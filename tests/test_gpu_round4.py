@@ -74,6 +74,30 @@ def test_lazy_walk_literal_sets(hip, shape):
     dfa.close()
 
 
+def test_lazy_walk_kernel_variants(hip):
+    """Three inputs per lane / two chunks in flight / static striding instead of the tile counter: every instantiation of
+    walk_lazy, on odd batch sizes (the last tile partial, fewer tiles than wavefronts, one input)."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(77)
+    alpha_b = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-"
+    words, flat = literal_set(hip, rng, alpha_b, 20000, 8, 16, 2)
+    orc = Oracle(flat)
+    dfa = hip.HipDfa(flat, hip.LAYOUT_SPARSE)
+    dfa.tune(KNOB_SPARSE_FAST, 3)
+    for n, L in ((1, 32), (191, 96), (193, 1024), (70001, 160)):
+        rows = rows_over(rng, alpha_b, n, L, words, foreign=0.001)
+        want = orc.table_walk(rows)
+        for nrows, nb, dyn in ((2, 0, 1), (2, 0, 0), (3, 0, 1), (3, 0, 0), (2, 2, 1)):
+            dfa.tune(hip.KNOB_ROWS, nrows)
+            dfa.tune(hip.KNOB_NB, nb)
+            dfa.tune(21, dyn)
+            for rep in range(3):
+                end, bm = dfa.exec_batch(rows)
+                assert np.array_equal(end, want), (n, L, nrows, nb, dyn, rep, int((end != want).sum()))
+                assert np.array_equal(np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool), want != NO)
+    dfa.close()
+
+
 def test_lazy_walk_absorbing_accept(hip):
     """An unanchored literal set WITHOUT end-ids: every output node collapses into one absorbing accept state (re_strings
     semantics, ac.c:293-296): the kernel variant that tests for absorbing states, with and without the wave retire."""
