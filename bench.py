@@ -185,7 +185,7 @@ def kernels_sha16():
     (tools/rocpd_summary.py stores it; a kernel edit makes bench.py drop `traffic` until tools/profile.sh is rerun)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("walk_kernels.h", "walk_packed.h", "launch.h"):
+    for f in ("walk_kernels.h", "walk_lazy.h", "launch.h"):
         with open(os.path.join(ROOT, "libfsm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -653,6 +653,107 @@ def main():
         dfa.close()
         return res
 
+    def run_lines(wl, kind):
+        """The front retest / rx actually drive (src/retest/main.c:1114, src/retest/reperf.c:772-784): short, packed lines.
+        Input i = the first len[i] bytes of row i of workload `wl` (so a pattern row keeps its prefix and stays alive), packed
+        back to back; `short`: 1e8 lines of 8..64 bytes, `ragged`: 2e7 lines of 0..1024 bytes -- both >= 3.6 GB walked per
+        launch.  Timed in four metadata forms; the line's `value` is the u64-offsets + u32-end-state form and its roofline
+        counts every byte that form moves: sum(len) + 8 B of offsets + 4 B of result per line."""
+        lo, hi, n_l = (8, 64, 100_000_000) if kind == "short" else (0, 1024, 20_000_000)
+        n_l = min(n_l, n)
+        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
+        dfa = hip.HipDfa(flat, a.layout)
+        rows = buf_all[:n_l]
+        generate(hip, wl, rows.data_ptr(), n_l, L, 0)
+        g = torch.Generator(device="cuda").manual_seed(SEED & 0x7FFFFFFF)
+        lens = torch.randint(lo, hi + 1, (n_l,), device="cuda", dtype=torch.int32, generator=g)
+        off = torch.zeros(n_l + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(lens, 0, dtype=torch.int64, out=off[1:])
+        total = int(off[-1].item())
+        packed = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+        hip.gen_pack_rows_device(rows.data_ptr(), L, lens.data_ptr(), off.data_ptr(), n_l, hi, packed.data_ptr())
+        off32 = off.to(torch.int32) if total < (1 << 32) else None
+        end = end_all[:n_l]
+        end2 = torch.empty_like(end)
+        bm = torch.zeros((n_l + 63) // 64, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        forms = {}
+
+        def timed(name, call, meta_bytes, out_bytes):
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            ms = []
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                call()
+                ms.append(dfa.last_kernel_ms())
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / a.steps * 1e3
+            k_ms = float(np.mean(ms))
+            tot = total + n_l * (meta_bytes + out_bytes)
+            forms[name] = {"ms_per_step": round(wall, 4), "kernel_ms_avg": round(k_ms, 4), "walked_GBps": round(total / wall / 1e6, 2),
+                           "bytes_per_launch": tot, "metadata_bytes_per_line": meta_bytes, "result_bytes_per_line": out_bytes,
+                           "total_GBps": round(tot / k_ms / 1e6, 2), "frac_of_hbm_peak": round(tot / k_ms / 1e6 / HBM_PEAK_GBS, 4),
+                           "kernel": dfa.last_kernel_name()}
+            return wall, k_ms
+
+        wall, k_ms = timed("off64_end", lambda: dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n_l, end.data_ptr(), 0, stream=stream), 8, 4)
+        ok_forms = True
+        if off32 is not None:
+            timed("off32_end", lambda: dfa.exec_batch_offsets32_device(packed.data_ptr(), off32.data_ptr(), n_l, end2.data_ptr(), 0, stream=stream), 4, 4)
+            ok_forms = ok_forms and bool(torch.equal(end, end2))
+        end2.fill_(7)
+        # lengths only: the pre-pass reads the lengths once more (4 B) and writes 8 B per 64 lines; its time is inside ms_per_step, not kernel_ms
+        timed("len_end", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, end2.data_ptr(), 0, stream=stream), 8.125, 4)
+        ok_forms = ok_forms and bool(torch.equal(end, end2))
+        timed("len_bitmap", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, 0, bm.data_ptr(), stream=stream), 8.125, 0.125)
+        acc = int((end != -1).sum().item())
+        ok_forms = ok_forms and bool(np.array_equal(np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n_l].astype(bool), (end != -1).cpu().numpy()))
+        info = dfa.info()
+        f0 = forms["off64_end"]
+        res = {"workload": f"{wl}_{kind}", "value": f0["walked_GBps"], "unit": "GB/s of line bytes walked", "ms_per_step": f0["ms_per_step"],
+               "config": {"workload": f"{kind} lines on the {wl} table: input i = the first len[i] bytes of row i of the {wl} workload, len uniform in [{lo}, {hi}], "
+                                      f"{n_l} lines packed back to back ({total} B) resident in HBM; u64 offsets in, u32 end states out",
+                          "lines": n_l, "line_bytes": total, "mean_len": round(total / n_l, 2), "dfa_states": flat.nstates, "table_layout": info["layout_name"],
+                          "accepted_inputs": acc},
+               "roofline": {"bound": "hbm", "achieved": f0["total_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f0["frac_of_hbm_peak"],
+                            "kernel": f0["kernel"], "kernel_ms_avg": f0["kernel_ms_avg"], "algorithmic_bytes_per_launch": f0["bytes_per_launch"],
+                            "algorithmic_bytes": "sum(len) + 8 B offsets + 4 B end state per line", "traffic": None, "traffic_source": None},
+               "forms": forms}
+        pj = os.path.join(ROOT, "profiles", f"pmc_{wl}_{kind}.json")
+        if os.path.exists(pj):
+            try:
+                t = json.load(open(pj))
+                if int(t.get("n", 0)) == n_l and t.get("kernels_sha16") == kernels_sha16():
+                    res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this sub-result (recorded, not measured in this run)"
+            except Exception:
+                pass
+        # parity: a stratified sample of the lines against the oracle's walk of the same bytes
+        if not a.no_cpu_baseline and a.cpu_sample != 0:
+            from oracle import pyoracle
+            idx = sample_indices(n_l, 100_000)
+            tidx = torch.from_numpy(idx).cuda()
+            srows = rows[tidx][:, :hi].cpu().numpy() if hi <= 64 else rows[tidx].cpu().numpy()
+            slens = lens[tidx].cpu().numpy().astype(np.uint32)
+            o = pyoracle.Oracle(flat)
+            want = o.table_walk(srows, slens)
+            got = end[tidx].cpu().numpy().view(np.uint32)
+            # ... and the packed copy holds those bytes (spot check)
+            k0 = int(idx[len(idx) // 2])
+            b0, b1 = int(off[k0].item()), int(off[k0 + 1].item())
+            same = bool(np.array_equal(packed[b0:b1].cpu().numpy(), rows[k0, :b1 - b0].cpu().numpy()))
+            res["cpu_baseline"] = {"kind": "port", "value": round(float(slens.sum()) / 1e9 / o.last_seconds, 5), "unit": "GB/s", "cores": 1,
+                                   "sample": f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, {len(idx)} of the lines"}
+            res["parity_vs_cpu_sample"] = "bit-exact" if np.array_equal(got, want) and same and ok_forms else "MISMATCH"
+            res["parity_sample"] = f"{len(idx)} lines: seeded stratified sample + first/last 64; the other metadata forms reproduce all {n_l} end states"
+            if res["parity_vs_cpu_sample"] != "bit-exact":
+                res["value"] = None
+        dfa.close()
+        del packed, off, lens, end2, bm
+        return res
+
     main_res = run(a.workload)
     subs = []
     if world == 1 and a.subs == "auto" and a.n == 0 and not shrunk:
@@ -663,7 +764,14 @@ def main():
         for wl in ("c3", "c3t", "c2", "c5"):
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
+        # the short / packed front of retest and rx, at steady-state size, on the C2 and C3 tables
+        for wl in ("c2", "c3"):
+            plan.append((wl, "short", None))
+            plan.append((wl, "ragged", None))
         for wl, variant, n_wl in plan:
+            if variant in ("short", "ragged"):
+                subs.append(run_lines(wl, variant))
+                continue
             r = run(wl, variant, n_wl, with_cpu=(variant is None))
             r.pop("_buf", None)
             dg = r.pop("_digest", None)

@@ -171,10 +171,40 @@ int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, const uint64_t *d_off, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
 
+/* Compact metadata for packed inputs (round 4).  The generated matchers of the reference take a line as a (b, e)
+ * pointer pair (src/libfsm/print/c.c:569-619) and retest / reperf hand lines over one by one (src/retest/main.c:1114,
+ * src/retest/reperf.c:772-784): a batch of them is bytes packed back to back plus, per line, 8 bytes of u64 offsets
+ * (above), or
+ *   4 bytes: u32 offsets off32[n + 1], for batches below 4 GiB;
+ *   4 bytes: the lengths alone, len[n] -- input i is the len[i] bytes after input i - 1.  The offsets are never
+ *            materialised: a pre-pass leaves the byte offset of every 64th input (8 bytes per 64 inputs) and the walk
+ *            kernels add a wavefront prefix sum of the 64 lengths they read anyway.
+ * Results as for fsm_hip_exec_batch (end_out and/or the 1-bit-per-input accept_bitmap, either may be NULL).  The host
+ * forms check their metadata (off32 non-decreasing); the device forms follow the *_device contract above.  A device
+ * call of the lengths form uses a per-dfa scratch block that grows (a blocking allocation) the first time a batch
+ * needs more than its predecessors. */
+int fsm_hip_exec_batch_offsets32(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint32_t *off32, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+int fsm_hip_exec_batch_offsets32_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint32_t *d_off32, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+int fsm_hip_exec_batch_lengths(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+
 /* Time of the most recent *_device launch on this dfa, measured with HIP
  * events recorded on the launch stream around the walk kernel only.
  * Blocks until that launch finished.  Returns milliseconds, or <0 on error. */
 double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *dfa);
+
+/* The walk kernel of the most recent launch on this dfa by its own (demangled) name, as rocprofv3 lists it -- e.g.
+ * "fsmhip::walk_ldsdma<fsmhip::CombSelfPol, 128, 2, 768>"; two names separated by " | " when the choice between them was
+ * made on the device.  Valid until the next launch on this dfa. */
+const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *dfa);
 
 /* ------------------------------------------------------------------ */
 /* end-ids (host side, by end state)                                  */
@@ -459,6 +489,12 @@ int fsm_hip_gen_inputs_device(void *d_base, size_t stride, size_t n,
 	const unsigned char *alphabet, unsigned nalpha,
 	const unsigned char *plant, unsigned plant_len, unsigned plant_every,
 	void *hip_stream);
+
+/* Lines out of rows, for the benchmarks of the variable-length fronts: input i = the first d_len[i] (<= max_len <= stride)
+ * bytes of row i of d_rows, copied to d_out + d_off[i] (d_off[i] = sum of the lengths before i: the caller's prefix sum).
+ * Device pointers, asynchronous on hip_stream. */
+int fsm_hip_gen_pack_rows_device(const void *d_rows, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	size_t max_len, void *d_out, void *hip_stream);
 
 /* Host twin of the generator (same bytes). */
 void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size_t n,

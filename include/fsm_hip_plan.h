@@ -18,11 +18,12 @@ extern "C" {
 
 enum {
 	FSM_HIP_KNOB_INPUT_MODE    = 1,  /* 0 direct per-lane loads, 1 LDS-DMA tiles (both: uniform 16-byte-aligned rows only),
-	                                  * 2 generic (per-lane loads, any input), 3 ragged (coalesced + lane refill, any input),
-	                                  * 4 packed (packed offsets only: a lane owns a byte range and walks across input
-	                                  * boundaries; other fronts take their auto choice); -1 auto */
+	                                  * 2 generic (per-lane loads, any input), 3 ragged (coalesced + lane refill, any input);
+	                                  * -1 auto.  (4 was walk_packed -- a lane owning a byte range across input boundaries:
+	                                  * correct, slower than walk_generic everywhere, removed in round 4; the record is
+	                                  * profiles/r03s_packed_* and tools/packed_model.py) */
 	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
-	FSM_HIP_KNOB_ROWS          = 3,  /* the lazy walk of the sparse layout: inputs per lane, 2 (default) or 3; ignored elsewhere */
+	FSM_HIP_KNOB_ROWS          = 3,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
@@ -32,11 +33,12 @@ enum {
 	FSM_HIP_KNOB_PREFETCH      = 10, /* direct mode: 0 = no register double-buffer (<= 64 VGPRs)      */
 	FSM_HIP_KNOB_NT            = 11, /* LDS-DMA mode, 128-byte segments: nontemporal input loads       */
 	FSM_HIP_KNOB_NOSKIP        = 13, /* 1: self-loop layouts never skip a whole chunk (measurement aid: every byte pays its test) */
-	FSM_HIP_KNOB_PK_RMIN       = 16, /* packed mode: log2 of the smallest row (bytes a lane owns), 7..10, default 7   */
-	FSM_HIP_KNOB_PK_RMAX       = 17, /* packed mode: log2 of the largest row, 7..10; 0 (default) = what LDS allows     */
-	FSM_HIP_KNOB_PK_MEAN_MAX   = 18, /* auto: batches whose mean input length exceeds this go to the ragged kernel   */
-	FSM_HIP_KNOB_PK_DEBUG      = 19, /* measurement aid: bit mask of walk_packed parts switched off (results are WRONG):
-	                                  * 1 result stores, 4 input loads, 16 packed_finish (raw state codes stay)           */
+	FSM_HIP_KNOB_PK_RMIN       = 16, /* retired with walk_packed (accepted, ignored)                 */
+	FSM_HIP_KNOB_PK_RMAX       = 17, /* retired (accepted, ignored)                                   */
+	FSM_HIP_KNOB_PICK_MEAN     = 18, /* variable-length batches whose mean input length (bytes) is below this go to walk_generic,
+	                                  * the others to walk_ragged; default 96 (the host fronts know the mean, the device fronts
+	                                  * ask a small kernel: walk_aux.h offsets_pick) */
+	FSM_HIP_KNOB_PK_DEBUG      = 19, /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_SPARSE_FAST   = 20, /* sparse layout, fixed-stride rows: 3 (default where the automaton has a lazy form) states beyond the
 	                                  * LDS set are entered without their record, a Bloom filter in LDS says when to fetch it
 	                                  * (walk_lazy.h); 1 (default otherwise) the record is the walk state and a byte is three

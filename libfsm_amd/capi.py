@@ -28,8 +28,8 @@ KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_
 KNOB_NOSKIP = 13
 KNOB_RAGGED_ALIGN = 14
 KNOB_DMA_BUFS = 15
-KNOB_PK_RMIN, KNOB_PK_RMAX, KNOB_PK_MEAN_MAX, KNOB_PK_DEBUG, KNOB_SPARSE_FAST = 16, 17, 18, 19, 20
-IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED, IN_PACKED = 0, 1, 2, 3, 4
+KNOB_PICK_MEAN, KNOB_SPARSE_FAST, KNOB_LAZY_DYN = 18, 20, 21
+IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsm_hip.so")
@@ -420,6 +420,44 @@ class HipDfa:
             raise _oserr("fsm_hip_exec_batch_offsets")
         return end, bm
 
+    def exec_batch_offsets32(self, base: np.ndarray, off32: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
+        """fsm_hip_exec_batch_offsets32: u32 offsets (batches below 4 GiB)."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off32 = np.ascontiguousarray(off32, dtype=np.uint32)
+        n = len(off32) - 1
+        end = np.empty(n, dtype=np.uint32) if want_end else None
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets32(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(off32.ctypes.data),
+                                                  C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets32")
+        return end, bm
+
+    def exec_batch_lengths(self, base: np.ndarray, lens: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
+        """fsm_hip_exec_batch_lengths: inputs packed back to back, their lengths and nothing else."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        end = np.empty(n, dtype=np.uint32) if want_end else None
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_lengths(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(lens.ctypes.data if n else None),
+                                                C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_lengths")
+        return end, bm
+
+    def exec_batch_offsets32_device(self, d_base: int, d_off32: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets32_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_off32), C.c_size_t(n), C.c_void_p(d_end or None),
+                                                         C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets32_device")
+
+    def exec_batch_lengths_device(self, d_base: int, d_len: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_lengths_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_len), C.c_size_t(n), C.c_void_p(d_end or None),
+                                                       C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_lengths_device")
+
     def exec_strings(self, strings: Sequence[bytes]):
         off = np.zeros(len(strings) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(s) for s in strings])
@@ -438,6 +476,10 @@ class HipDfa:
         C.set_errno(0)
         if self._lib.fsm_hip_exec_batch_device(self._h, d_base, stride, d_len or None, n, d_end or None, d_bitmap or None, stream or None) != 0:
             raise _oserr("fsm_hip_exec_batch_device")
+
+    def last_kernel_name(self) -> str:
+        self._lib.fsm_hip_last_kernel_name.restype = C.c_char_p
+        return (self._lib.fsm_hip_last_kernel_name(C.c_void_p(self._h)) or b"").decode()
 
     def exec_batch_eager_device(self, d_base: int, stride: int, n: int, d_end: int, d_sets: int, d_len: int = 0, stream: int = 0):
         """d_sets: n * eager_words() u64 on the device."""
@@ -672,6 +714,44 @@ class HipNode:
             raise _oserr("fsm_hip_node_exec_batch")
         return end, bm
 
+    def exec_batch_offsets32(self, base: np.ndarray, off32: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
+        """fsm_hip_exec_batch_offsets32: u32 offsets (batches below 4 GiB)."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        off32 = np.ascontiguousarray(off32, dtype=np.uint32)
+        n = len(off32) - 1
+        end = np.empty(n, dtype=np.uint32) if want_end else None
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets32(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(off32.ctypes.data),
+                                                  C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets32")
+        return end, bm
+
+    def exec_batch_lengths(self, base: np.ndarray, lens: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
+        """fsm_hip_exec_batch_lengths: inputs packed back to back, their lengths and nothing else."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        end = np.empty(n, dtype=np.uint32) if want_end else None
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_lengths(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(lens.ctypes.data if n else None),
+                                                C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_lengths")
+        return end, bm
+
+    def exec_batch_offsets32_device(self, d_base: int, d_off32: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_offsets32_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_off32), C.c_size_t(n), C.c_void_p(d_end or None),
+                                                         C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_offsets32_device")
+
+    def exec_batch_lengths_device(self, d_base: int, d_len: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_lengths_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_len), C.c_size_t(n), C.c_void_p(d_end or None),
+                                                       C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_lengths_device")
+
     def exec_strings(self, strings: Sequence[bytes]):
         off = np.zeros(len(strings) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(s) for s in strings])
@@ -777,6 +857,15 @@ def gen_inputs_device(d_base: int, n: int, stride: int, first_index: int = 0, se
     if lib.fsm_hip_gen_inputs_device(d_base, stride, n, first_index, seed, _ptr(a), len(a) if a is not None else 0,
                                      _ptr(p), len(p) if p is not None else 0, plant_every, stream or None) != 0:
         raise _oserr("fsm_hip_gen_inputs_device")
+
+
+def gen_pack_rows_device(d_rows: int, stride: int, d_len: int, d_off: int, n: int, max_len: int, d_out: int, stream: int = 0):
+    """fsm_hip_gen_pack_rows_device: input i = the first len[i] bytes of row i, packed at d_out + off[i]."""
+    lib = load_library()
+    C.set_errno(0)
+    if lib.fsm_hip_gen_pack_rows_device(C.c_void_p(d_rows), C.c_size_t(stride), C.c_void_p(d_len), C.c_void_p(d_off), C.c_size_t(n),
+                                        C.c_size_t(max_len), C.c_void_p(d_out), C.c_void_p(stream or None)) != 0:
+        raise _oserr("fsm_hip_gen_pack_rows_device")
 
 
 def pack_affixes(items: Sequence[bytes]) -> np.ndarray:

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <cxxabi.h>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,7 +21,7 @@
 #include "plan.h"
 #include "launch.h"
 #include "gen_kernels.h"
-#include "walk_packed_aux.h"
+#include "walk_aux.h"
 
 using namespace fsmhip;
 
@@ -37,7 +39,6 @@ struct fsm_hip_dfa {
 	uint32_t *d_lazy_ctr = nullptr;                  /* ... and a ring of tile counters: a launch zeroes and uses the next one (launches on
 	                                                  * several streams may be in flight; LAZY_CTRS of them never are) */
 	unsigned lazy_ctr_next = 0;
-	int knob_lazy_rows = 2;                          /* inputs per lane of the lazy walk (2 | 3) */
 	int knob_lazy_dyn = 1;                           /* the lazy walk's wavefronts claim their tiles from a counter (0: static striding) */
 	/* device end-id delivery (built on first use) */
 	std::vector<uint32_t> fin_host;                 /* copy of the fin table uploaded to d_fin */
@@ -52,15 +53,18 @@ struct fsm_hip_dfa {
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	uint32_t *d_ew_off = nullptr, *d_ew_word = nullptr; /* wide eager sets (> 64 ids) */
 	uint64_t *d_ew_mask = nullptr;
-	/* device scratch of the packed front (parameters, first[], kbits, state codes): one grow-only block per dfa.  Calls are
-	 * enqueued under the dfa's lock; a call on another stream than the block's last user first waits for that user's
-	 * event, so the block is never shared by two launches in flight */
-	unsigned char *pk_scratch = nullptr;
-	size_t pk_scratch_bytes = 0;
-	hipStream_t pk_scratch_stream = nullptr;
-	hipEvent_t pk_scratch_ev = nullptr;
-	bool pk_scratch_busy = false;
-	std::vector<void *> pk_scratch_old;              /* outgrown blocks: freed with the dfa */
+	/* device-side choice between walk_generic and walk_ragged: a ring of flags, one per launch (launches on several streams
+	 * may be in flight; PICK_FLAGS of them never are), allocated with the dfa */
+	uint32_t *d_pick = nullptr;
+	unsigned pick_next = 0;
+	/* the lengths-only front: tile bases (u64 per 64 inputs) + block totals: one grow-only block per dfa.  Calls are enqueued
+	 * under the dfa's lock; every call waits for the block's last user's event, so the block is never shared by two
+	 * launches in flight (waiting on one's own stream costs nothing) */
+	unsigned char *tb_scratch = nullptr;
+	size_t tb_scratch_bytes = 0;
+	hipEvent_t tb_scratch_ev = nullptr;
+	bool tb_scratch_busy = false;
+	std::vector<void *> tb_scratch_old;              /* outgrown blocks: freed with the dfa */
 	unsigned char *arena = nullptr;                  /* device scratch of the host-pointer front */
 	size_t arena_bytes = 0;
 	unsigned char *stage = nullptr;                  /* pinned host staging for small calls */
@@ -73,6 +77,7 @@ struct fsm_hip_dfa {
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
+	std::string last_kernel;     /* demangled name(s) of the walk kernel(s) of the last launch */
 	/* tuning knobs (fsm_hip_dfa_tune) */
 	int knob_input_mode = -1;    /* -1 auto */
 	int knob_nb = 0;             /* 0 auto */
@@ -85,12 +90,9 @@ struct fsm_hip_dfa {
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
-	int knob_pk_rmin = 7;        /* packed front: smallest row, log2 bytes */
-	int knob_pk_rmax = 0;        /* ... largest row, log2 bytes (<= 10); 0 = what leaves room for a full workgroup */
 	int knob_sparse_fast = 1;    /* sparse layout: entry-as-state walk (0: the id-as-state chain loop, for A/B runs) */
 	bool sparse_fast_ok = true;  /* the record array sits inside one 4 GiB window (SparseFastPol::enter) */
-	int knob_pk_debug = 0;       /* measurement aid: parts of walk_packed switched off (results are wrong) */
-	int knob_pk_mean_max = 192;  /* ... longest mean input length (bytes) walk_packed takes; longer: walk_ragged */
+	int knob_pick_mean = 96;     /* variable-length batches whose mean input length is below this many bytes go to walk_generic */
 	unsigned flags = 0;
 };
 
@@ -108,7 +110,7 @@ static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
 	d->table_lds = GlobPol::lds_bytes((uint32_t)hot);
 }
 
-static const unsigned LAZY_CTRS = 64;
+static const unsigned LAZY_CTRS = 64, PICK_FLAGS = 64;
 
 static int hip_errno(hipError_t e)
 {
@@ -423,6 +425,8 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		a.btab = d->d_btab;
 		a.early = (flags & FSM_HIP_NO_EARLY_RETIRE) ? 0u : 1u;
 	}
+	HIP_TRY(hipMalloc((void **)&d->d_pick, PICK_FLAGS * sizeof(uint32_t)));
+	HIP_TRY(hipEventCreateWithFlags(&d->tb_scratch_ev, hipEventDisableTiming));
 	HIP_TRY(hipEventCreate(&d->ev0));
 	HIP_TRY(hipEventCreate(&d->ev1));
 	HIP_TRY(hipStreamCreateWithFlags(&d->hs, hipStreamNonBlocking));
@@ -452,9 +456,10 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_ew_off) (void)hipFree(d->d_ew_off);
 	if (d->d_ew_word) (void)hipFree(d->d_ew_word);
 	if (d->d_ew_mask) (void)hipFree(d->d_ew_mask);
-	if (d->pk_scratch) (void)hipFree(d->pk_scratch);
-	for (void *q : d->pk_scratch_old) (void)hipFree(q);
-	if (d->pk_scratch_ev) (void)hipEventDestroy(d->pk_scratch_ev);
+	if (d->d_pick) (void)hipFree(d->d_pick);
+	if (d->tb_scratch) (void)hipFree(d->tb_scratch);
+	for (void *q : d->tb_scratch_old) (void)hipFree(q);
+	if (d->tb_scratch_ev) (void)hipEventDestroy(d->tb_scratch_ev);
 	if (d->arena) (void)hipFree(d->arena);
 	if (d->stage) (void)hipHostFree(d->stage);
 	if (d->hs) (void)hipStreamDestroy(d->hs);
@@ -517,12 +522,12 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	c.sparse_fast = d->sparse_fast_ok ? d->knob_sparse_fast : (d->knob_sparse_fast == 3 ? 3 : 0);
 	c.lazy_abs = 0;
 	if (mode == IN_DIRECT && layout == FSM_HIP_LAYOUT_SPARSE && !eager && !resumed && d->d_lazy != nullptr && d->knob_sparse_fast == 3 &&
-	    ((stride / 16u) % 4u == 0 || ((stride / 16u) % 2u == 0 && (d->knob_lazy_rows == 3 || d->knob_nb == 2)))) {
+	    (stride / 16u) % 4u == 0) {
 		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
 		c.mode = IN_LAZY;
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
-		c.lazy_rows = d->knob_lazy_rows == 3 && (stride / 16u) % 2u == 0 ? 3 : 2;
-		c.nb = c.lazy_rows == 3 || d->knob_nb == 2 ? 2 : 4;
+		c.lazy_eva = d->plan.lazy_img[15] != 0;
+		c.nb = 4;
 		c.waves = 16;
 		c.lds = d->plan.lazy_lds_bytes;
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
@@ -574,33 +579,6 @@ struct BatchHint {
 	bool short_mean = false;   /* the inputs average < 96 bytes */
 };
 
-/* the packed front's walk_packed: rows as long as the per-wave LDS bitmask may be with a full 16-wave workgroup behind
- * one table copy */
-static bool packed_cfg(const fsm_hip_dfa *d, LaunchCfg &c, uint32_t &rmax)
-{
-	const uint32_t layout = d->plan.layout;
-	const bool c16 = !(layout == FSM_HIP_LAYOUT_GLOBAL || layout == FSM_HIP_LAYOUT_SPARSE);
-	const int wmax = 16;   /* launch.h packed_threads */
-	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
-	const uint32_t room = d->lds_limit > d->table_lds ? d->lds_limit - d->table_lds : 0u;
-	rmax = 9;
-	if (d->knob_pk_rmax >= 7 && d->knob_pk_rmax <= (int)FSMHIP_PK_RMAX) rmax = (uint32_t)d->knob_pk_rmax;
-	else while (rmax > 7u && (uint32_t)waves * packed_wave_lds(rmax, c16) > room) rmax--;
-	if ((uint32_t)d->knob_pk_rmin > rmax) rmax = (uint32_t)d->knob_pk_rmin <= FSMHIP_PK_RMAX ? (uint32_t)d->knob_pk_rmin : FSMHIP_PK_RMAX;
-	while (waves > 1 && (uint32_t)waves * packed_wave_lds(rmax, c16) > room) waves--;
-	if ((uint32_t)waves * packed_wave_lds(rmax, c16) > room) return false;
-	memset(&c, 0, sizeof c);
-	c.mode = IN_PACKED;
-	c.waves = waves;
-	c.lds = d->table_lds + (uint32_t)waves * packed_wave_lds(rmax, c16);
-	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));
-	if (bpc * waves > 32) bpc = 32 / waves;
-	if (bpc < 1) bpc = 1;
-	if (d->knob_blocks_per_cu > 0) bpc = d->knob_blocks_per_cu;
-	c.blocks_per_cu = bpc;
-	return true;
-}
-
 static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	const Plan &p = d->plan;
@@ -617,6 +595,22 @@ static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg
 }
 
 /* FSM_HIP_DEBUG=2: synchronise after every stage of a launch and say which one it was (a GPU fault aborts the process) */
+/* the launched kernel's own name, as the profiler shows it */
+static std::string kernel_name(const void *kfn, hipStream_t s)
+{
+	if (kfn == nullptr) return "?";
+	const char *m = hipKernelNameRefByPtr(kfn, s);
+	if (m == nullptr) return "?";
+	int st = 0;
+	char *dm = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+	std::string r = st == 0 && dm != nullptr ? dm : m;
+	free(dm);
+	const size_t p = r.find("(fsmhip::WalkArgs");
+	if (p != std::string::npos) r.resize(p);
+	if (r.compare(0, 5, "void ") == 0) r.erase(0, 5);
+	return r;
+}
+
 static void debug_stage(hipStream_t s, const char *what)
 {
 	static const int lvl = getenv("FSM_HIP_DEBUG") ? atoi(getenv("FSM_HIP_DEBUG")) : 0;
@@ -632,149 +626,57 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 {
 	if (a.n == 0) return 0;
 	const int eager = a.eager_out == nullptr ? 0 : a.eager_words > 1 ? 2 : 1;
-	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : a.off == nullptr ? (uint64_t)a.n * a.stride : 0;
+	const bool varlen = a.off != nullptr || a.off32 != nullptr || a.len != nullptr;
+	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : !varlen ? (uint64_t)a.n * a.stride : 0;
 	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr);
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 64u * c.lazy_rows - 1u) / (64u * c.lazy_rows) + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
+	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
 	if (d->knob_noskip > 0) a.early |= 4u;
 
-	/* Packed offsets (the retest / rx front).  Short inputs (mean < 96 bytes) walk fastest one per lane with per-lane
+	/* Variable-length inputs (the retest / rx front).  Short ones (mean < 96 bytes) walk fastest one per lane with per-lane
 	 * loads (walk_generic), long ones in 128-byte segments with lane refill (walk_ragged).  A host-pointer front knows the
-	 * mean; a device-pointer front cannot know off[n] without a synchronising copy, so BOTH kernels are launched and
-	 * a one-thread kernel decides on the device which of them returns at once (offsets_pick, walk_packed_aux.h).
-	 * walk_packed (a lane owns a byte range and walks across input boundaries) is opt-in, FSM_HIP_KNOB_INPUT_MODE = 4: it
-	 * measured slower than walk_generic at every length (profiles/r03s_*). */
-	LaunchCfg pc;
-	uint32_t pk_rmax = 0;
-	const bool packed = a.off != nullptr && eager == 0 && a.state_io == nullptr && a.n < 0xFFFFF000ull &&
-		d->knob_input_mode == IN_PACKED && packed_cfg(d, pc, pk_rmax);
-	const bool both = packed;   /* packed_first may refuse a batch (rows that first[] cannot hold): the ragged / generic kernel stands by */
-	const bool pick = !packed && a.off != nullptr && known_bytes == 0 && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
-	uint32_t *scratch = nullptr;
+	 * mean; a device-pointer front cannot know it without a synchronising copy, so BOTH kernels are launched and a small
+	 * kernel decides on the device which of them returns at once (offsets_pick, walk_aux.h). */
+	const bool pick = varlen && known_bytes == 0 && !hint.short_mean && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
-	DfaLock lk(md->mu);   /* the timing events and the packed front's scratch block are per dfa */
+	DfaLock lk(md->mu);   /* the timing events, the flag ring and the tile-base block are per dfa */
 	hipError_t e = hipSuccess;
-	if (packed) {
-		/* scratch (the dfa's own block, see pk_scratch): parameters, first[] (one entry per
-		 * row: rows are at least 128 bytes), the bitmap of empty inputs, and the raw state codes when the caller wants
-		 * neither end states nor ids (they are mapped in place otherwise) */
-		uint64_t nvmax = 2u * a.n < 4096u ? 4096u : 2u * a.n > ((uint64_t)1 << 23) ? ((uint64_t)1 << 23) : 2u * a.n;
-		if (known_bytes != 0 && (known_bytes >> 7) + 2u < nvmax) nvmax = (known_bytes >> 7) + 2u;
-		const size_t head = ((size_t)FSMHIP_PK_FIRST_OFF + nvmax + 2u + 3u) & ~(size_t)3u, kwords = (a.n >> 6) + 1u;
-		const bool own_codes = a.end_out == nullptr && a.out2 == nullptr;
-		const size_t want = (head + 2u * kwords + (own_codes ? a.n : 0)) * sizeof(uint32_t);
-		if (md->pk_scratch_ev == nullptr) e = hipEventCreateWithFlags(&md->pk_scratch_ev, hipEventDisableTiming);
-		if (e == hipSuccess && md->pk_scratch_busy && md->pk_scratch_stream != s) e = hipStreamWaitEvent(s, md->pk_scratch_ev, 0);
-		if (e == hipSuccess && want > md->pk_scratch_bytes) {
-			if (md->pk_scratch) md->pk_scratch_old.push_back(md->pk_scratch);   /* launches in flight may still use it */
-			md->pk_scratch = nullptr;
-			md->pk_scratch_bytes = 0;
-			size_t cap = (size_t)1 << 16;
-			while (cap < want) cap *= 2;
-			e = hipMalloc((void **)&md->pk_scratch, cap);
-			if (e == hipSuccess) md->pk_scratch_bytes = cap;
-		}
-		scratch = reinterpret_cast<uint32_t *>(md->pk_scratch);
-		if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, sizeof(PackedParams), s);
-		a.pk = scratch;
-		a.pk_kbits = reinterpret_cast<uint64_t *>(scratch + head);
-		a.pk_codes = a.end_out != nullptr ? a.end_out : a.out2 != nullptr ? a.out2 : scratch + head + 2u * kwords;
-		a.pk_rmin_bytes = 1u << (d->knob_pk_rmin < (int)pk_rmax ? d->knob_pk_rmin : (int)pk_rmax);
-		a.pk_rmax = pk_rmax;
-		a.pk_nvmax = (uint32_t)nvmax;
-		a.pk_mean_max = d->knob_input_mode < 0 ? (uint32_t)d->knob_pk_mean_max : 0xFFFFFFFFu;
-		a.pk_lanes = (uint64_t)d->ncu * pc.blocks_per_cu * pc.waves * 64u;
-		a.pk_debug = (uint32_t)d->knob_pk_debug;
-	}
+	std::string picked;
 	/* the ragged kernel sets bitmap bits one input at a time */
-	if (e == hipSuccess && (!packed || both) && c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
+	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
 	if (e == hipSuccess && c.mode == IN_LAZY && d->knob_lazy_dyn && d->d_lazy_ctr != nullptr) {
 		a.tile_ctr = d->d_lazy_ctr + (md->lazy_ctr_next++ % LAZY_CTRS);
 		e = hipMemsetAsync(a.tile_ctr, 0, sizeof(uint32_t), s);
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
-	if (e == hipSuccess && packed) {
-		uint64_t fb = (a.n + 1u + 255u) / 256u;
-		if (fb > (uint64_t)d->ncu * 8u) fb = (uint64_t)d->ncu * 8u;
-		if (getenv("FSM_HIP_DEBUG") && atoi(getenv("FSM_HIP_DEBUG")) >= 2) (void)hipMemsetAsync(a.pk_codes, 0xEE, a.n * sizeof(uint32_t), s);
-		debug_stage(s, "packed scratch");
-		hipLaunchKernelGGL(packed_first, dim3((unsigned)fb), dim3(256), 0, s, a);
-		e = hipGetLastError();
-		debug_stage(s, "packed_first");
-		if (e == hipSuccess) {
-			/* rows are at least 128 bytes: with the batch's size known, no more workgroups than it has tiles */
-			uint64_t pb = (uint64_t)d->ncu * pc.blocks_per_cu;
-			if (known_bytes != 0) {
-				const uint64_t t = ((known_bytes >> 7) + 2u + 63u) / 64u, b = (t + pc.waves - 1) / pc.waves;
-				if (b < pb) pb = b;
-			}
-			e = launch_layout(d, 0, pc, a, dim3((unsigned)pb), dim3((unsigned)pc.waves * 64u), s);
-			debug_stage(s, "walk_packed");
-			if (getenv("FSM_HIP_DEBUG") && atoi(getenv("FSM_HIP_DEBUG")) >= 2) {   /* which inputs got no state code? */
-				std::vector<uint32_t> h(a.n);
-				PackedParams pr;
-				(void)hipMemcpy(h.data(), a.pk_codes, a.n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-				(void)hipMemcpy(&pr, scratch, sizeof pr, hipMemcpyDeviceToHost);
-				size_t bad = 0;
-				size_t wild = 0;
-				for (size_t i = 0; i < a.n; i++) {
-					if (h[i] == 0xEEEEEEEEu) { if (bad++ < 8) fprintf(stderr, " [unwritten %zu]", i); }
-					else if (h[i] / a.fin_div >= d->fin_host.size()) { if (wild++ < 8) fprintf(stderr, " [code %zu = %#x]", i, h[i]); }
-				}
-				fprintf(stderr, " wild=%zu", wild);
-				fprintf(stderr, " packed: n=%zu unwritten=%zu rshift=%u nrows=%llu use=%u has_empty=%u nvmax=%u grid=%llu x %d\n", (size_t)a.n, bad,
-				        pr.rshift, (unsigned long long)pr.nrows, pr.use, pr.has_empty, a.pk_nvmax, (unsigned long long)pb, pc.waves);
-			}
-		}
-	}
 	if (e == hipSuccess && pick) {
-		/* the device-side choice: the same block of scratch, event-guarded like the packed front's */
-		if (md->pk_scratch_ev == nullptr) e = hipEventCreateWithFlags(&md->pk_scratch_ev, hipEventDisableTiming);
-		if (e == hipSuccess && md->pk_scratch_busy && md->pk_scratch_stream != s) e = hipStreamWaitEvent(s, md->pk_scratch_ev, 0);
-		if (e == hipSuccess && md->pk_scratch == nullptr) {
-			e = hipMalloc((void **)&md->pk_scratch, (size_t)1 << 16);
-			if (e == hipSuccess) md->pk_scratch_bytes = (size_t)1 << 16;
-		}
-		if (e == hipSuccess) {
-			a.pk = reinterpret_cast<uint32_t *>(md->pk_scratch);
-			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(1), 0, s, a, 96u);
-			e = hipGetLastError();
-		}
+		a.pick_flag = md->d_pick + (md->pick_next++ % PICK_FLAGS);
+		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)d->knob_pick_mean);
+		e = hipGetLastError();
 		if (e == hipSuccess) {
 			/* short: walk_generic, which returns at once unless the flag says short (1) */
 			const LaunchCfg g = pick_cfg(d, false, a.stride, eager, true, false);
 			const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
 			WalkArgs ag = a;
-			ag.skip_flag = &reinterpret_cast<const PackedParams *>(md->pk_scratch)->use;
+			ag.skip_flag = a.pick_flag;
 			ag.skip_when = 0u;
 			e = launch_layout(d, eager, g, ag, dim3((unsigned)(gb0 < gcap ? gb0 : gcap)), dim3((unsigned)g.waves * 64u), s);
-			a.skip_flag = ag.skip_flag;
+			picked = kernel_name(g.kfn, s) + " (mean length < " + std::to_string(d->knob_pick_mean) + " B, decided on the device) | ";
+			a.skip_flag = a.pick_flag;
 			a.skip_when = 1u;   /* long: walk_ragged, below */
 		}
 	}
-	if (e == hipSuccess && (!packed || both)) {
-		if (both) { a.skip_flag = &reinterpret_cast<const PackedParams *>(scratch)->use; a.skip_when = 1u; }
+	if (e == hipSuccess) {
+		c.kfn = nullptr;
 		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
-		debug_stage(s, "walk (fixed stride / ragged / generic)");
-	}
-	if (e == hipSuccess && packed && !(d->knob_pk_debug & 16)) {   /* (16: raw state codes left in place) */
-		uint64_t fb = (ntiles + 3u) / 4u;
-		if (fb > (uint64_t)d->ncu * 8u) fb = (uint64_t)d->ncu * 8u;
-		hipLaunchKernelGGL(packed_finish, dim3((unsigned)fb), dim3(256), 0, s, a);
-		e = hipGetLastError();
-		debug_stage(s, "packed_finish");
+		md->last_kernel = picked + kernel_name(c.kfn, s);
+		debug_stage(s, "walk");
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
-	if ((packed || pick) && md->pk_scratch_ev != nullptr) {
-		const hipError_t e2 = hipEventRecord(md->pk_scratch_ev, s);
-		md->pk_scratch_stream = s;
-		md->pk_scratch_busy = true;
-		if (e == hipSuccess) e = e2;
-	}
 	if (e != hipSuccess) {
 		if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: launch -> %s\n", hipGetErrorString(e));
 		errno = hip_errno(e);
@@ -782,6 +684,47 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	}
 	md->timed = true;
 	return 0;
+}
+
+/* The lengths-only front: byte offset of every 64th input of a batch packed back to back (walk_aux.h tile_bases_*), into the
+ * dfa's grow-only block; the walk that follows on the same stream reads it.  The block's previous user (any stream) is
+ * waited for first; `tbase` = the array the walk kernels take (T + 1 entries, the last one the batch's size). */
+static int tile_bases(fsm_hip_dfa *d, const uint32_t *d_len, size_t n, hipStream_t s, const uint64_t **tbase)
+{
+	DfaLock lk(d->mu);
+	const uint64_t T1 = (n + 63u) / 64u + 1u, nb = (T1 + 1023u) / 1024u;
+	const size_t want = (size_t)(T1 + nb) * sizeof(uint64_t);
+	hipError_t e = hipSuccess;
+	if (d->tb_scratch_busy) e = hipStreamWaitEvent(s, d->tb_scratch_ev, 0);
+	if (e == hipSuccess && want > d->tb_scratch_bytes) {
+		/* (grows by doubling: a handful of blocking hipMalloc calls over a dfa's life; launches in flight may still use the old block) */
+		if (d->tb_scratch) d->tb_scratch_old.push_back(d->tb_scratch);
+		d->tb_scratch = nullptr;
+		d->tb_scratch_bytes = 0;
+		size_t cap = (size_t)1 << 16;
+		while (cap < want) cap *= 2;
+		e = hipMalloc((void **)&d->tb_scratch, cap);
+		if (e == hipSuccess) d->tb_scratch_bytes = cap;
+	}
+	if (e == hipSuccess) {
+		uint64_t *tb = reinterpret_cast<uint64_t *>(d->tb_scratch), *bt = tb + T1;
+		hipLaunchKernelGGL(tile_bases_pass1, dim3((unsigned)nb), dim3(1024), 0, s, d_len, (uint64_t)n, T1, tb, bt);
+		hipLaunchKernelGGL(tile_bases_pass2, dim3(1), dim3(1024), 0, s, bt, nb);
+		uint64_t g3 = (T1 + 255u) / 256u;
+		if (g3 > (uint64_t)d->ncu * 8u) g3 = (uint64_t)d->ncu * 8u;
+		hipLaunchKernelGGL(tile_bases_pass3, dim3((unsigned)g3), dim3(256), 0, s, tb, T1, (const uint64_t *)bt);
+		e = hipGetLastError();
+		*tbase = tb;
+	}
+	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	return 0;
+}
+
+/* ... and once the walk is enqueued: the block is busy until this point of the stream */
+static void tile_bases_done(fsm_hip_dfa *d, hipStream_t s)
+{
+	DfaLock lk(d->mu);
+	if (hipEventRecord(d->tb_scratch_ev, s) == hipSuccess) d->tb_scratch_busy = true;
 }
 
 static int exec_stride_device(const struct fsm_hip_dfa *d,
@@ -811,22 +754,41 @@ extern "C" int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *d,
 	return exec_stride_device(d, d_base, stride, d_len, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
 }
 
-static int exec_offsets_device(const struct fsm_hip_dfa *d,
-	const void *d_base, const uint64_t *d_off, size_t n,
+/* inputs packed back to back, located by u64 offsets, u32 offsets, or their lengths alone (exactly one of the three) */
+static int exec_packed_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, const uint32_t *d_off32, const uint32_t *d_len, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
 {
-	if (d == nullptr || (n != 0 && d_off == nullptr)) { errno = EINVAL; return -1; }
+	if (d == nullptr || (n != 0 && d_off == nullptr && d_off32 == nullptr && d_len == nullptr)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = 0;
 	a.len = nullptr;
 	a.off = d_off;
+	a.off32 = d_off == nullptr ? d_off32 : nullptr;
 	a.n = n;
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
-	return launch_walk(d, a, false, static_cast<hipStream_t>(hip_stream), hint);
+	const bool lenonly = d_off == nullptr && d_off32 == nullptr;
+	if (lenonly) {
+		a.len = d_len;
+		if (tile_bases(const_cast<fsm_hip_dfa *>(d), d_len, n, s, &a.tbase) != 0) return -1;
+	}
+	const int r = launch_walk(d, a, false, s, hint);
+	if (lenonly) tile_bases_done(const_cast<fsm_hip_dfa *>(d), s);
+	return r;
+}
+
+static int exec_offsets_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
+{
+	if (n != 0 && d_off == nullptr) { errno = EINVAL; return -1; }
+	return exec_packed_device(d, d_base, d_off, nullptr, nullptr, n, d_end_out, d_accept_bitmap, hip_stream, hint);
 }
 
 extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
@@ -834,6 +796,29 @@ extern "C" int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *d,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
 {
 	return exec_offsets_device(d, d_base, d_off, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+extern "C" int fsm_hip_exec_batch_offsets32_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint32_t *d_off32, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	if (n != 0 && d_off32 == nullptr) { errno = EINVAL; return -1; }
+	return exec_packed_device(d, d_base, nullptr, d_off32, nullptr, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+extern "C" int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *d,
+	const void *d_base, const uint32_t *d_len, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	if (n != 0 && d_len == nullptr) { errno = EINVAL; return -1; }
+	return exec_packed_device(d, d_base, nullptr, nullptr, d_len, n, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+}
+
+extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
+{
+	if (d == nullptr) return "";
+	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
+	return d->last_kernel.c_str();
 }
 
 extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
@@ -952,7 +937,7 @@ struct HostCall {
 static int exec_host(const struct fsm_hip_dfa *d,
 	const unsigned char *base, size_t in_bytes, size_t stride,
 	const uint32_t *len, const uint64_t *off, size_t n,
-	uint32_t *end_out, uint64_t *accept_bitmap)
+	uint32_t *end_out, uint64_t *accept_bitmap, const uint32_t *off32 = nullptr, bool packed_len = false)
 {
 	if (d == nullptr) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
@@ -963,21 +948,22 @@ static int exec_host(const struct fsm_hip_dfa *d,
 	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
 	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
 	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_off32 = off32 ? hc.add(HostCall::IN, off32, nullptr, (n + 1) * sizeof(uint32_t)) : -1;
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	const int p_bm = hc.add(HostCall::OUT, nullptr, accept_bitmap, ((n + 63) / 64) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
 	BatchHint hint;
 	hint.bytes = in_bytes;
-	if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
+	if (off != nullptr || off32 != nullptr || packed_len) {
+		hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
+	} else if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
 		uint64_t sum = 0;
 		for (size_t i = 0; i < n; i++) sum += len[i];
-		hint.short_mean = sum / n < 96u;
-	} else if (off != nullptr) {
-		hint.short_mean = in_bytes / n < 96u;
+		hint.short_mean = sum / n < (uint64_t)d->knob_pick_mean;
 	}
-	if (off) {
-		if (exec_offsets_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), n,
-		                        hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs, hint) != 0) return -1;
+	if (off || off32 || packed_len) {
+		if (exec_packed_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), hc.dev<uint32_t>(p_off32), packed_len ? hc.dev<uint32_t>(p_len) : nullptr, n,
+		                       hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs, hint) != 0) return -1;
 	} else {
 		if (exec_stride_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), n,
 		                       hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), hc.d->hs, hint) != 0) return -1;
@@ -1006,6 +992,29 @@ extern "C" int fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *d,
 	const size_t total = n ? (size_t)off[n] : 0;
 	if (total != 0 && base == nullptr) { errno = EINVAL; return -1; }
 	return exec_host(d, base, total, 0, nullptr, off, n, end_out, accept_bitmap);
+}
+
+extern "C" int fsm_hip_exec_batch_offsets32(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint32_t *off32, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (n != 0 && off32 == nullptr) { errno = EINVAL; return -1; }
+	for (size_t i = 0; i < n; i++)
+		if (off32[i + 1] < off32[i]) { errno = EINVAL; return -1; }
+	const size_t total = n ? (size_t)off32[n] : 0;
+	if (total != 0 && base == nullptr) { errno = EINVAL; return -1; }
+	return exec_host(d, base, total, 0, nullptr, nullptr, n, end_out, accept_bitmap, off32);
+}
+
+extern "C" int fsm_hip_exec_batch_lengths(const struct fsm_hip_dfa *d,
+	const unsigned char *base, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (n != 0 && len == nullptr) { errno = EINVAL; return -1; }
+	size_t total = 0;
+	for (size_t i = 0; i < n; i++) total += len[i];
+	if (total != 0 && base == nullptr) { errno = EINVAL; return -1; }
+	return exec_host(d, base, total, 0, len, nullptr, n, end_out, accept_bitmap, nullptr, true);
 }
 
 /* ------------------------------------------------------------------ */
@@ -1044,7 +1053,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
-	case FSM_HIP_KNOB_ROWS: d->knob_lazy_rows = value == 3 ? 3 : 2; break;   /* (the other kernels: one input per lane; two never helped, profiles/r01_sweep2*) */
+	case FSM_HIP_KNOB_ROWS: break;   /* retired: two inputs per lane never helped the table walks (profiles/r01_sweep2*); the lazy walk always has two */
 	case FSM_HIP_KNOB_LAZY_DYN: d->knob_lazy_dyn = value != 0; break;
 	case FSM_HIP_KNOB_MASK: break;   /* retired: exec-masking absorbing lanes cost more than it saved */
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
@@ -1059,11 +1068,11 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
 	case FSM_HIP_KNOB_RAGGED_ALIGN: break;   /* retired: segments start at the input's own first byte now */
-	case FSM_HIP_KNOB_PK_RMIN: if (value < 7 || value > (int)FSMHIP_PK_RMAX) { errno = EINVAL; return -1; } d->knob_pk_rmin = value; break;
-	case FSM_HIP_KNOB_PK_RMAX: if (value != 0 && (value < 7 || value > (int)FSMHIP_PK_RMAX)) { errno = EINVAL; return -1; } d->knob_pk_rmax = value; break;
-	case FSM_HIP_KNOB_PK_DEBUG: d->knob_pk_debug = value; break;
+	case FSM_HIP_KNOB_PK_RMIN:
+	case FSM_HIP_KNOB_PK_RMAX:
+	case FSM_HIP_KNOB_PK_DEBUG: break;   /* retired with walk_packed (round 4): accepted, ignored */
 	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value < 0 || value > 3 ? (d->d_lazy ? 3 : 1) : value; break;
-	case FSM_HIP_KNOB_PK_MEAN_MAX: if (value < 0) { errno = EINVAL; return -1; } d->knob_pk_mean_max = value; break;
+	case FSM_HIP_KNOB_PICK_MEAN: if (value < 0) { errno = EINVAL; return -1; } d->knob_pick_mean = value; break;
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
 	}
@@ -1204,6 +1213,22 @@ extern "C" void fsm_hip_gen_inputs_host(unsigned char *base, size_t stride, size
 		if (g.plant_len != 0 && gi % g.plant_every == 0)
 			memcpy(p + plant_offset(g, gi), g.plant, g.plant_len);
 	}
+}
+
+extern "C" int fsm_hip_gen_pack_rows_device(const void *d_rows, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	size_t max_len, void *d_out, void *hip_stream)
+{
+	if (n == 0) return 0;
+	if (d_rows == nullptr || d_len == nullptr || d_off == nullptr || d_out == nullptr || max_len > stride) { errno = EINVAL; return -1; }
+	const uint64_t wpr = (max_len + 7u) / 8u;
+	if (wpr == 0) return 0;
+	uint64_t blocks = ((uint64_t)n * wpr + 255u) / 256u;
+	if (blocks > 256u * 64u) blocks = 256u * 64u;
+	hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+	                   static_cast<const unsigned char *>(d_rows), (uint64_t)stride, d_len, d_off, (uint64_t)n, wpr, static_cast<unsigned char *>(d_out));
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	return 0;
 }
 
 /* ---- affix generator (see walk_kernels.h) ---- */

@@ -121,6 +121,23 @@ gen_affix_kernel(const GenArgs g, const AffixArgs x)
 	}
 }
 
+/* Lines out of rows (the retest / rx front of the benchmarks): input i = the first len[i] bytes of row i, packed back to
+ * back at out + off[i].  One thread per 8 bytes of a line; wpr = ceil(longest line / 8). */
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(const unsigned char *rows, uint64_t stride, const uint32_t *len, const uint64_t *off, uint64_t n, uint64_t wpr, unsigned char *out)
+{
+	const uint64_t total = n * wpr;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t row = t / wpr, at = (t - row * wpr) * 8u;
+		const uint64_t l = len[row];
+		if (at >= l) continue;
+		const unsigned char *src = rows + row * stride + at;
+		unsigned char *dst = out + off[row] + at;
+		const uint64_t k = l - at < 8u ? l - at : 8u;
+		for (uint64_t j = 0; j < k; j++) dst[j] = src[j];
+	}
+}
+
 /* Read-only streaming probe: the HBM read rate a trivially coalesced kernel reaches on this
  * device (16 B per lane, grid-stride, optionally nontemporal), reported by bench.py next to the
  * spec peak.  (The LDS-DMA probe below reads faster: it is the third candidate of the probe.) */

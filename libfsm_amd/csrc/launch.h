@@ -10,12 +10,11 @@
 #define FSM_HIP_LAUNCH_H
 
 #include "walk_kernels.h"
-#include "walk_packed.h"
 
 namespace fsmhip {
 
 struct LaunchCfg {
-	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED | IN_PACKED | IN_LAZY */
+	int mode;            /* IN_DIRECT | IN_LDSDMA | IN_GENERIC | IN_RAGGED | IN_LAZY */
 	int nb;              /* direct: 16-byte chunks in flight per lane (4 or 8) */
 	int waves, blocks_per_cu;
 	int seg;             /* LDS-DMA: 64 or 128 */
@@ -23,8 +22,9 @@ struct LaunchCfg {
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
-	int lazy_rows;       /* IN_LAZY: inputs per lane, 2 or 3 (3: two chunks per row in flight) */
+	int lazy_eva;        /* IN_LAZY: some LDS record answers with a state from F up (plan.cpp img[15]) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
+	mutable const void *kfn;   /* out: the kernel launch_fn launched (its name goes into fsm_hip_last_kernel_name) */
 };
 
 /* which policy of a family */
@@ -47,6 +47,7 @@ static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
+	c.kfn = (const void *)k;
 	return hipGetLastError();
 }
 
@@ -55,16 +56,12 @@ static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs
 template <class Pol> struct ldsdma_threads { static constexpr int value = 1024; };
 template <> struct ldsdma_threads<CombSelfPol> { static constexpr int value = 768; };
 
-/* thread cap of walk_packed: every instantiation stays under the 128 registers of a 16-wave workgroup */
-template <class Pol> struct packed_threads { static constexpr int value = 1024; };
-
 /* plain walk: every input path */
 template <class Pol>
 static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
 	walk_fn k = nullptr;
 	switch (c.mode) {
-	case IN_PACKED:  k = walk_packed<Pol, packed_threads<Pol>::value>; break;
 	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
 	case IN_GENERIC: k = walk_generic<Pol>; break;
 	case IN_LDSDMA:

@@ -43,6 +43,8 @@
  * Any length / alignment / packed offsets:
  *   walk_ragged  the LDS-DMA input path with per-lane source addresses + lane refill per segment;
  *   walk_generic per-lane 16-byte loads (fallback, and the better one for very short inputs).
+ * Where an input lies: fixed stride (+ lengths), u64 or u32 offsets, or lengths alone (packed back to back: per-tile
+ * bases from a small pre-pass + a wavefront prefix sum).
  */
 #ifndef FSM_HIP_WALK_KERNELS_H
 #define FSM_HIP_WALK_KERNELS_H
@@ -58,6 +60,9 @@ struct WalkArgs {
 	uint64_t        stride;   /* bytes between inputs (fixed-stride modes)            */
 	const uint32_t *len;      /* per-input lengths or NULL (= stride)                 */
 	const uint64_t *off;      /* packed mode: n+1 offsets, or NULL                    */
+	const uint32_t *off32;    /* packed mode, batches below 4 GiB: n+1 32-bit offsets, or NULL */
+	const uint64_t *tbase;    /* packed mode, lengths only (len != NULL, stride == 0): byte offset of input 64 t for every
+	                           * tile t of 64 inputs (tile_bases_* below); the offsets inside a tile are a wavefront prefix sum */
 	uint64_t        n;        /* number of inputs                                     */
 	uint32_t       *end_out;  /* n entries or NULL                                    */
 	uint64_t       *bitmap;   /* ceil(n/64) words or NULL                             */
@@ -94,19 +99,10 @@ struct WalkArgs {
 	const uint32_t *ew_off;
 	const uint32_t *ew_word;
 	const uint64_t *ew_mask;
-	/* packed front (walk_packed.h): scratch block = PackedParams + first[]; where the raw state codes go; row-size
-	 * bounds (log2 bytes), the most rows first[] holds, the longest mean input length walk_packed takes */
-	uint32_t       *pk;
-	uint32_t       *pk_codes;
-	uint64_t       *pk_kbits;       /* bit j: input j is empty */
-	uint32_t        pk_rmin_bytes;  /* smallest row in bytes (knob) */
-	uint32_t        pk_rmax;        /* log2 of the largest row: what the per-wave LDS bitmask holds (<= FSMHIP_PK_RMAX) */
-	uint32_t        pk_nvmax, pk_mean_max;
-	uint32_t        pk_debug;       /* measurement aid (FSM_HIP_KNOB_PK_DEBUG): 1 no result stores, 4 no input loads */
-	uint64_t        pk_lanes;       /* lanes of the resident grid: rows are sized to give each wavefront about four tiles */
 	/* two kernels launched for one batch, the choice made on the device: return at once if *skip_flag == skip_when */
 	const uint32_t *skip_flag;
 	uint32_t        skip_when;
+	uint32_t       *pick_flag;   /* offsets_pick writes 1 (short inputs: walk_generic) or 0 (walk_ragged) here */
 	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy; a zeroed tile counter, or NULL */
 	const void     *lazy;
 	uint32_t       *tile_ctr;
@@ -134,7 +130,28 @@ __device__ __forceinline__ uint32_t fin_index(const WalkArgs &a, uint32_t code)
 	return code / a.fin_div;
 }
 
-enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_PACKED = 4, IN_LAZY = 5 };
+/* one past the last byte of a batch, relative to its base */
+__device__ __forceinline__ uint64_t batch_bytes(const WalkArgs &a)
+{
+	if (a.off != nullptr) return a.off[a.n];
+	if (a.off32 != nullptr) return a.off32[a.n];
+	if (a.tbase != nullptr) return a.tbase[(a.n + 63u) / 64u];
+	return a.n * a.stride;
+}
+
+/* exclusive prefix sum over the 64 lanes of a wavefront (the lengths-only front: where an input starts inside its tile) */
+__device__ __forceinline__ uint64_t wave_excl_prefix(uint32_t v, uint32_t lane)
+{
+	uint64_t x = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint64_t y = __shfl_up(x, d, 64);
+		if (lane >= (uint32_t)d) x += y;
+	}
+	return x - v;
+}
+
+enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_LAZY = 5 };   /* (4 was walk_packed: removed in round 4) */
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
 #define FSMHIP_BTAB_BYTES 256u
@@ -1462,7 +1479,7 @@ walk_generic(const WalkArgs a)
 	const uint64_t ntiles = (a.n + 63u) / 64u, tstride = (uint64_t)gridDim.x * nw;
 	const uint64_t base = reinterpret_cast<uint64_t>(a.base);
 	/* one past the batch's last byte: no load may reach beyond it */
-	const uint64_t limit = base + (a.off != nullptr ? a.off[a.n] : a.n * a.stride);
+	const uint64_t limit = base + batch_bytes(a);
 	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);   /* 1 KiB that is always there: what a lane without a chunk reads */
 
 	/* 16 bytes at any address.  `edgy` (wave-uniform: some input of this step ends within 16 bytes of the batch's end --
@@ -1473,12 +1490,16 @@ walk_generic(const WalkArgs a)
 	};
 
 	/* the offsets / lengths of a step's inputs, asked for one step ahead (clamped indices: the loads are unconditional) */
-	uint64_t nb = 0, ne = 0;
-	uint32_t nl = 0;
+	uint64_t nb = 0, ne = 0, ntb = 0;
+	uint32_t nl = 0, nb32 = 0, ne32 = 0;
 	auto fetch = [&](uint64_t tile) {
 		const uint64_t i = tile * 64u + lane, ic = i < a.n ? i : a.n - 1u;
 		if (a.off != nullptr) { nb = a.off[ic]; ne = a.off[ic + 1u]; }
-		else if (a.len != nullptr) nl = a.len[ic];
+		else if (a.off32 != nullptr) { nb32 = a.off32[ic]; ne32 = a.off32[ic + 1u]; }
+		else if (a.len != nullptr) {
+			nl = a.len[ic];
+			if (a.tbase != nullptr) ntb = a.tbase[tile < ntiles ? tile : ntiles];
+		}
 	};
 
 	uint64_t tile = (uint64_t)blockIdx.x * nw + wave;
@@ -1492,6 +1513,8 @@ walk_generic(const WalkArgs a)
 		const bool valid = i < a.n;
 		uint64_t beg = 0, len = 0;
 		if (a.off != nullptr) { beg = nb; len = ne - nb; }
+		else if (a.off32 != nullptr) { beg = nb32; len = ne32 - nb32; }
+		else if (a.tbase != nullptr) { len = valid ? nl : 0u; beg = ntb + wave_excl_prefix((uint32_t)len, lane); }
 		else { beg = i * a.stride; len = a.len != nullptr ? nl : a.stride; }
 		if (!valid) { beg = 0; len = 0; }
 		fetch(tile + tstride);
@@ -1614,7 +1637,7 @@ walk_ragged(const WalkArgs a)
 	const uint64_t w_hi = w_lo + per < a.n ? w_lo + per : a.n;
 	if (w_lo >= w_hi) return;
 	/* one past the last byte of the batch: no 16-byte fetch may reach beyond it */
-	const uint64_t limit = reinterpret_cast<uint64_t>(a.base) + (a.off != nullptr ? a.off[a.n] : a.n * a.stride);
+	const uint64_t limit = reinterpret_cast<uint64_t>(a.base) + batch_bytes(a);
 
 	const uint32_t lr = lane / 8u, lq = lane % 8u;                   /* loader role */
 	unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
@@ -1623,7 +1646,8 @@ walk_ragged(const WalkArgs a)
 
 	uint64_t staged = w_lo, next = w_lo;      /* wave-uniform: ring holds [next, staged) */
 	u32x4 soff = {0u, 0u, 0u, 0u};            /* staging loads in flight: this lane's off[i], off[i + 1] ... */
-	uint32_t slen = 0;                        /* ... or its len[i] */
+	uint32_t slen = 0, s32a = 0, s32b = 0;    /* ... or its len[i], or its off32[i], off32[i + 1] */
+	uint64_t stb = 0;                         /* lengths only: the byte offset of the first input being staged (staged is a multiple of 64) */
 	uint32_t spend = 0;                       /* wave-uniform: how many pairs they are */
 
 	bool have = false;                        /* this lane holds an input whose segment is in the tile */
@@ -1639,12 +1663,21 @@ walk_ragged(const WalkArgs a)
 			__asm__ volatile("" ::: "memory");
 		}
 		if (spend != 0) {
+			/* lengths only: where each of the staged inputs starts (every lane takes part in the prefix sum) */
+			uint64_t pfx = 0;
+			if (a.tbase != nullptr) pfx = stb + wave_excl_prefix(lane < spend ? slen : 0u, lane);
 			if (lane < spend) {
 				const uint64_t i = staged + lane;
 				uint64_t b, l;
 				if (a.off != nullptr) {
 					b = ((uint64_t)soff.y << 32) | soff.x;
 					l = (((uint64_t)soff.w << 32) | soff.z) - b;
+				} else if (a.off32 != nullptr) {
+					b = s32a;
+					l = s32b - s32a;
+				} else if (a.tbase != nullptr) {
+					b = pfx;
+					l = slen;
 				} else {
 					b = i * a.stride;
 					l = a.len != nullptr ? slen : a.stride;
@@ -1723,9 +1756,12 @@ walk_ragged(const WalkArgs a)
 				const u32x4 *po = reinterpret_cast<const u32x4 *>(a.off + i);   /* off[i] and off[i + 1] */
 				const uint32_t *pl = a.len + i;                                  /* (both addresses first: a temporary formed
 				                                                                 * after one load would be ordered behind it) */
+				const uint32_t *p32 = a.off32 + i;
 				if (a.off != nullptr) soff = *po;
+				else if (a.off32 != nullptr) { s32a = p32[0]; s32b = p32[1]; }
 				else if (a.len != nullptr) slen = *pl;
 			}
+			if (a.tbase != nullptr) stb = a.tbase[staged >> 6];
 			spend = (uint32_t)c;
 		}
 

@@ -1,9 +1,10 @@
 """GPU (-m gpu): parity tests added in round 3, all through the C ABI.
 
-  * walk_packed -- the short-input kernel of the packed-offsets front (a lane owns a byte range and walks across
-    input boundaries): every length 0..40 at every alignment, retest-like line sets, hostile length mixes, rows
-    of 128 bytes to 1 KiB, every table layout, offsets arrays at 8-mod-16 addresses, off[0] != 0, batches that
-    end exactly on a line, the device-side choice between walk_packed and walk_ragged;
+  * the packed-offsets front (written for walk_packed, the round-3 kernel that was removed in round 4; the cases now
+    run walk_generic, walk_ragged and the device-side choice between them, and -- round 4 -- the u32-offsets and
+    lengths-only forms of the same batches): every length 0..40 at every alignment, retest-like line sets, hostile
+    length mixes, every table layout, offsets arrays at 8-mod-16 addresses, off[0] != 0, batches that end exactly
+    on a line;
   against the oracle, bit-exact."""
 import os
 
@@ -92,8 +93,8 @@ def _cases(name, rng):
 
 @pytest.mark.parametrize("name", ["c1.npz", "c3.npz"])
 def test_packed_kernel_length_distributions(hip, name):
-    """walk_packed forced (IN_PACKED) and the device-side auto choice, every layout the DFA can take, 1 to 12 waves,
-    rows of 128 bytes (an input nearly always runs past its row) to 1 KiB: end states and bitmap against the oracle."""
+    """walk_generic / walk_ragged forced and the auto choice, every layout the DFA can take, 1 to 12 waves; u64 offsets,
+    u32 offsets and lengths only: end states and bitmap against the oracle."""
     from oracle.pyoracle import Oracle
     rng = np.random.RandomState(5 + len(name))
     g = Golden(os.path.join(GOLDEN, name))
@@ -105,21 +106,26 @@ def test_packed_kernel_length_distributions(hip, name):
         ret, want = o.exec_strings(strings)
         base, off = _packed(strings)
         for L, dfa in dfas:
-            # (mode, waves, smallest row, largest row): rows of exactly 128 / 256 / 1024 bytes, and the kernel's own choice
-            for mode, waves, rmin, rmax in ((hip.IN_PACKED, 0, 7, 0), (hip.IN_PACKED, 1, 7, 7), (hip.IN_PACKED, 5, 8, 8), (hip.IN_PACKED, 0, 10, 10), (-1, 0, 7, 0)):
-                if L != hip.LAYOUT_AUTO and (waves, rmin) not in ((0, 7), (1, 7)):
+            lens = np.diff(off.astype(np.int64)).astype(np.uint32)
+            for mode, waves in ((hip.IN_GENERIC, 0), (hip.IN_GENERIC, 1), (hip.IN_RAGGED, 5), (hip.IN_RAGGED, 0), (-1, 0)):
+                if L != hip.LAYOUT_AUTO and waves not in (0, 1):
                     continue
-                print(name, cname, L, mode, waves, rmin, rmax, flush=True)
+                print(name, cname, L, mode, waves, flush=True)
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
-                dfa.tune(hip.KNOB_PK_RMIN, rmin)
-                dfa.tune(hip.KNOB_PK_RMAX, rmax)
                 end, bm = dfa.exec_batch_offsets(base, off)
                 bad = np.nonzero(end != want)[0]
-                assert len(bad) == 0, (name, cname, L, mode, waves, rmin, rmax, len(bad), bad[:8], [len(strings[i]) for i in bad[:8]])
-                assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, rmin)
+                assert len(bad) == 0, (name, cname, L, mode, waves, len(bad), bad[:8], [len(strings[i]) for i in bad[:8]])
+                assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves)
                 end, bm = dfa.exec_batch_offsets(base, off, want_bitmap=False)      # end states only
                 assert np.array_equal(end, want)
+                # the compact-metadata forms of the same batch (round 4)
+                end, bm = dfa.exec_batch_offsets32(base, off.astype(np.uint32))
+                assert np.array_equal(end, want) and np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, "off32")
+                end, bm = dfa.exec_batch_lengths(base, lens)
+                assert np.array_equal(end, want) and np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves, "lengths")
+                _, bm = dfa.exec_batch_lengths(base, lens, want_end=False)          # the 1-bit-per-input answer alone
+                assert np.array_equal(bits(bm, len(strings)), ret == 1)
     for _, dfa in dfas:
         dfa.close()
 
@@ -143,7 +149,6 @@ def test_packed_kernel_device_front_alignments(hip):
         return bytes(s)
 
     dfa = hip.HipDfa(g.flat)
-    dfa.tune(hip.KNOB_INPUT_MODE, hip.IN_PACKED)
     batches = []
     for total in range(0, 41):
         cut = sorted(rng.randint(0, total + 1, rng.randint(0, 6)))
@@ -171,8 +176,23 @@ def test_packed_kernel_device_front_alignments(hip):
             d_end = torch.full((n,), 7, dtype=torch.int32, device="cuda")
             d_bm = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device="cuda")
             base_ptr = big.data_ptr() + shift
-            for waves in (0, 1):
+            d_off32 = (d_off - lead).to(torch.int32)                       # the u32 form is relative to the first input's byte
+            d_len = (d_off[1:] - d_off[:-1]).to(torch.int32)
+            for waves, mode in ((0, -1), (1, hip.IN_GENERIC), (0, hip.IN_RAGGED)):
                 dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_INPUT_MODE, mode)
+                for form in ("off32", "len"):
+                    d_end.fill_(7)
+                    d_bm.zero_()
+                    if form == "off32":
+                        dfa.exec_batch_offsets32_device(base_ptr + lead, d_off32.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr())
+                    else:
+                        dfa.exec_batch_lengths_device(base_ptr + lead, d_len.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr())
+                    torch.cuda.synchronize()
+                    assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (bi, n, len(base), shift, lead, osh, waves, mode, form)
+                    assert np.array_equal(bits(d_bm.cpu().numpy()[:(n + 63) // 64], n), ret == 1)
+                d_end.fill_(7)
+                d_bm.zero_()
                 dfa.exec_batch_offsets_device(base_ptr, d_off.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr())
                 torch.cuda.synchronize()
                 assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (bi, n, len(base), shift, lead, osh, waves)
@@ -186,9 +206,9 @@ def test_packed_kernel_device_front_alignments(hip):
 
 
 def test_packed_kernel_large_batch_and_auto_choice(hip):
-    """6e6 packed inputs of 8..64 bytes resident on the device (216 MB): walk_packed (which the auto mode picks: mean
-    36 bytes) agrees with walk_generic on every input and with the oracle on a sample; 2e6 inputs of 0..1024 bytes
-    (mean 512: auto leaves them to walk_ragged) the same, with walk_packed forced as well."""
+    """6e6 packed inputs of 8..64 bytes resident on the device (216 MB): the device-side choice (walk_generic: mean 36
+    bytes) agrees with walk_ragged and walk_generic forced on every input and with the oracle on a sample; 2e6 inputs of
+    0..1024 bytes (mean 512: the choice is walk_ragged) the same; and the u32-offsets and lengths-only forms agree too."""
     import torch
     from oracle.pyoracle import Oracle
     g = Golden(os.path.join(GOLDEN, "c1.npz"))
@@ -206,20 +226,37 @@ def test_packed_kernel_large_batch_and_auto_choice(hip):
         e = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(3)]
         bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
         ms = {}
-        for k, mode in enumerate((-1, hip.IN_PACKED, hip.IN_GENERIC)):
+        for k, mode in enumerate((-1, hip.IN_RAGGED, hip.IN_GENERIC)):
             dfa.tune(hip.KNOB_INPUT_MODE, mode)
             for rep in range(2):
                 dfa.exec_batch_offsets_device(buf.data_ptr(), d_off.data_ptr(), n, e[k].data_ptr(), bm.data_ptr() if k == 0 else 0)
             ms[mode] = dfa.last_kernel_ms()
         torch.cuda.synchronize()
         assert torch.equal(e[0], e[2]) and torch.equal(e[1], e[2])
+        dfa.tune(hip.KNOB_INPUT_MODE, -1)
+        d_off32, d_len = d_off.to(torch.int32), (d_off[1:] - d_off[:-1]).to(torch.int32)
+        bm2 = torch.zeros_like(bm)
+        dfa.exec_batch_offsets32_device(buf.data_ptr(), d_off32.data_ptr(), n, e[1].data_ptr(), bm2.data_ptr())
+        ms["off32"] = dfa.last_kernel_ms()
+        assert torch.equal(e[1], e[2]) and torch.equal(bm2, bm)
+        e[1].fill_(5)
+        bm2.zero_()
+        dfa.exec_batch_lengths_device(buf.data_ptr(), d_len.data_ptr(), n, e[1].data_ptr(), bm2.data_ptr())
+        ms["len"] = dfa.last_kernel_ms()
+        torch.cuda.synchronize()
+        assert torch.equal(e[1], e[2]) and torch.equal(bm2, bm)
+        bm2.zero_()
+        dfa.exec_batch_lengths_device(buf.data_ptr(), d_len.data_ptr(), n, 0, bm2.data_ptr())      # bitmap only
+        ms["len_bitmap"] = dfa.last_kernel_ms()
+        assert torch.equal(bm2, bm)
         assert int((e[0] != -1).sum()) == int(bits(bm.cpu().numpy(), n).sum()) > 0
         host = buf.reshape(-1)[:total].cpu().numpy()
         idx = rng.randint(0, n, 5000)
         strings = [bytes(host[int(off[i]):int(off[i + 1])]) for i in idx]
         ret, want = o.exec_strings(strings)
         assert np.array_equal(e[0].cpu().numpy().view(np.uint32)[idx], want)
-        print(f"packed front n={n} lens={lo}..{hi - 1}: auto {total / ms[-1] / 1e6:.0f} GB/s, packed {total / ms[hip.IN_PACKED] / 1e6:.0f}, generic {total / ms[hip.IN_GENERIC] / 1e6:.0f}")
+        print(f"packed front n={n} lens={lo}..{hi - 1}: auto {total / ms[-1] / 1e6:.0f} GB/s, ragged {total / ms[hip.IN_RAGGED] / 1e6:.0f}, generic {total / ms[hip.IN_GENERIC] / 1e6:.0f}, "
+              f"u32 offsets {total / ms['off32'] / 1e6:.0f}, lengths only {total / ms['len'] / 1e6:.0f} (walk kernel; bitmap only {total / ms['len_bitmap'] / 1e6:.0f})")
     dfa.close()
 
 

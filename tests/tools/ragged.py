@@ -47,21 +47,31 @@ def main():
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
             ref = None
-            for front, mode, waves, align in (("packed", -1, 0, 0), ("packed", 4, 0, 0), ("packed", 4, 8, 0), ("packed", 3, 0, 0), ("packed", 2, 0, 0),
-                                              ("stride+len", 3, 0, 0), ("stride+len", 2, 0, 0), ("rows", 3, 0, 0), ("rows", -1, 0, 0)):
+            off32 = off.to(torch.int32) if total < (1 << 32) else None
+            bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+            for front, mode, waves, align in (("packed", -1, 0, 0), ("packed", 3, 0, 0), ("packed", 2, 0, 0), ("off32", -1, 0, 0), ("lengths", -1, 0, 0), ("len-bitmap", -1, 0, 0),
+                                              ("stride+len", -1, 0, 0), ("stride+len", 3, 0, 0), ("stride+len", 2, 0, 0), ("rows", 3, 0, 0), ("rows", -1, 0, 0)):
                 if only is not None and f"{wl}:{front}:{mode}" not in only.split(","):
                     continue
                 if front == "rows" and dist != "uniform0-1024":
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves or int(os.environ.get("PK_WAVES", 0)))
-                for kn, ev in ((hip.KNOB_PK_RMIN, "PK_RMIN"), (hip.KNOB_PK_RMAX, "PK_RMAX"), (hip.KNOB_PK_MEAN_MAX, "PK_MEAN_MAX"), (hip.KNOB_PK_DEBUG, "PK_DEBUG"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP")):
+                for kn, ev in ((hip.KNOB_PICK_MEAN, "PICK_MEAN"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP")):
                     if os.environ.get(ev):
                         dfa.tune(kn, int(os.environ[ev]))
                 ms = []
                 for r in range(4):
                     if front == "packed":
                         dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n, end.data_ptr(), 0)
+                    elif front == "off32":
+                        if off32 is None:
+                            break
+                        dfa.exec_batch_offsets32_device(packed.data_ptr(), off32.data_ptr(), n, end.data_ptr(), 0)
+                    elif front == "lengths":
+                        dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, end.data_ptr(), 0)
+                    elif front == "len-bitmap":       # the 1-bit-per-input answer alone (the end states of the previous front stay in `end`)
+                        dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, 0, bm.data_ptr())
                     elif front == "rows":       # whole 1024-byte rows: what the same kernel (3) / the LDS-DMA kernel (-1) does without raggedness
                         dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)
                     else:
@@ -70,6 +80,8 @@ def main():
                     if r:
                         ms.append(t)
                 torch.cuda.synchronize()
+                if not ms:
+                    continue
                 if front == "rows":
                     print(f"{wl} {dfa.info()['layout_name']:8s} lens=1024           front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
                           f"GB/s(walked)={n * L / min(ms) / 1e6:8.1f}", flush=True)
@@ -78,6 +90,9 @@ def main():
                 if ref is None:
                     ref = end.clone()
                 ok = ok and bool(torch.equal(ref, end))
+                if front == "len-bitmap":
+                    got = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+                    ok = ok and np.array_equal(got, ref.cpu().numpy() != -1)
                 print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
                       f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
             dfa.close()
