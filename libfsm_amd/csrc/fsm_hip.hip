@@ -526,7 +526,6 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
 		c.mode = IN_LAZY;
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
-		c.lazy_eva = d->plan.lazy_img[15] != 0;
 		c.nb = 4;
 		c.waves = 16;
 		c.lds = d->plan.lazy_lds_bytes;

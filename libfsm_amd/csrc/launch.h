@@ -22,7 +22,6 @@ struct LaunchCfg {
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
-	int lazy_eva;        /* IN_LAZY: some LDS record answers with a state from F up (plan.cpp img[15]) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 	mutable const void *kfn;   /* out: the kernel launch_fn launched (its name goes into fsm_hip_last_kernel_name) */
 };
@@ -63,7 +62,15 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	walk_fn k = nullptr;
 	switch (c.mode) {
 	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
-	case IN_GENERIC: k = walk_generic<Pol>; break;
+	case IN_GENERIC:
+		/* the plain walk (no second output table, no resume) has an instantiation per metadata form: with the form decided at
+		 * run time every pointer of every form stays live across the loop -- 40-56 scalar registers spilled to vector lanes
+		 * against 7-19 (tools/kernel_resources.py) */
+		if (a.out2 == nullptr && a.state_io == nullptr) {
+			k = a.off != nullptr ? walk_generic<Pol, 1024, true, FR_OFF64> : a.off32 != nullptr ? walk_generic<Pol, 1024, true, FR_OFF32>
+			  : a.tbase != nullptr ? walk_generic<Pol, 1024, true, FR_LENS> : walk_generic<Pol, 1024, true, FR_STRIDE>;
+		} else k = walk_generic<Pol>;
+		break;
 	case IN_LDSDMA:
 		if (c.seg == 128) k = c.nt ? walk_ldsdma<Pol, 128, 2, ldsdma_threads<Pol>::value> : walk_ldsdma<Pol, 128, 0, ldsdma_threads<Pol>::value>;
 		else k = walk_ldsdma<Pol, 64, 0, ldsdma_threads<Pol>::value>;

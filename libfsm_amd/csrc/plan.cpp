@@ -736,7 +736,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
  * on which its row differs from car[m]'s answers -- so the result is delta for ANY automaton, by construction, and
  * tests/test_plan.py re-derives that for every reachable (state, carried record, byte).
  *
- * Image (u32 words): hdr[16] | LDS part: sh[256] (bytes) at LDS address 0 (byte -> 63 - bit, or 0x80 for bytes whose
+ * Image (u32 words): hdr[16] | LDS part: sh[256] at LDS address 0 (byte -> 63 - bit, or 0x80000000 for bytes whose
  * class owns no bit), filter[fwords], records[H + 1] (the last one all-sentinel: Z)
  * | own records, 16 bytes per state {bits, base, stride} | car[S1].
  */
@@ -817,8 +817,8 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	if (H == 0 || p.start >= H) return;
 	LR.resize(H);
 	uint32_t fwords = 4096;
-	while ((uint64_t)fwords * 2u * 4u + ((uint64_t)H + 1u) * 16u + 256u <= lds_limit) fwords *= 2u;
-	if ((uint64_t)fwords * 4u + ((uint64_t)H + 1u) * 16u + 256u > lds_limit) return;
+	while ((uint64_t)fwords * 2u * 4u + ((uint64_t)H + 1u) * 16u + 1024u <= lds_limit) fwords *= 2u;
+	if ((uint64_t)fwords * 4u + ((uint64_t)H + 1u) * 16u + 1024u > lds_limit) return;
 	const uint32_t Z = H;
 
 	auto evalF = [&](uint32_t e, uint32_t b) -> uint32_t {
@@ -917,7 +917,7 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	}
 
 	/* 3. the image */
-	const uint32_t sh_off = 0, filt_off = 256u, rec_off = filt_off + fwords * 4u, lds_bytes = rec_off + (H + 1u) * 16u;
+	const uint32_t sh_off = 0, filt_off = 1024u, rec_off = filt_off + fwords * 4u, lds_bytes = rec_off + (H + 1u) * 16u;
 	const uint32_t lds_w = lds_bytes / 4u, grec_w = (16u + lds_w + 3u) & ~3u;
 	std::vector<uint32_t> &img = p.lazy_img;
 	const size_t car_w = (size_t)grec_w + (size_t)S1 * 4u;
@@ -933,7 +933,7 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	}
 	for (unsigned v = 0; v < 256; v++) {
 		const uint32_t b = bit_of[p.cls[v]];
-		reinterpret_cast<uint8_t *>(L + sh_off / 4u)[v] = (uint8_t)(b != 0xff ? 63u - b : 0x80u);   /* bit 7: the kernel ORs a chunk's 16 entries into its sentinel test */
+		L[sh_off / 4u + v] = b != 0xff ? 63u - b : SENT;   /* bit 31: the kernel ORs a chunk's 16 entries into its sentinel test */
 	}
 	uint32_t nzstates = 0, nsent = 0;
 	for (uint32_t s = H; s < N; s++) {

@@ -1434,11 +1434,18 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 	}
 }
 
+/* does the policy give the bytes beyond an input's end a class of their own (step16_part_ident)?  Then a partial chunk is
+ * as cheap as a whole one */
+template <class Pol>
+constexpr auto tail_in_step(int) -> decltype(static_cast<const Pol *>(nullptr)->ident, true) { return true; }
+template <class Pol> constexpr bool tail_in_step(long) { return false; }
+
 /* ------------------------------------------------------------------ */
 /* walk_generic: ragged lengths, any alignment, fixed stride or packed */
 /* ------------------------------------------------------------------ */
 
-/* 16 bytes of which [addr, limit) exist (out of line: the last step or two of a batch) */
+/* 16 bytes of which [addr, limit) exist (out of line: the tiles that touch the batch's last bytes, and tiles whose 64
+ * inputs span 4 GiB or more) */
 __device__ __noinline__ u32x4 load_chunk_edge(uint64_t addr, bool want, uint64_t limit, uint64_t safe)
 {
 	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;
@@ -1450,20 +1457,41 @@ __device__ __noinline__ u32x4 load_chunk_edge(uint64_t addr, bool want, uint64_t
 	return u32x4{d[0], d[1], d[2], d[3]};
 }
 
+/* result write-back of the plain walk (no second per-state table, no resume): what the PLAIN instantiation of walk_generic
+ * keeps live across its loop is then the two output pointers and the fin table */
+__device__ __forceinline__ void write_result_plain(const WalkArgs &a, uint64_t word, uint64_t i, bool valid, uint32_t st)
+{
+	uint32_t end = FSMHIP_NO_MATCH;
+	const uint32_t idx = fin_index(a, st);
+	if (valid) end = a.fin[idx];
+	if (valid && a.end_out != nullptr) a.end_out[i] = end;
+	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
+	if (a.bitmap != nullptr && (threadIdx.x & 63u) == 0 && word * 64u < a.n) a.bitmap[word] = m;
+}
+
 /*
- * One input per lane, 64 consecutive inputs per wavefront and step of a persistent loop.  The walk of a short input
- * (the lines retest / rx feed) is a few hundred cycles; what it waited for, in the first version of this kernel, were
- * four memory round trips in a row: the offsets, the first chunk, every further chunk one ahead, the fin[] lookup of
- * the result.  Now a step has ONE wait:
+ * One input per lane, 64 consecutive inputs per wavefront and step of a persistent loop: the kernel of the lines retest /
+ * rx feed (a few dozen bytes each) and the fallback for everything else.  A step has ONE wait:
  *  - the offsets (or lengths) of the NEXT step's inputs are asked for at the top of a step;
- *  - an input's first NC = 4 chunks are loaded together, from its own byte address: global_load_dwordx4 takes any
- *    alignment, so chunk 0 starts at the input's first byte and only the input's LAST chunk can be partial (the first
- *    version read aligned chunks: a packed input's first chunk was partial too, and a partial chunk costs 16 predicated
- *    steps).  A chunk that would reach past the batch's last byte is assembled from byte loads;
+ *  - an input's first NC = 4 chunks are loaded together from its own byte address (no partial chunk at the head).  Round 4:
+ *    BUFFER loads through a resource re-based, per step, on the first input of the tile and bounded 8 bytes short of the
+ *    batch's last byte: the address of a chunk is one 32-bit offset + an immediate (the first version added 64-bit
+ *    addresses and selected a safe address for the lanes without that chunk: ~20 vector instructions a step), a chunk that
+ *    lies beyond the batch reads zeros instead of faulting, and the only tiles that take the out-of-line byte assembly are
+ *    the ones that really touch the batch's last 8 bytes (or span 4 GiB);
  *  - the previous step's results are looked up (fin[]) and written under the same wait.
- * Inputs longer than NC chunks go on one chunk at a time with the next one in flight, as before.
+ * The walk itself, round 4: every lane walks its WHOLE chunks first -- unpredicated steps under the lane's own condition
+ * -- and the one partial chunk an input can have (its last len % 16 bytes) takes ONE predicated step for all lanes at the
+ * end.  (The first version ran chunk c for all lanes at once: with 64 lengths per wavefront some lane's input ended in every
+ * chunk, so all four steps were predicated ones -- twice the instructions of a plain step for the column tables.)
+ * Inputs longer than NC chunks go on one chunk at a time with the next one in flight.
+ * PLAIN: no second output table, no resume state (launch.h picks it whenever that is so): fewer live scalars.
  */
-template <class Pol, int MAXT = 1024>
+/* FRONT: which metadata form the instantiation is for (FR_ANY: decided at run time from the arguments: every pointer of
+ * every form then stays live across the loop) */
+enum { FR_ANY = 0, FR_OFF64 = 1, FR_OFF32 = 2, FR_LENS = 3, FR_STRIDE = 4 };
+
+template <class Pol, int MAXT = 1024, bool PLAIN = false, int FRONT = FR_ANY>
 __global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
 {
@@ -1474,32 +1502,29 @@ walk_generic(const WalkArgs a)
 	__syncthreads();
 
 	constexpr uint32_t NC = 4;
-	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;   /* not a flat load */
+	const bool f_off = FRONT == FR_ANY ? a.off != nullptr : FRONT == FR_OFF64;
+	const bool f_off32 = FRONT == FR_ANY ? a.off == nullptr && a.off32 != nullptr : FRONT == FR_OFF32;
+	const bool f_lens = FRONT == FR_ANY ? a.off == nullptr && a.off32 == nullptr && a.tbase != nullptr : FRONT == FR_LENS;
 	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
 	const uint64_t ntiles = (a.n + 63u) / 64u, tstride = (uint64_t)gridDim.x * nw;
 	const uint64_t base = reinterpret_cast<uint64_t>(a.base);
 	/* one past the batch's last byte: no load may reach beyond it */
-	const uint64_t limit = base + batch_bytes(a);
-	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);   /* 1 KiB that is always there: what a lane without a chunk reads */
-
-	/* 16 bytes at any address.  `edgy` (wave-uniform: some input of this step ends within 16 bytes of the batch's end --
-	 * the batch's last step or two) sends every load of the step through the out-of-line byte assembly */
-	auto load_chunk = [&](uint64_t addr, bool want, bool edgy) -> u32x4 {
-		if (edgy) return load_chunk_edge(addr, want, limit, safe);
-		return *(glb_chunk_p)(want ? addr : safe);      /* unconditional: the loads of a step are counted, not waited for one by one */
-	};
+	const uint64_t total = f_off ? a.off[a.n] : f_off32 ? a.off32[a.n] : f_lens ? a.tbase[(a.n + 63u) / 64u] : a.n * a.stride, limit = base + total;
+	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);   /* 1 KiB that is always there: what a lane without a chunk reads on the slow path */
 
 	/* the offsets / lengths of a step's inputs, asked for one step ahead (clamped indices: the loads are unconditional) */
 	uint64_t nb = 0, ne = 0, ntb = 0;
 	uint32_t nl = 0, nb32 = 0, ne32 = 0;
 	auto fetch = [&](uint64_t tile) {
 		const uint64_t i = tile * 64u + lane, ic = i < a.n ? i : a.n - 1u;
-		if (a.off != nullptr) { nb = a.off[ic]; ne = a.off[ic + 1u]; }
-		else if (a.off32 != nullptr) { nb32 = a.off32[ic]; ne32 = a.off32[ic + 1u]; }
-		else if (a.len != nullptr) {
-			nl = a.len[ic];
-			if (a.tbase != nullptr) ntb = a.tbase[tile < ntiles ? tile : ntiles];
-		}
+		if (f_off) { nb = a.off[ic]; ne = a.off[ic + 1u]; }
+		else if (f_off32) { nb32 = a.off32[ic]; ne32 = a.off32[ic + 1u]; }
+		else if (f_lens) { nl = a.len[ic]; ntb = a.tbase[tile < ntiles ? tile : ntiles]; }
+		else if (a.len != nullptr) nl = a.len[ic];
+	};
+	auto result = [&](uint64_t word, uint64_t i, bool valid, uint32_t code) {
+		if (PLAIN) write_result_plain(a, word, i, valid, code);
+		else write_result(a, word, i, valid, code);
 	};
 
 	uint64_t tile = (uint64_t)blockIdx.x * nw + wave;
@@ -1512,46 +1537,91 @@ walk_generic(const WalkArgs a)
 		const uint64_t i = tile * 64u + lane;
 		const bool valid = i < a.n;
 		uint64_t beg = 0, len = 0;
-		if (a.off != nullptr) { beg = nb; len = ne - nb; }
-		else if (a.off32 != nullptr) { beg = nb32; len = ne32 - nb32; }
-		else if (a.tbase != nullptr) { len = valid ? nl : 0u; beg = ntb + wave_excl_prefix((uint32_t)len, lane); }
+		if (f_off) { beg = nb; len = ne - nb; }
+		else if (f_off32) { beg = nb32; len = ne32 - nb32; }
+		else if (f_lens) { len = valid ? nl : 0u; beg = ntb + wave_excl_prefix((uint32_t)len, lane); }
 		else { beg = i * a.stride; len = a.len != nullptr ? nl : a.stride; }
-		if (!valid) { beg = 0; len = 0; }
+		if (!valid) len = 0;
 		fetch(tile + tstride);
-		const uint64_t p0 = base + beg;
-		const uint64_t nchunks = (len + 15u) / 16u;
+		/* the tile's window: from its first input's first byte (inputs lie in index order: lane 0's) */
+		const uint64_t tb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(beg >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)beg);
+		if (!valid) beg = tb;
+		const uint64_t rel64 = beg - tb, nfull = len >> 4;
+		const uint32_t tail = (uint32_t)len & 15u;
+		const uint64_t nchunks = nfull + (tail != 0u ? 1u : 0u);
 		typename Pol::S st[1] = { init_state(pol, start_code(a, i, valid), a, i, valid, 0) };
-		const bool edgy = __any(nchunks != 0 && p0 + 16u * nchunks > limit);
+		/* slow: an input of this step ends within 8 bytes of the batch's end, or the step's inputs reach 4 GiB beyond its first byte
+		 * (then 32-bit offsets do not do), or lie out of order */
+		const bool slow = __any(nchunks != 0 && (beg + len + 8u > total || rel64 + 16u * nchunks >= 0xFFFFFF00ull || beg < tb));
+		const uint64_t wbytes = total - tb >= 8u ? total - tb - 8u : 0u;
+		const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base + tb), 0, (int)(wbytes < 0xFFFFFFF0ull ? (uint32_t)wbytes : 0xFFFFFFF0u), 0x00020000);
+		const uint32_t rel = (uint32_t)rel64;
+		const uint64_t p0 = base + beg;
+		auto load_chunk = [&](uint64_t c) -> u32x4 {
+			if (slow) return load_chunk_edge(p0 + 16u * c, c < nchunks, limit, safe);
+			return __builtin_amdgcn_raw_buffer_load_b128(win, (int)(rel + 16u * (uint32_t)c), 0, 0);
+		};
 		u32x4 wq[NC];
 #pragma unroll
-		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(p0 + 16u * j, j < nchunks, edgy);
+		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(j);
 		/* the previous step's results: their fin[] lookup is in flight with this step's chunks */
-		if (pend) write_result(a, ptile, pi, pvalid, pcode);
-#pragma unroll
-		for (uint32_t c = 0; c < NC; c++) {
-			if (!__any(c < nchunks)) break;
-			if (c < nchunks) {
-				const uint64_t left = len - c * 16u;
-				if (__all(left >= 16u)) {
-					/* every lane still walking has a whole chunk: no per-byte predicate */
-					const u32x4 w1[1] = { wq[c] };
-					step16<Pol, 1>(pol, st, w1);
-				} else {
-					step16_part(pol, st[0], wq[c], 0u, left < 16u ? (uint32_t)left : 16u);
+		if (pend) result(ptile, pi, pvalid, pcode);
+		if (tail_in_step<Pol>(0)) {
+			/* self-loop-mask layouts with a spare class: the bytes beyond an input's end become that class in the state-
+			 * independent part of a step, so a partial chunk costs what a whole one does -- chunk c of every lane in one step */
+			/* (one copy of the step code, the four chunks rotated through wq[0]: unrolled, the two forms of a step times four
+			 * were 55 KB of a 64 KB instruction cache that two CUs share) */
+#pragma unroll 1
+			for (uint32_t c = 0; c < NC; c++) {
+				if (!__any(c < nchunks)) break;
+				if (c < nchunks) {
+					if (__all(c < nfull)) {
+						const u32x4 w1[1] = { wq[0] };
+						step16<Pol, 1>(pol, st, w1);
+					} else {
+						step16_part(pol, st[0], wq[0], 0u, c < nfull ? 16u : tail);
+					}
+				}
+				wq[0] = wq[1]; wq[1] = wq[2]; wq[2] = wq[3];
+			}
+			if (__any(nchunks > NC)) {
+				u32x4 w[1] = { load_chunk(NC) };
+				for (uint64_t c = NC; __any(c < nchunks); c++) {
+					if (c < nchunks) {
+						const u32x4 wn = load_chunk(c + 1u);   /* next chunk in flight */
+						if (__all(c < nfull)) step16<Pol, 1>(pol, st, w);
+						else step16_part(pol, st[0], w[0], 0u, c < nfull ? 16u : tail);
+						w[0] = wn;
+					}
+					if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
 				}
 			}
-		}
-		if (__any(nchunks > NC)) {
-			u32x4 w[1] = { load_chunk(p0 + 16u * NC, nchunks > NC, edgy) };
-			for (uint64_t c = NC; __any(c < nchunks); c++) {
-				if (c < nchunks) {
-					const u32x4 wn = load_chunk(p0 + 16u * (c + 1u), c + 1u < nchunks, edgy);   /* next chunk in flight */
-					const uint64_t left = len - c * 16u;
-					if (__all(left >= 16u)) step16<Pol, 1>(pol, st, w);
-					else step16_part(pol, st[0], w[0], 0u, left < 16u ? (uint32_t)left : 16u);
-					w[0] = wn;
+		} else {
+			/* whole chunks, each lane its own (unpredicated steps under the lane's condition); the partial one is kept for the end */
+			u32x4 tw = wq[0];
+#pragma unroll
+			for (uint32_t c = 0; c < NC; c++) {
+				if (!__any(c < nfull)) break;
+				if (c < nfull) {
+					const u32x4 w1[1] = { wq[c] };
+					step16<Pol, 1>(pol, st, w1);
 				}
-				if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
+				if (c + 1u < NC && nfull == c + 1u) tw = wq[c + 1u];
+			}
+			if (__any(nchunks > NC)) {
+				u32x4 w[1] = { load_chunk(NC) };
+				for (uint64_t c = NC; __any(c < nchunks); c++) {
+					if (c < nchunks) {
+						const u32x4 wn = load_chunk(c + 1u);   /* next chunk in flight */
+						if (c < nfull) step16<Pol, 1>(pol, st, w);
+						else tw = w[0];
+						w[0] = wn;
+					}
+					if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1 >= nchunks)) break;
+				}
+			}
+			if (__any(tail != 0u)) {
+				if (tail != 0u) step16_part(pol, st[0], tw, 0u, tail);
 			}
 		}
 		finish_state(pol, a, i, valid, st[0], 0);
@@ -1561,7 +1631,7 @@ walk_generic(const WalkArgs a)
 		pvalid = valid;
 		pcode = Pol::code(st[0]);
 	}
-	if (pend) write_result(a, ptile, pi, pvalid, pcode);
+	if (pend) result(ptile, pi, pvalid, pcode);
 }
 
 /* ------------------------------------------------------------------ */

@@ -30,7 +30,7 @@
 
 namespace fsmhip {
 
-#define FSMHIP_LAZY_SH_BYTES 256u       /* sh[256] (one byte each) sits at LDS address 0, the filter right behind it */
+#define FSMHIP_LAZY_SH_BYTES 1024u      /* sh[256] (u32: a byte-wide table measured slower, profiles/r06c_*) sits at LDS address 0, the filter right behind it */
 
 /* one exact step through build_sparse's records in DEVICE memory (no LDS mirror, the FULLBASE shortcut not taken:
  * the chain simply goes on to the base) */
@@ -68,7 +68,6 @@ struct LazyCtx {
 
 typedef const u32x4 __attribute__((address_space(3))) *lazy_rec_p;
 typedef const uint32_t __attribute__((address_space(3))) *lazy_u32_p;
-typedef const uint8_t __attribute__((address_space(3))) *lazy_u8_p;
 
 /* popcount(x) + acc as ONE v_bcnt_u32_b32 (its second operand is an addend); without the barrier the compiler
  * re-associates two of them into v_bcnt, v_bcnt, v_add3 */
@@ -116,7 +115,7 @@ __device__ __forceinline__ LazyState lazy_enter(const LazyCtx &cx, uint32_t id, 
  * written over 0 / 1 integers the compiler does it with vector selects.  The dependent chain from one own-record gather to
  * the next is: shift, sign test, (scalar or), select of the offset -- the filter word of the next state was read for the
  * LDS answer `ev` while the gather was in flight. */
-template <bool ABS, bool EVA>
+template <bool ABS>
 __device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint32_t sh, uint32_t &bacc)
 {
 	const u32x4 rb = *(lazy_rec_p)(uintptr_t)(cx.recbase + s.E * 16u);
@@ -133,7 +132,8 @@ __device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint3
 	const bool evD = (int32_t)ev >= (int32_t)cx.H;
 	uint32_t rep = evD ? cfb : ev;
 	const uint32_t fwn = *(lazy_u32_p)(uintptr_t)(((ev << 2) & cx.fmask) + FSMHIP_LAZY_SH_BYTES);
-	const bool evA = EVA && ev >= cx.F;     /* (EVA false: no LDS record answers with a state from F up -- plan.cpp img[15]) */
+	const bool evA = ev >= cx.F;     /* (compiling this compare out where no LDS record answers with a state from F up -- plan.cpp img[15] --
+	                                  * made the compiler keep A in a VGPR: 10 % more vector instructions, profiles/r06c_c5_lazy_u8_eva_slower.txt) */
 	/* the own record's {bits, base, stride}: the k-th exception leads to base + k * stride (an exception of a state beyond
 	 * the LDS set leads beyond the LDS set: plan.cpp) */
 	const bool hA = lazy_probe(g.x, g.y, 0u, sh, nA);
@@ -166,11 +166,11 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 #pragma unroll 1
 	for (uint32_t k = 0; k < 16u; k++) {
 		const uint32_t byte = byte_dyn(w, k);
-		const uint32_t sh = *(lazy_u8_p)(uintptr_t)byte;
+		const uint32_t sh = *(lazy_u32_p)(uintptr_t)(byte * 4u);
 		LazyState c = lazy_enter(cx, id, E);
 		uint32_t b = 0;
-		lazy_step<ABS, true>(cx, c, sh, b);
-		if ((int32_t)(b | (sh << 24)) < 0) {
+		lazy_step<ABS>(cx, c, sh, b);
+		if ((int32_t)(b | sh) < 0) {
 			/* the exact step; what a state beyond the LDS set carries comes from plan.cpp's car[] */
 			c.id = sparse_next_global(simg, id, byte, cx.abs_min);
 			c.E = c.id < cx.H ? c.id : car[c.id];
@@ -183,7 +183,7 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 /* ROWS inputs per lane (independent chains: the instruction-level parallelism a second workgroup per CU would give),
  * NB 16-byte chunks per row in flight.  a.tile_ctr != NULL: the wavefronts claim their tiles of 64 * ROWS inputs from that
  * counter (zeroed on the launch stream) instead of striding: the tail of the persistent grid balances to one tile. */
-template <bool ABS, bool EVA, int ROWS, int NB>
+template <bool ABS, int ROWS, int NB>
 __global__ void __launch_bounds__(1024)
 walk_lazy(const WalkArgs a)
 {
@@ -249,9 +249,9 @@ walk_lazy(const WalkArgs a)
 #pragma unroll
 				for (int r = 0; r < ROWS; r++)
 #pragma unroll
-					for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u8_p)(uintptr_t)byte_of(cur[j][r], k);
+					for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], k) * 4u);
 				uint32_t sid[ROWS], sE[ROWS], bacc[ROWS];
-				/* a byte whose class owns no bit has bit 7 set in its sh entry: the chunk then goes the exact way too */
+				/* a byte whose class owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too */
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) {
 					sid[r] = st[r].id;
@@ -259,12 +259,11 @@ walk_lazy(const WalkArgs a)
 					bacc[r] = 0u;
 #pragma unroll
 					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
-					bacc[r] <<= 24;
 				}
 #pragma unroll
 				for (int k = 0; k < 16; k++)
 #pragma unroll
-					for (int r = 0; r < ROWS; r++) lazy_step<ABS, EVA>(cx, st[r], sh[r][k], bacc[r]);
+					for (int r = 0; r < ROWS; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
 				uint32_t ball = 0;
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) ball |= bacc[r];

@@ -414,10 +414,10 @@ def lazy_decode(p):
         return None
     assert img[0] == 0x31595a4c
     H, F, fwords, rec_off, filt_off, lds_bytes, grec_off = (int(x) for x in img[1:8])
-    assert filt_off == 256 and rec_off == filt_off + 4 * fwords and lds_bytes == rec_off + 16 * (H + 1) <= 160 * 1024
+    assert filt_off == 1024 and rec_off == filt_off + 4 * fwords and lds_bytes == rec_off + 16 * (H + 1) <= 160 * 1024
     assert fwords & (fwords - 1) == 0 and int(img[13]) == p.S1
     L = img[16:16 + lds_bytes // 4]
-    sh = np.frombuffer(L[:64].astype(np.uint32).tobytes(), np.uint8).astype(np.int64)
+    sh = L[:256]
     filt = L[filt_off // 4: filt_off // 4 + fwords]
     rec = L[rec_off // 4:].reshape(H + 1, 4)
     own = img[grec_off // 4: grec_off // 4 + 4 * p.S1].reshape(p.S1, 4)
@@ -452,7 +452,7 @@ def lazy_step(z, abs_min, sid, E, sh, use_abs):
             m = (int(g[2]) + pc * stride) & 0xFFFFFFFF
     if use_abs and sid >= abs_min:
         m, rep = sid, E
-    return m, rep, bool((m | rep | (sh << 24)) & SENT)
+    return m, rep, bool((m | rep | sh) & SENT)
 
 
 def check_lazy(p, want, max_pairs=None):
@@ -479,7 +479,7 @@ def check_lazy(p, want, max_pairs=None):
             t = int(want[s][by])
             if sent:
                 nsent += 1
-                nsent_bit += not (sh & 0x80)
+                nsent_bit += not (sh & SENT)
                 m, rep = t, (t if t < H else int(z["car"][t]))            # the exact path; a state beyond the LDS set is handed what it carries
             else:
                 nfast += 1
