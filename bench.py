@@ -263,7 +263,7 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
     gb = rows.size / 1e9
     nrows = len(rows)
     if workload == "c5" or not pyoracle.have_ref():
-        o = pyoracle.Oracle(flat)
+        o = get_oracle(flat)
         want = o.table_walk(rows)
         out.update(kind="port", value=round(gb / o.last_seconds, 5),
                    sample=f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, {nrows} inputs x {L} B spread over the whole batch")
@@ -296,7 +296,7 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
     t_hoist = f.last_seconds
     vm = f.vm_match_stride(rows, 2)
     t_vm = f.last_seconds
-    want = pyoracle.Oracle(flat).table_walk(rows)
+    want = get_oracle(flat).table_walk(rows)
     assert np.array_equal(end, want[fe_idx]), "oracle != reference fsm_exec"
     assert np.array_equal(hend, want[ho_idx]), "hoisted fsm_exec != fsm_exec"
     assert np.array_equal(vm == 1, want != 0xFFFFFFFF), "reference VM != fsm_exec"
@@ -331,12 +331,22 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
     return out, parity
 
 
+_ORACLES = {}
+
+
+def get_oracle(flat):
+    """one checker (and one dense table: 1 GB for the 1e5-literal automaton) per automaton and run"""
+    from oracle import pyoracle
+    if id(flat) not in _ORACLES:
+        _ORACLES[id(flat)] = pyoracle.Oracle(flat)
+    return _ORACLES[id(flat)]
+
+
 def full_parity(torch, flat, buf, end, n, L):
     """'full N compare GPU vs CPU table-walker'.  Every input is streamed back from the device
     in 2 GiB slices and walked by the oracle's dense-table walker (itself pinned to fsm_exec on every golden
     fixture) on all granted host cores; every end state must agree."""
-    from oracle import pyoracle
-    o = pyoracle.Oracle(flat)
+    o = get_oracle(flat)
     ncores, _ = host_cores()
     step = max(1, (2 << 30) // L)
     bad, t0, t_cpu = 0, time.perf_counter(), 0.0
@@ -400,7 +410,7 @@ def node_front(a):
     # every replica holds the whole bitmap; its popcount is the reduced match count
     same = all(int(np.unpackbits(m.cpu().numpy().view(np.uint8)).sum()) == cnt for m in bms[:2]) and cnt_async == cnt
     out = {"front": "fsm_hip_node_exec_batch_device (C ABI, one process, one host thread per device)", "devices": devices,
-           "uses_rccl": node.uses_rccl(), "workload": wl, "inputs_total": n, "input_len": L, "steps": a.steps,
+           "uses_rccl": node.uses_rccl(), "rccl_library": node.rccl_path(), "workload": wl, "inputs_total": n, "input_len": L, "steps": a.steps,
            "ms_per_step": round(el / a.steps * 1e3, 4), "value_GBps": round(n * L / (el / a.steps) / 1e9, 2),
            "walk_kernel_ms_per_device": per_dev_ms,
            "async_ms_per_step": round(el_async / a.steps * 1e3, 4), "async_value_GBps": round(n * L / (el_async / a.steps) / 1e9, 2),
@@ -535,6 +545,7 @@ def main():
 
         for _ in range(4):  # setup, untimed: the first launches after a long generator kernel run at ramping clocks
             dfa.exec_batch_device(buf.data_ptr(), L, n_, end.data_ptr(), bm.data_ptr(), stream=stream)
+        kernel_name = dfa.last_kernel_name()   # the library's own word for what it launched (as rocprofv3 lists it)
         for _ in range(a.warmup):
             step(False)
         drain()
@@ -556,8 +567,13 @@ def main():
         elapsed = float(el.item())
 
         acc_t = (end != -1).sum().to(torch.int64).reshape(1)
+        rank_kms = None
         if world > 1:
             dist.all_reduce(acc_t)
+            mine = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+            allk = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allk, mine)
+            rank_kms = [round(float(t.item()), 4) for t in allk]
         if rank != 0:
             dfa.close()
             return None
@@ -602,11 +618,15 @@ def main():
                              if world > 1 else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
-            "roofline": {"bound": "hbm" if wl != "c5" else "l2-gather (record gathers in flight per CU); HBM figures for uniformity",
+            **({"multi_gpu": {"walk_kernel_ms_per_rank": rank_kms,
+                              "exchange_exposed_ms_per_step": round(max(0.0, ms_step - max(rank_kms)), 4),
+                              "note": "ms_per_step minus the slowest rank's walk kernel: what the RCCL all-gather of the accept bitmap (overlapped with the next step's walk) and the host loop add"}}
+               if rank_kms else {}),
+            "roofline": {"bound": "hbm" if wl != "c5" else "instruction issue of a table walk whose table is in L2 (HBM figures for uniformity; see gather_ceiling)",
                          "achieved": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if roof_bytes is None else round(roof_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "walk (fsmhip::walk_*)", "kernel_ms_avg": round(k_ms, 4),
+                         "kernel": kernel_name, "kernel_ms_avg": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         # "also report touched bytes when early-retire is enabled".  A wavefront stops reading once all 64 of its
@@ -621,10 +641,10 @@ def main():
             "note": "HBM bytes per launch from the recorded PMC passes (reads + the 4-byte results): ~1.00 means every input byte was still fetched",
         }
         if wl == "c5":
-            res["roofline"]["note"] = ("this walk is bound by the record gathers its vector-memory pipe keeps in flight, not by HBM (DESIGN.md section 3; "
-                                       "profiles/r04p_c5_memory_pipeline.txt: 0.33 L2 requests per input byte at 231 cycles, TA busy 80 %, stalled by the L1 56 %; "
-                                       "profiles/r04m_c5_pmc_*: 35 vector + 11 scalar instructions per wave byte-step; calibrated HBM traffic 1.8x algorithmic): "
-                                       "the fraction of HBM peak is reported for uniformity only")
+            res["roofline"]["note"] = ("round 4: the lazy walk (walk_lazy.h) enters a state beyond the LDS set without fetching its record -- 0.086 L2 requests per "
+                                       "input byte where the record-as-state walk made 0.33 -- and is bound by instruction issue now, not by gathers and not by HBM "
+                                       "(profiles/r06b_c5_lazy_pmc_rows2.txt; DESIGN.md section 3): the fraction of HBM peak is reported for uniformity, "
+                                       "roofline.gather_ceiling gives the memory-side denominator")
         if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
             sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if wl == "c2" else 100_000)
             idx = sample_indices(n_, sample)
@@ -640,12 +660,30 @@ def main():
             res["parity_sample"] = f"{len(idx)} inputs: seeded stratified sample of [0, {n_}) + first/last 64 rows" + (" + rows around byte offset 2^32" if n_ > (1 << 22) + 64 else "")
             if not (parity and twin):
                 res["value"] = None  # a fast wrong answer is not a result
-        # the full-N compare, for the main workload of a default run (c5's table walker would need the 8 GB dense
-        # table; its checks are the sample above and cpu_baseline.reference_at_3e5_states)
-        if world == 1 and wl != "c5" and (a.full_parity or (variant is None and wl == a.workload and not a.no_full_parity and with_cpu and not a.no_cpu_baseline)):
+        # the full-N compare, for the main workload of a default run -- and for c5 wherever it runs (round 4: its
+        # table is 1 GB as the oracle keeps it and the cpu_baseline leg has built it already; 1e7 rows take the walker's threads
+        # about a minute)
+        if world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5"):
             res["full_parity"] = full_parity(torch, flat, buf, end, n_, L)
             if res["full_parity"]["mismatches"]:
                 res["value"] = None
+        if wl == "c5":
+            # a denominator for this walk: what the memory system gives 16-byte gathers from a table of this size at full occupancy
+            # (the walk's own-record gathers, 0.07 per input byte), and what the instruction stream allows
+            try:
+                ng = 1 << 28
+                gms = hip.gather_probe_ms(buf.data_ptr(), 18 << 20, ng, 16, bm.data_ptr(), stream)
+                per_byte = 0.068
+                res["roofline"]["gather_ceiling"] = {
+                    "probe": "fsm_hip_gather_probe_ms: 2^28 independent 16-byte gathers over an 18 MB window, 8 workgroups of 256 per CU",
+                    "gathers_per_second": round(ng / gms * 1e3, 0), "walk_gathers_per_input_byte": per_byte,
+                    "walk_gathers_source": "profiles/r06b_c5_lazy_pmc_rows2.txt: TCP_TCC_READ_REQ 0.086 per input byte, 0.016 of them the input's own lines",
+                    "implied_GBps": round(ng / gms * 1e3 / per_byte / 1e9, 1),
+                    "note": "the walk is not at this ceiling: with 25 vector instructions per input byte-step it is bound by instruction issue "
+                            "(VALU 55-60 % busy, LDS 51 %, TA 56 %: profiles/r06b_c5_lazy_pmc_rows2.txt); the issue ceiling at 4 cycles per wave64 "
+                            "instruction is ~1.3 TB/s"}
+            except Exception as e:  # noqa: BLE001
+                res["roofline"]["gather_ceiling"] = {"error": repr(e)[:200]}
         res["_buf"] = (buf, bm)
         # a digest of all n end states: a variant run over the same inputs (noskip, loadskip) must reproduce the main run's
         res["_digest"] = (int(end.to(torch.int64).sum().item()), int((end.to(torch.int64) * (torch.arange(n_, device="cuda", dtype=torch.int64) % 1000003 + 1)).sum().item()),
@@ -737,7 +775,7 @@ def main():
             tidx = torch.from_numpy(idx).cuda()
             srows = rows[tidx][:, :hi].cpu().numpy() if hi <= 64 else rows[tidx].cpu().numpy()
             slens = lens[tidx].cpu().numpy().astype(np.uint32)
-            o = pyoracle.Oracle(flat)
+            o = get_oracle(flat)
             want = o.table_walk(srows, slens)
             got = end[tidx].cpu().numpy().view(np.uint32)
             # ... and the packed copy holds those bytes (spot check)
@@ -818,7 +856,9 @@ def main():
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--node-front", "--workload", a.workload, "--steps", str(a.steps),
                    "--warmup", str(a.warmup), "--len", str(L)]
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)   # never run on real multi-GPU hardware yet: bounded
+            # bounded, but generously: every device first generates its own 100 GB of inputs, and the first RCCL communicator
+            # of a process takes tens of seconds to come up
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600 + 120 * torch.cuda.device_count())
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             res["node_front"] = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
         except Exception as e:  # noqa: BLE001

@@ -413,6 +413,10 @@ void fsm_hip_node_shard(const struct fsm_hip_node *node, size_t n, int k, size_t
 /* 1 if the device-resident exchange below runs over RCCL (distinct devices, librccl present), 0 if it is done
  * with peer-to-peer copies */
 int fsm_hip_node_uses_rccl(const struct fsm_hip_node *node);
+/* The shared object the node front's RCCL entry points were bound from (dlopen + dladdr; "" before the first node that
+ * wanted RCCL, or when there is none): a process that has torch's RCCL bundle mapped binds that one, a plain C host
+ * /opt/rocm/lib's. */
+const char *fsm_hip_node_rccl_path(void);
 
 /* fsm_hip_exec_batch / _offsets over the whole node: same arguments, same results.  Every device stages its
  * own slice from the caller's pages and copies its results straight into the caller's arrays at the shard's

@@ -687,6 +687,10 @@ class HipNode:
     def uses_rccl(self) -> bool:
         return bool(self._lib.fsm_hip_node_uses_rccl(C.c_void_p(self._h)))
 
+    def rccl_path(self) -> str:
+        self._lib.fsm_hip_node_rccl_path.restype = C.c_char_p
+        return (self._lib.fsm_hip_node_rccl_path() or b"").decode()
+
     def replica(self, k: int) -> "HipDfa":
         """Borrowed view of the k-th replica (do not close it)."""
         h = self._lib.fsm_hip_node_dfa(C.c_void_p(self._h), C.c_int(k))
@@ -866,6 +870,16 @@ def gen_pack_rows_device(d_rows: int, stride: int, d_len: int, d_off: int, n: in
     if lib.fsm_hip_gen_pack_rows_device(C.c_void_p(d_rows), C.c_size_t(stride), C.c_void_p(d_len), C.c_void_p(d_off), C.c_size_t(n),
                                         C.c_size_t(max_len), C.c_void_p(d_out), C.c_void_p(stream or None)) != 0:
         raise _oserr("fsm_hip_gen_pack_rows_device")
+
+
+def gather_probe_ms(d_base: int, nbytes: int, ngathers: int, vec_bytes: int, d_scratch4: int, stream: int = 0) -> float:
+    """fsm_hip_gather_probe_ms: one launch of `ngathers` independent vec_bytes-byte loads at pseudo-random offsets of the buffer."""
+    lib = load_library()
+    lib.fsm_hip_gather_probe_ms.restype = C.c_double
+    ms = lib.fsm_hip_gather_probe_ms(C.c_void_p(d_base), C.c_size_t(nbytes), C.c_size_t(ngathers), C.c_int(vec_bytes), C.c_void_p(d_scratch4), C.c_void_p(stream or None))
+    if ms < 0:
+        raise _oserr("fsm_hip_gather_probe_ms")
+    return float(ms)
 
 
 def pack_affixes(items: Sequence[bytes]) -> np.ndarray:

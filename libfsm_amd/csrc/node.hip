@@ -45,6 +45,7 @@ struct rccl_api {
 };
 static rccl_api R;
 static std::once_flag rccl_once;
+static char rccl_path[512] = "";   /* the shared object ncclAllGather was bound from (dladdr): a torch process has its own bundle mapped */
 
 static void rccl_resolve()
 {
@@ -58,6 +59,8 @@ static void rccl_resolve()
 	*(void **)&R.GroupStart = dlsym(h, "ncclGroupStart");
 	*(void **)&R.GroupEnd = dlsym(h, "ncclGroupEnd");
 	R.state = R.CommInitAll && R.CommDestroy && R.AllGather && R.AllReduce && R.GroupStart && R.GroupEnd ? 1 : -1;
+	Dl_info di;
+	if (R.AllGather != nullptr && dladdr((void *)R.AllGather, &di) != 0 && di.dli_fname != nullptr) snprintf(rccl_path, sizeof rccl_path, "%s", di.dli_fname);
 }
 
 /* one parked host thread per device (but device 0's shard, which the calling thread drives): created with the node,
@@ -215,6 +218,8 @@ extern "C" struct fsm_hip_node *fsm_hip_node_create(const struct fsm_hip_dfa_des
 extern "C" int fsm_hip_node_ndev(const struct fsm_hip_node *nd) { return nd == nullptr ? 0 : (int)nd->dev.size(); }
 
 extern "C" int fsm_hip_node_uses_rccl(const struct fsm_hip_node *nd) { return nd != nullptr && !nd->comm.empty(); }
+
+extern "C" const char *fsm_hip_node_rccl_path(void) { return rccl_path; }
 
 extern "C" struct fsm_hip_dfa *fsm_hip_node_dfa(struct fsm_hip_node *nd, int k)
 {
