@@ -73,3 +73,53 @@ def test_re_l_hip_is_the_automaton_the_reference_builds(printers, tmp_path):
     # an NFA cannot be flattened: the printer fails like any other that needs a DFA
     out = subprocess.run([printers[1], "-r", "pcre", "-n", "-l", "hip", "a|ab"], capture_output=True, timeout=120)
     assert out.returncode != 0 and out.stdout[:6] != b"FSMHIP"
+
+
+def test_ir_flattening_equals_walk_edges_flattening(printers, tmp_path):
+    """The IR consumer (integration/print/print_hip_ir.c: libfsm's codegen IR -- strategy, groups of ranges, mode, error
+    ranges -- expanded the way the VM compiler's dfa_table does it, vm/ir.c:649-750) against the shim's flattening through
+    fsm_walk_edges, on every DFA of the reference's regex-dialect corpus (tests/{pcre,...}/out*.fsm, determinised and
+    minimised first where the fixture is an NFA) and on the 1 024-pattern union of configs[2]."""
+    import glob
+    check = os.path.join(os.path.dirname(printers[0]), "irflat_check")
+    if not os.path.exists(check):
+        pytest.skip("integration/_build/print/irflat_check not built")
+    ref = "/root/reference/tests"
+    files = sorted(f for d in ("pcre", "pcre-anchor", "pcre-flags", "pcre-repeat", "native", "glob", "like", "literal", "sql")
+                   for f in glob.glob(os.path.join(ref, d, "out*.fsm")))
+    if len(files) < 200:
+        pytest.skip("the reference's fixture corpus is not on this machine")
+    out = subprocess.run([check, "-d"] + files, capture_output=True, text=True, timeout=600)
+    tail = out.stdout.strip().splitlines()[-1]
+    nok, nbad, nskip = (int(x) for x in __import__("re").findall(r"\d+", tail))
+    assert out.returncode == 0 and nbad == 0 and nok >= 240 and nok + nskip == len(files), tail
+    # configs[2]: rx unions the 1 024 patterns and prints the DFA through the IR consumer; the table read back must accept
+    # exactly what the golden automaton (flattened from the reference's own union by tests/golden/make_golden.py through
+    # fsm_walk_edges) accepts, with the same end-id sets
+    import libfsm_amd as hip
+    from oracle.pyoracle import Oracle
+    from common import Golden, GOLDEN
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+    pf = tmp_path / "patterns"
+    pf.write_bytes(b"\n".join(pats) + b"\n")
+    out = subprocess.run([printers[0], "-u", "-l", "hip", str(pf)], capture_output=True, timeout=600)
+    assert out.returncode == 0 and out.stdout[:6] == b"FSMHIP", out.stderr[-300:]
+    (tmp_path / "c3.fsmhip").write_bytes(out.stdout)
+    flat = hip.FlatDfa.read_c(str(tmp_path / "c3.fsmhip"))
+    assert abs(flat.nstates - g.flat.nstates) <= 2      # (rx keeps a state the golden's minimisation dropped)
+    rng = np.random.RandomState(8)
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    lines = []
+    for i in range(6000):
+        if i % 2:
+            p = pats[rng.randint(len(pats))]
+            lines.append(p[1:p.index(b"[")] + bytes(rng.randint(48, 58, rng.randint(1, 40)).astype(np.uint8)) + (b"x" if rng.randint(2) else b"yz"))
+        else:
+            lines.append(bytes(a[rng.randint(0, len(a), rng.randint(0, 50))]))
+    o1, o2 = Oracle(flat), Oracle(g.flat)
+    r1, e1 = o1.exec_strings(lines)
+    r2, e2 = o2.exec_strings(lines)
+    assert np.array_equal(r1, r2) and (r1 == 1).sum() > 2500
+    for i in np.nonzero(r1 == 1)[0][:1500]:
+        assert list(o1.endids(int(e1[i]))) == list(o2.endids(int(e2[i])))
