@@ -97,6 +97,7 @@ enum {
 	FSM_HIP_LAYOUT_COMBSELF = 6, /* comb + self-loop mask per state (<= 32 classes) */
 	FSM_HIP_LAYOUT_SPARSE = 7,   /* base-row records (failure-link form) in HBM/L2, hottest in LDS */
 	FSM_HIP_LAYOUT_LDSSELF = 8,  /* dense table in LDS + self-loop mask per state (<= 32 classes) */
+	FSM_HIP_LAYOUT_LDS2   = 9,   /* dense table over PAIRS of byte classes in LDS: one lookup per two input bytes (plain walks) */
 	FSM_HIP_LAYOUT_MASK   = 0xf,
 	FSM_HIP_NO_EARLY_RETIRE = 0x10  /* never stop a wavefront early on absorbing states */
 };

@@ -19,9 +19,9 @@ NO_ID = 0xFFFFFFFE
 STATE_START = 0xFFFFFFFD
 STATE_DEAD = 0xFFFFFFFC
 
-LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_SPARSE, LAYOUT_LDSSELF = 0, 1, 2, 3, 4, 5, 6, 7, 8
-LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself", 7: "sparse", 8: "ldsself"}
-ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_COMB256, LAYOUT_LDSSELF, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
+LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_SPARSE, LAYOUT_LDSSELF, LAYOUT_LDS2 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself", 7: "sparse", 8: "ldsself", 9: "lds2"}
+ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_LDS2, LAYOUT_COMB256, LAYOUT_LDSSELF, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
 
 KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11

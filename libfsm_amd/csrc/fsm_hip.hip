@@ -272,6 +272,21 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			d->table_lds = lds_bytes_btab() + ((a.tab_bytes + 15u) & ~15u);
 			break;
 		}
+		case FSM_HIP_LAYOUT_LDS2: {
+			uint16_t *t = nullptr;
+			HIP_TRY(upload(&t, p.lds_tab));
+			d->d_tab = t;
+			HIP_TRY(upload(&d->d_fin, p.fin));
+			for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
+			const uint32_t row = p.lds2_c1 * p.lds2_c1;      /* entries per state: the walk's state is state * row */
+			a.tab_bytes = (uint32_t)(p.lds_tab.size() * 2);
+			a.start = p.start * row;
+			a.abs_min = p.abs_min * row;
+			a.fin_div = row;
+			a.dflt = p.lds2_c1;
+			d->table_lds = Lds2Pol::lds_bytes(a.tab_bytes);
+			break;
+		}
 		case FSM_HIP_LAYOUT_LDSSELF: {
 			uint16_t *t = nullptr;
 			HIP_TRY(upload(&t, p.lds_tab));
@@ -354,6 +369,7 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 			case FSM_HIP_LAYOUT_SPARSE: d->enc_host[n2] = n2; break;
 			case FSM_HIP_LAYOUT_LDS:
 			case FSM_HIP_LAYOUT_LDSSELF: d->enc_host[n2] = n2 * p.row_bytes; break;
+			case FSM_HIP_LAYOUT_LDS2: d->enc_host[n2] = n2 * p.lds2_c1 * p.lds2_c1; break;
 			case FSM_HIP_LAYOUT_COMB:
 			case FSM_HIP_LAYOUT_COMBSELF: d->enc_host[n2] = p.comb_off[n2]; break;
 			case FSM_HIP_LAYOUT_COMB256: d->enc_host[n2] = p.comb256_off[n2]; break;
@@ -585,6 +601,7 @@ static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg
 	case FSM_HIP_LAYOUT_TINY:     return launch_tiny(p.tiny5_col.empty() ? POL_TINY64 : POL_TINY5, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_LDS:      return launch_lds(POL_LDS, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_LDSSELF:  return launch_lds(POL_LDSSELF, eager, c, a, grid, block, s);
+	case FSM_HIP_LAYOUT_LDS2:     return launch_lds(POL_LDS2, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_COMB:     return launch_comb(POL_COMB, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_COMB256:  return launch_comb(POL_COMB256, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_COMBSELF: return launch_comb(POL_COMBSELF, eager, c, a, grid, block, s);
@@ -1032,6 +1049,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	switch (p.layout) {
 	case FSM_HIP_LAYOUT_TINY: out->table_bytes = p.tiny5_col.empty() ? 256 * 8 : 256 * 4; break;
 	case FSM_HIP_LAYOUT_LDS:
+	case FSM_HIP_LAYOUT_LDS2:
 	case FSM_HIP_LAYOUT_LDSSELF: out->table_bytes = p.lds_tab.size() * 2; break;
 	case FSM_HIP_LAYOUT_COMB: out->table_bytes = p.comb.size() * 4 + 1024; break;
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;

@@ -29,7 +29,7 @@ struct LaunchCfg {
 /* which policy of a family */
 enum {
 	POL_TINY5 = 0, POL_TINY64 = 1,
-	POL_LDS = 0, POL_LDSSELF = 1,
+	POL_LDS = 0, POL_LDSSELF = 1, POL_LDS2 = 2,
 	POL_COMB = 0, POL_COMB256 = 1, POL_COMBSELF = 2,
 	POL_GLOB = 0, POL_SPARSE = 1
 };

@@ -270,6 +270,27 @@ try {
 		p.layout = FSM_HIP_LAYOUT_LDS;
 		return 0;
 	};
+	/* LDS2: the dense table over PAIRS of classes -- one LDS lookup per TWO input bytes.  The lookup layouts are bound by
+	 * the LDS array (a wave's 64 random table reads are replayed for every bank conflict: 62-81 % busy at one read per
+	 * byte, profiles/r04f_*): halving the reads is the one lever that moves them.  (S + 1) * (C + 1)^2 entries of 16 bits:
+	 * up to ~60 Ki entries (300 states x 13 classes, 1000 x 7) beside 16 waves of per-lane input loads.  Plain walks only
+	 * (an eager walk must see every state entered). */
+	auto emit_lds2 = [&]() -> int {
+		const uint64_t C1 = (uint64_t)C + 1u, entries = (uint64_t)S1 * C1 * C1;
+		if (has_eager || entries > 61440u || entries * 2u + 256u + 16u * 1024u > lds_limit) return ENOTSUP;
+		p.lds2_c1 = (uint32_t)C1;
+		p.row_bytes = (uint32_t)(C1 * C1 * 2u);
+		p.lds_tab.assign((size_t)entries, 0);
+		auto d1 = [&](uint32_t n, uint32_t c) { return c < C ? p.dense[(size_t)n * C + c] : n; };
+		for (uint32_t n = 0; n < S1; n++)
+			for (uint32_t c1 = 0; c1 < C1; c1++) {
+				const uint32_t m = d1(n, c1);
+				for (uint32_t c2 = 0; c2 < C1; c2++)
+					p.lds_tab[((size_t)n * C1 + c1) * C1 + c2] = (uint16_t)(d1(m, c2) * (uint32_t)(C1 * C1));
+			}
+		p.layout = FSM_HIP_LAYOUT_LDS2;
+		return 0;
+	};
 	auto emit_comb = [&]() -> int {
 		uint32_t max_entries = lds_room > 1024u ? (uint32_t)std::min<uint64_t>((lds_room - 1024u) / 4u, 65535u) : 0u;
 		int r = build_comb(p, max_entries, false);
@@ -365,6 +386,7 @@ try {
 	case FSM_HIP_LAYOUT_LDSSELF: return emit_ldsself();
 	case FSM_HIP_LAYOUT_TINY:   return emit_tiny();
 	case FSM_HIP_LAYOUT_LDS:    return emit_lds();
+	case FSM_HIP_LAYOUT_LDS2:   return emit_lds2();
 	case FSM_HIP_LAYOUT_COMB:   return emit_comb();
 	case FSM_HIP_LAYOUT_GLOBAL: return emit_glob();
 	case FSM_HIP_LAYOUT_COMB256: return emit_comb256();
@@ -374,6 +396,8 @@ try {
 		/* many states sit in self-loops ([0-9]+, .*): bytes that do not change the state then
 		 * cost one conflict-free lookup (CombSelfPol) */
 		if (p.selfloop_fraction >= 0.15 && emit_combself() == 0) return 0;
+		/* one lookup per two bytes where the pair table fits: ahead of every one-lookup-per-byte layout */
+		if (emit_lds2() == 0) return 0;
 		if (emit_comb256() == 0) return 0;
 		if (p.selfloop_fraction >= 0.15 && emit_ldsself() == 0) return 0;
 		if (emit_lds() == 0) return 0;

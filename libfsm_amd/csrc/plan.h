@@ -57,6 +57,10 @@ struct Plan {
 	 * entry = next_state * (row_bytes/4)                                   */
 	std::vector<uint16_t> lds_tab;
 	uint32_t row_bytes = 0;
+	/* LDS2 (stride 2): lds_tab[state][c1 * C1 + c2] = row index of delta(delta(state, c1), c2) in ENTRIES (state * C1 * C1),
+	 * C1 = C + 1: class C is "no byte", the identity of every state -- T[s][c][C] = delta(s, c) serves an odd byte, the bytes
+	 * beyond an input's end are given class C.  row_bytes = C1 * C1 * 2. */
+	uint32_t lds2_c1 = 0;
 	/* COMB: column default + exception comb.
 	 * comb entry = (owner_off << 16) | next_off  where *_off are the comb
 	 * row offsets (in entries) of the owning / destination state;

@@ -319,6 +319,49 @@ struct LdsPol {
 };
 
 /*
+ * Lds2Pol: the dense table over PAIRS of byte classes (plan.cpp emit_lds2): T[state][c1 * C1 + c2] = the state two bytes on,
+ * as a row index in entries.  A 16-byte chunk is 8 lookups instead of 16 -- the lookup layouts are bound by the LDS array,
+ * whose 64 random reads per wave are replayed for every bank conflict -- and the dependent chain per TWO bytes is one
+ * add-shift and one ds_read_u16.  Class C ("no byte") is the identity: it serves a lone byte (next()) and the bytes beyond
+ * an input's end (step16_part_ident).
+ */
+struct Lds2Pol {
+	static constexpr bool heavy_next = false;
+	typedef uint32_t P;          /* byte class */
+	typedef uint32_t S;          /* row index in entries: state * C1 * C1 */
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	const uint8_t *bp;           /* LDS byte -> class map */
+	const unsigned char *tab;    /* LDS table */
+	uint32_t C1, ident, abs_min;
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		tab = lds + FSMHIP_BTAB_BYTES;
+		C1 = a.dflt;             /* C + 1 */
+		ident = C1 - 1u;
+		abs_min = absorbing_limit(a);
+	}
+	__device__ __forceinline__ bool ident_ok() const { return true; }
+	__device__ __forceinline__ bool absorbing(S s) const { return s >= abs_min; }
+	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
+	__device__ __forceinline__ S pair(S st, P c1, P c2) const
+	{
+		return *reinterpret_cast<const uint16_t *>(tab + ((st + (c1 * C1 + c2)) << 1));
+	}
+	__device__ __forceinline__ S next(S st, P c) const { return pair(st, c, ident); }
+	__device__ __forceinline__ void walk16(S &st, const P (&pre)[16]) const
+	{
+#pragma unroll
+		for (int k = 0; k < 16; k += 2) st = pair(st, pre[k], pre[k + 1]);
+	}
+};
+
+/*
  * LdsSelfPol: LdsPol plus the self-loop mask of the current state in a register (the planner stores it
  * after each row).  Bytes whose class is a self-loop of the state cost no table lookup, whole chunks of
  * them are skipped with one wave vote (skip16), and -- unlike the comb layouts -- states keep their
@@ -349,6 +392,7 @@ struct LdsSelfPol {
 		ident = a.ident_class;
 		skip_on = !(a.early & 4u);
 	}
+	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
 	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, mask_of(code) }; return s; }
 	__device__ __forceinline__ static uint32_t code(const S &s) { return s.st; }
@@ -476,6 +520,7 @@ struct CombSelfPol {
 		ident = a.ident_class;
 		skip_on = !(a.early & 4u);
 	}
+	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
 	/* every input starts from the start state unless it is resumed: its mask is fetched once per
 	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
 	__device__ __forceinline__ S init(uint32_t code) const
@@ -1399,7 +1444,7 @@ template <class Pol>
 __device__ __forceinline__ auto step16_part_ident(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t lo, uint32_t cnt, int)
 	-> decltype(pol.ident, bool())
 {
-	if (pol.ident >= 32u) return false;
+	if (!pol.ident_ok()) return false;
 	typename Pol::P pre[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
@@ -1407,8 +1452,7 @@ __device__ __forceinline__ auto step16_part_ident(const Pol &pol, typename Pol::
 		pre[k] = ((uint32_t)k - lo) < cnt ? c : (typename Pol::P)pol.ident;
 	}
 	if (skip_chunk(pol, st, pre, 0)) return true;
-#pragma unroll
-	for (int k = 0; k < 16; k++) st = pol.next(st, pre[k]);
+	walk_chunk(pol, st, pre, 0);      /* the policy's own chunk walk if it has one (Lds2Pol: pairs), else 16 x next() */
 	return true;
 }
 template <class Pol>

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from common import Golden, all_golden_paths, golden_id
-from libfsm_amd import (ALL_LAYOUTS, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_LDSSELF, LAYOUT_SPARSE, LAYOUT_TINY,
+from libfsm_amd import (ALL_LAYOUTS, LAYOUT_LDS2, LAYOUT_COMB, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_GLOBAL, LAYOUT_LDS, LAYOUT_LDSSELF, LAYOUT_SPARSE, LAYOUT_TINY,
                         FlatDfa, Plan)
 
 NO = 0xFFFFFFFF
@@ -196,6 +196,25 @@ def check_plan(flat, layout):
             bits = (sm[:, None] >> np.arange(Cn)[None, :]) & 1
             assert np.array_equal(bits[~absorbing].astype(bool), loops[~absorbing])
             assert (sm[absorbing] == 0xFFFFFFFF).all()
+    elif p.layout == LAYOUT_LDS2:
+        # stride 2: T[state][c1 * C1 + c2] = row index (entries) of the state two bytes on; class C is the identity.
+        # Every (state, byte) through the single-byte form next() = pair(c, ident); every state x a sample of byte PAIRS
+        # (and (ident, byte), (ident, ident)) through the pair form
+        tab = p.get("lds_tab").astype(np.int64)
+        C1 = Cn + 1
+        row = C1 * C1
+        assert p.row_bytes == row * 2 and len(tab) == S1 * row and S1 * row <= 61440
+        base = np.arange(S1)[:, None] * row
+        e = tab[base + cls[bytes_][None, :] * C1 + Cn]
+        assert (e % row == 0).all()
+        got = e // row
+        rng2 = np.random.RandomState(S1)
+        b1, b2 = rng2.randint(0, 256, 400), rng2.randint(0, 256, 400)
+        e2 = tab[base + (cls[b1] * C1 + cls[b2])[None, :]] // row
+        mid = want[:, b1]                                                   # [S1][400]: the state after the first byte
+        assert np.array_equal(e2, want[mid, b2[None, :]])
+        assert np.array_equal(tab[base[:, 0] + Cn * C1 + Cn] // row, np.arange(S1))
+        assert np.array_equal(tab[base + (Cn * C1 + cls[bytes_])[None, :]] // row, want)
     elif p.layout in (LAYOUT_COMB, LAYOUT_COMBSELF):
         comb = p.get("comb").astype(np.int64)
         off = p.get("comb_off").astype(np.int64)
