@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged"],
+                    help="c*_short / c*_ragged: the packed-lines front alone (what the default run reports as sub_results), for profiling")
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
     ap.add_argument("--n", "--inputs", dest="n", type=int, default=0,
@@ -738,16 +739,18 @@ def main():
 
         wall, k_ms = timed("off64_end", lambda: dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n_l, end.data_ptr(), 0, stream=stream), 8, 4)
         ok_forms = True
-        if off32 is not None:
+        only64 = os.environ.get("FSM_BENCH_LINES_FORMS") == "off64"      # profiling runs: one kernel, one form
+        if off32 is not None and not only64:
             timed("off32_end", lambda: dfa.exec_batch_offsets32_device(packed.data_ptr(), off32.data_ptr(), n_l, end2.data_ptr(), 0, stream=stream), 4, 4)
             ok_forms = ok_forms and bool(torch.equal(end, end2))
         end2.fill_(7)
         # lengths only: the pre-pass reads the lengths once more (4 B) and writes 8 B per 64 lines; its time is inside ms_per_step, not kernel_ms
-        timed("len_end", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, end2.data_ptr(), 0, stream=stream), 8.125, 4)
-        ok_forms = ok_forms and bool(torch.equal(end, end2))
-        timed("len_bitmap", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, 0, bm.data_ptr(), stream=stream), 8.125, 0.125)
+        if not only64:
+            timed("len_end", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, end2.data_ptr(), 0, stream=stream), 8.125, 4)
+            ok_forms = ok_forms and bool(torch.equal(end, end2))
+            timed("len_bitmap", lambda: dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n_l, 0, bm.data_ptr(), stream=stream), 8.125, 0.125)
         acc = int((end != -1).sum().item())
-        ok_forms = ok_forms and bool(np.array_equal(np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n_l].astype(bool), (end != -1).cpu().numpy()))
+        ok_forms = ok_forms and (only64 or bool(np.array_equal(np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n_l].astype(bool), (end != -1).cpu().numpy())))
         info = dfa.info()
         f0 = forms["off64_end"]
         res = {"workload": f"{wl}_{kind}", "value": f0["walked_GBps"], "unit": "GB/s of line bytes walked", "ms_per_step": f0["ms_per_step"],
@@ -792,6 +795,15 @@ def main():
         del packed, off, lens, end2, bm
         return res
 
+    if "_" in a.workload:       # the packed-lines front alone
+        wl, kind = a.workload.split("_")
+        r = run_lines(wl, kind)
+        r.update(metric="input GB/s matched (whole node)", n_gpus=world, steps=a.steps, warmup=a.warmup, higher_is_better=True, scaling=a.scaling,
+                 vs_baseline=None, dtype="u8", data="synthetic")
+        r["config"]["inputs_per_gpu"] = r["config"]["lines"]
+        r["config"]["input_len"] = r["config"]["mean_len"]
+        print(json.dumps(r), flush=True)
+        return
     main_res = run(a.workload)
     subs = []
     if world == 1 and a.subs == "auto" and a.n == 0 and not shrunk:

@@ -393,11 +393,13 @@ try {
 	case FSM_HIP_LAYOUT_COMBSELF: return emit_combself();
 	case FSM_HIP_LAYOUT_AUTO:
 		if (emit_tiny() == 0) return 0;
+		/* one lookup per two bytes where the pair table fits: ahead of every one-lookup-per-byte layout, the self-loop
+		 * ones included -- those walk self-loop runs at 6 TB/s but a transition-dense input at 1.2 (profiles/
+		 * r06f_lds2_probe.txt: 107 states, 21 classes), the pair table 4.6-4.75 whatever the input */
+		if (emit_lds2() == 0) return 0;
 		/* many states sit in self-loops ([0-9]+, .*): bytes that do not change the state then
 		 * cost one conflict-free lookup (CombSelfPol) */
 		if (p.selfloop_fraction >= 0.15 && emit_combself() == 0) return 0;
-		/* one lookup per two bytes where the pair table fits: ahead of every one-lookup-per-byte layout */
-		if (emit_lds2() == 0) return 0;
 		if (emit_comb256() == 0) return 0;
 		if (p.selfloop_fraction >= 0.15 && emit_ldsself() == 0) return 0;
 		if (emit_lds() == 0) return 0;

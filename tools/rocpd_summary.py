@@ -15,27 +15,61 @@ import sqlite3
 import sys
 
 
-def rows(db, sql):
+def rows(db, sql, params=()):
     con = sqlite3.connect(db)
     cur = con.cursor()
-    cur.execute(sql)
+    cur.execute(sql, params)
     cols = [d[0] for d in cur.description]
     return [dict(zip(cols, r)) for r in cur.fetchall()]
+
+
+def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib):
+    """The packed-lines front (bench.py --workload c3_short ...): algorithmic bytes = sum(len) + 8 B offsets + 4 B result per line.
+    The lines are read by per-lane 16-byte buffer loads at 36-byte (short) or 512-byte (ragged) mean pitch, not by the
+    16-byte-per-lane coalesced stream the x2 correction of FETCH_SIZE was calibrated on: the raw counter is taken at face value
+    when it already covers >= 0.75 of the bytes that must be read, doubled otherwise -- both figures are recorded."""
+    n = bench["config"]["lines"]
+    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+    must_read = bench["config"]["line_bytes"] + 8 * n
+    raw = fetch_kib * 1024
+    read = raw if raw >= 0.75 * must_read else 2 * raw
+    hbm = read + write_kib * 1024
+    summary = {
+        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline (FSM_BENCH_LINES_FORMS=off64; then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
+        "bench_line_under_trace": bench,
+        "kernel_stats_top": [{"name": t["name"][:120], "calls": t["total_calls"], "avg_us": round(t["average"], 1), "pct": round(t["percentage"], 2)} for t in top[:5]],
+        "walk_kernel": {"name": walk["name"], "calls": walk["total_calls"], "avg_ms": round(walk["average"] / 1e3, 4),
+                        "algorithmic_GBps": round(alg / (walk["average"] * 1e-6) / 1e9, 1)},
+        "pmc": {"FETCH_SIZE_KiB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": pmc["WRITE_SIZE"], "fetch_bytes_raw": raw, "fetch_bytes_doubled": 2 * raw,
+                "read_bytes_taken": read, "bytes_that_must_be_read": must_read, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+                "traffic_over_algorithmic": round(hbm / alg, 4)},
+    }
+    json.dump(summary, open(out + "_rocprof_summary.json", "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+    w_, kind = wl.split("_")
+    json.dump({"n": n, "hbm_bytes_per_launch": hbm, "kernel": walk["name"], "kernels_sha16": B.kernels_sha16(), "source": os.path.basename(out) + "_rocprof_summary.json"},
+              open(os.path.join(os.path.dirname(out), f"pmc_{w_}_{kind}.json"), "w"))
+    print(json.dumps(summary["walk_kernel"]), json.dumps(summary["pmc"]["traffic_over_algorithmic"]))
 
 
 def main():
     prof, wl, out = sys.argv[1:4]
     bench = json.loads(open(os.path.join(prof, "bench_trace.json")).read().strip().splitlines()[-1])
     top = rows(glob.glob(os.path.join(prof, "trace", "*.db"))[0], "select name, total_calls, total_duration, average, percentage from top_kernels")
-    walk = [t for t in top if "walk_" in t["name"]][0]
+    walk = sorted([t for t in top if "walk_" in t["name"]], key=lambda t: -t["total_duration"])[0]   # (the device-side choice launches two: the one that ran)
     pmc = {}
     for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        r = rows(glob.glob(os.path.join(prof, which, "*.db"))[0],
-                 f"select name, counter_name, counter_value, duration from pmc_events where counter_name = '{ctr}' and name like '%walk_%'")
+        db = glob.glob(os.path.join(prof, which, "*.db"))[0]
+        r = rows(db, f"select name, counter_name, counter_value, duration from pmc_events where counter_name = '{ctr}' and name = ?", (walk["name"],))
+        if not r:
+            r = rows(db, f"select name, counter_name, counter_value, duration from pmc_events where counter_name = '{ctr}' and name like '%walk_%'")
         pmc[ctr] = [x["counter_value"] for x in r]
     n, L = bench["config"]["inputs_per_gpu"], bench["config"]["input_len"]
     fetch_kib = sum(pmc["FETCH_SIZE"]) / len(pmc["FETCH_SIZE"])
     write_kib = sum(pmc["WRITE_SIZE"]) / len(pmc["WRITE_SIZE"])
+    if "lines" in bench["config"]:
+        return lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib)
     # Read side.  gfx950 tallies a 128-byte request of a 16-byte-per-lane coalesced stream as 64 bytes
     # (MI355X_MICROARCH.md section HBM): the streamed input, n * L bytes, shows up as n * L / 2.  A gather that
     # misses is ONE 64-byte request tallied as 64 bytes (tools/fetch_calib.py, profiles/r02e_fetch_calib.json:
