@@ -172,6 +172,14 @@ int fsm_hip_exec_batch_offsets_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, const uint64_t *d_off, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
 
+/* Every output of one batch from ONE walk (device pointers, asynchronous): end states and / or the accept bitmap (as
+ * fsm_hip_exec_batch_device), device-side end-ids (ids_mode = FSM_HIP_IDS_*, d_id_out: as fsm_hip_exec_batch_ids_device) and
+ * eager-output sets (d_eager_out: as fsm_hip_exec_batch_eager_device), whichever pointers are not NULL.  Rows with a
+ * stride (+ d_len) or packed with d_off (then stride is ignored and d_len must be NULL). */
+int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream);
+
 /* Compact metadata for packed inputs (round 4).  The generated matchers of the reference take a line as a (b, e)
  * pointer pair (src/libfsm/print/c.c:569-619) and retest / reperf hand lines over one by one (src/retest/main.c:1114,
  * src/retest/reperf.c:772-784): a batch of them is bytes packed back to back plus, per line, 8 bytes of u64 offsets

@@ -1818,6 +1818,52 @@ extern "C" int fsm_hip_exec_batch_eager_offsets_device(const struct fsm_hip_dfa 
 	return eager_device(d, d_base, 0, nullptr, d_off, n, d_end_out, d_eager_out, hip_stream, BatchHint());
 }
 
+/* Every output of one batch from ONE walk: end states and / or the accept bitmap, device-side end-ids (ids_mode, d_id_out) and
+ * eager sets (d_eager_out), whichever are asked for -- the walk kernels write all of them in one pass (the multi-device front used
+ * to launch one walk per output) */
+extern "C" int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (d == nullptr || (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0) || (d_off != nullptr && d_len != nullptr)) { errno = EINVAL; return -1; }
+	if (d_id_out != nullptr) {
+		if (ids_mode != FSM_HIP_IDS_EARLIEST && ids_mode != FSM_HIP_IDS_RET && ids_mode != FSM_HIP_IDS_ERROR) { errno = EINVAL; return -1; }
+		if (ensure_ids(d) != 0) return -1;
+		if (ids_mode == FSM_HIP_IDS_ERROR) {
+			if (d->ids_conflict != FSM_HIP_NO_MATCH) { errno = EINVAL; return -1; }
+			ids_mode = FSM_HIP_IDS_EARLIEST;
+		}
+	}
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	WalkArgs a = d->proto;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = d_off ? 0 : stride;
+	a.len = d_off ? nullptr : d_len;
+	a.off = d_off;
+	a.n = n;
+	a.end_out = d_end_out;
+	a.bitmap = d_accept_bitmap;
+	if (d_id_out != nullptr) {
+		a.fin2 = ids_mode == FSM_HIP_IDS_EARLIEST ? d->d_fin_earliest : d->d_fin_ret;
+		a.out2 = d_id_out;
+	}
+	if (d_eager_out != nullptr) {
+		if (d->plan.emask.empty() || d->plan.eager_words > 1) {
+			/* no state emits anything: all zeros; wide sets are OR-ed in place: start from zero */
+			const size_t w = d->plan.emask.empty() ? 1 : d->plan.eager_words;
+			hipError_t e = hipMemsetAsync(d_eager_out, 0, n * w * sizeof(uint64_t), s);
+			if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+		}
+		if (!d->plan.emask.empty()) a.eager_out = d_eager_out;
+	}
+	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
+	return launch_walk(d, a, fast, s, BatchHint());
+}
+
 static int eager_host(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n,
 	uint32_t *end_out, uint64_t *eager_out)
 {

@@ -61,7 +61,11 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 {
 	walk_fn k = nullptr;
 	switch (c.mode) {
-	case IN_RAGGED:  k = walk_ragged<Pol, 768>; break;
+	case IN_RAGGED:
+		if (a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr))
+			k = a.off != nullptr ? walk_ragged<Pol, 768, FR_OFF64> : a.off32 != nullptr ? walk_ragged<Pol, 768, FR_OFF32> : walk_ragged<Pol, 768, FR_LENS>;
+		else k = walk_ragged<Pol, 768>;
+		break;
 	case IN_GENERIC:
 		/* the plain walk (no second output table, no resume) has an instantiation per metadata form: with the form decided at
 		 * run time every pointer of every form stays live across the loop -- 40-56 scalar registers spilled to vector lanes

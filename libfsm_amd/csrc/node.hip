@@ -386,20 +386,10 @@ extern "C" int fsm_hip_node_exec_device(struct fsm_hip_node *nd, const struct fs
 		fsm_hip_dfa *d = nd->dfa[(size_t)k];
 		uint32_t *e_out = b->d_end_out ? b->d_end_out[k] : nullptr;
 		if (cnt != 0) {
-			int r = 0;
-			if (b->d_eager_out != nullptr && b->d_eager_out[k] != nullptr) {
-				if (b->d_off != nullptr) r = fsm_hip_exec_batch_eager_offsets_device(d, b->d_base[k], b->d_off[k], cnt, e_out, b->d_eager_out[k], s);
-				else r = fsm_hip_exec_batch_eager_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, e_out, b->d_eager_out[k], s);
-				e_out = nullptr;   /* delivered */
-			}
-			if (r == 0 && b->d_id_out != nullptr && b->d_id_out[k] != nullptr) {
-				if (b->d_off != nullptr) r = fsm_hip_exec_batch_ids_offsets_device(d, b->d_base[k], b->d_off[k], cnt, b->ids_mode, b->d_id_out[k], s);
-				else r = fsm_hip_exec_batch_ids_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, b->ids_mode, b->d_id_out[k], s);
-			}
-			if (r == 0 && (e_out != nullptr || slice != nullptr)) {
-				if (b->d_off != nullptr) r = fsm_hip_exec_batch_offsets_device(d, b->d_base[k], b->d_off[k], cnt, e_out, slice, s);
-				else r = fsm_hip_exec_batch_device(d, b->d_base[k], b->stride, b->d_len ? b->d_len[k] : nullptr, cnt, e_out, slice, s);
-			}
+			/* one walk writes every output asked for (round 3 launched one per output) */
+			const int r = fsm_hip_exec_batch_all_device(d, b->d_base[k], b->stride, b->d_off == nullptr && b->d_len ? b->d_len[k] : nullptr,
+			                                            b->d_off ? b->d_off[k] : nullptr, cnt, e_out, slice, b->ids_mode,
+			                                            b->d_id_out ? b->d_id_out[k] : nullptr, b->d_eager_out ? b->d_eager_out[k] : nullptr, s);
 			if (r != 0) return -1;
 		}
 		if (count) {

@@ -1492,7 +1492,8 @@ template <class Pol> constexpr bool tail_in_step(long) { return false; }
  * inputs span 4 GiB or more) */
 __device__ __noinline__ u32x4 load_chunk_edge(uint64_t addr, bool want, uint64_t limit, uint64_t safe)
 {
-	typedef const u32x4 __attribute__((address_space(1))) *glb_chunk_p;
+	typedef u32x4 __attribute__((aligned(1))) u32x4_any;      /* an input starts at any byte */
+	typedef const u32x4_any __attribute__((address_space(1))) *glb_chunk_p;
 	if (!want) return *(glb_chunk_p)safe;
 	if (addr + 16u <= limit) return *(glb_chunk_p)addr;
 	uint32_t d[4] = {0u, 0u, 0u, 0u};
@@ -1726,10 +1727,14 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
  * that build of walk_ragged<EagerPol<TinyPol<u64>>> returned a wrong result in ~3 % of launches with two
  * wavefronts per SIMD: see the note in TinyPol::next.)
  */
-template <class Pol, int MAXT>
+/* FRONT as for walk_generic: an instantiation per metadata form keeps only that form's pointers live */
+template <class Pol, int MAXT, int FRONT = FR_ANY>
 __global__ void __launch_bounds__(MAXT)
 walk_ragged(const WalkArgs a)
 {
+	const bool f_off = FRONT == FR_ANY ? a.off != nullptr : FRONT == FR_OFF64;
+	const bool f_off32 = FRONT == FR_ANY ? a.off == nullptr && a.off32 != nullptr : FRONT == FR_OFF32;
+	const bool f_lens = FRONT == FR_ANY ? a.off == nullptr && a.off32 == nullptr && a.tbase != nullptr : FRONT == FR_LENS;
 	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
 	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -1751,7 +1756,7 @@ walk_ragged(const WalkArgs a)
 	const uint64_t w_hi = w_lo + per < a.n ? w_lo + per : a.n;
 	if (w_lo >= w_hi) return;
 	/* one past the last byte of the batch: no 16-byte fetch may reach beyond it */
-	const uint64_t limit = reinterpret_cast<uint64_t>(a.base) + batch_bytes(a);
+	const uint64_t limit = reinterpret_cast<uint64_t>(a.base) + (f_off ? a.off[a.n] : f_off32 ? a.off32[a.n] : f_lens ? a.tbase[(a.n + 63u) / 64u] : a.n * a.stride);
 
 	const uint32_t lr = lane / 8u, lq = lane % 8u;                   /* loader role */
 	unsigned char *rd = stg + (lane / 8u) * 1024u + (lane % 8u) * 128u;   /* reader role */
@@ -1779,17 +1784,17 @@ walk_ragged(const WalkArgs a)
 		if (spend != 0) {
 			/* lengths only: where each of the staged inputs starts (every lane takes part in the prefix sum) */
 			uint64_t pfx = 0;
-			if (a.tbase != nullptr) pfx = stb + wave_excl_prefix(lane < spend ? slen : 0u, lane);
+			if (f_lens) pfx = stb + wave_excl_prefix(lane < spend ? slen : 0u, lane);
 			if (lane < spend) {
 				const uint64_t i = staged + lane;
 				uint64_t b, l;
-				if (a.off != nullptr) {
+				if (f_off) {
 					b = ((uint64_t)soff.y << 32) | soff.x;
 					l = (((uint64_t)soff.w << 32) | soff.z) - b;
-				} else if (a.off32 != nullptr) {
+				} else if (f_off32) {
 					b = s32a;
 					l = s32b - s32a;
-				} else if (a.tbase != nullptr) {
+				} else if (f_lens) {
 					b = pfx;
 					l = slen;
 				} else {
@@ -1871,11 +1876,11 @@ walk_ragged(const WalkArgs a)
 				const uint32_t *pl = a.len + i;                                  /* (both addresses first: a temporary formed
 				                                                                 * after one load would be ordered behind it) */
 				const uint32_t *p32 = a.off32 + i;
-				if (a.off != nullptr) soff = *po;
-				else if (a.off32 != nullptr) { s32a = p32[0]; s32b = p32[1]; }
+				if (f_off) soff = *po;
+				else if (f_off32) { s32a = p32[0]; s32b = p32[1]; }
 				else if (a.len != nullptr) slen = *pl;
 			}
-			if (a.tbase != nullptr) stb = a.tbase[staged >> 6];
+			if (f_lens) stb = a.tbase[staged >> 6];
 			spend = (uint32_t)c;
 		}
 
