@@ -62,9 +62,10 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 	walk_fn k = nullptr;
 	switch (c.mode) {
 	case IN_RAGGED:
-		if (a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr))
-			k = a.off != nullptr ? walk_ragged<Pol, 768, FR_OFF64> : a.off32 != nullptr ? walk_ragged<Pol, 768, FR_OFF32> : walk_ragged<Pol, 768, FR_LENS>;
-		else k = walk_ragged<Pol, 768>;
+		/* (one instantiation per metadata form, as for walk_generic, takes this kernel's SGPR spills from 21-44 to 0-15 -- and
+		 * its rate on the column tables from 2.95 to 2.71 TB/s, on the C3 table from 3.49 to 3.52: a same-box A/B,
+		 * profiles/r06i_ragged_per_form_ab.txt.  The staging loads' wait moves.  The form-generic kernel stays.) */
+		k = walk_ragged<Pol, 768>;
 		break;
 	case IN_GENERIC:
 		/* the plain walk (no second output table, no resume) has an instantiation per metadata form: with the form decided at

@@ -57,7 +57,7 @@ def main():
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves or int(os.environ.get("PK_WAVES", 0)))
-                for kn, ev in ((hip.KNOB_PICK_MEAN, "PICK_MEAN"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP")):
+                for kn, ev in ((hip.KNOB_PICK_MEAN, "PICK_MEAN"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP"), (hip.KNOB_EARLY_RETIRE, "RAGGED_EARLY")):
                     if os.environ.get(ev):
                         dfa.tune(kn, int(os.environ[ev]))
                 ms = []
