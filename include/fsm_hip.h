@@ -373,10 +373,10 @@ int fsm_hip_ret_get(const struct fsm_hip_dfa *dfa, uint32_t ret_index,
  * distinct ids): bit k%64 of eager_out[i*W + k/64] <=> id fsm_hip_eager_id(dfa, k)
  * was emitted (ids numbered in ascending order).  eager_out holds n*W words.
  * end_out is as in fsm_hip_exec_batch.
- * LIMIT: the result is a SET.  fsm_exec calls the callback once per state entered, in stream order, repeats
- * included (exec.c:126-144); the order and the multiplicity of the emissions are not kept (the reference's own
- * tests compare sets: tests/eager_output/utils.c:227-231).  A caller that needs the first-emission order of an
- * input's ids must run that input through fsm_exec. */
+ * The result is a SET: fsm_exec calls the callback once per id per state entered, in stream order, repeats
+ * included (exec.c:126-144); these calls keep neither the order nor the multiplicity of the emissions (the
+ * reference's own tests compare sets: tests/eager_output/utils.c:227-231).  A caller that needs the callback
+ * stream itself uses fsm_hip_exec_batch_eager_trace below. */
 int fsm_hip_exec_batch_eager(const struct fsm_hip_dfa *dfa,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *eager_out);
@@ -392,6 +392,24 @@ int fsm_hip_exec_batch_eager_offsets(const struct fsm_hip_dfa *dfa,
 int fsm_hip_exec_batch_eager_offsets_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, const uint64_t *d_off, size_t n,
 	uint32_t *d_end_out, uint64_t *d_eager_out, void *hip_stream);
+
+/* The callback STREAM of fsm_exec (exec.c:120-144, match_eager_outputs_for_state :62-78), order and repeats kept:
+ * for input i, count_out[i] = how many times the reference would have called the eager-output callback, and the
+ * first min(count_out[i], cap) calls are recorded as ids_out[i*cap + k] = the id passed, pos_out[i*cap + k] = the
+ * number of input bytes consumed when it fired (0: the start state's outputs, which fire before the first byte;
+ * t + 1: the state entered on byte t).  Nothing fires after a missing edge.  count_out[i] > cap: the stream of
+ * input i was cut at cap records -- call again with a larger cap.  Within ONE state's set the ids come in ascending
+ * order (fsm_eager_output_get's order, eager_output.c:317-329); the reference's callback order inside one state is
+ * the insertion order of its internal table (eager_output.c:264-266), which no public getter exposes.
+ * Inputs: packed (off != NULL: n + 1 offsets, stride/len ignored) or stride (+ len, may be NULL).  end_out and
+ * pos_out may be NULL.  This is an exact-semantics path over the plain table in device memory (uploaded on first
+ * use: nstates * classes * 4 bytes), one input per lane; the set-valued calls above are the fast ones. */
+int fsm_hip_exec_batch_eager_trace(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n, size_t cap,
+	uint32_t *end_out, uint32_t *count_out, uint32_t *ids_out, uint32_t *pos_out);
+int fsm_hip_exec_batch_eager_trace_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n, size_t cap,
+	uint32_t *d_end_out, uint32_t *d_count_out, uint32_t *d_ids_out, uint32_t *d_pos_out, void *hip_stream);
 
 size_t fsm_hip_eager_id_count(const struct fsm_hip_dfa *dfa);
 size_t fsm_hip_eager_words(const struct fsm_hip_dfa *dfa);   /* ceil(id_count / 64), at least 1 */

@@ -546,6 +546,35 @@ class HipDfa:
         sets = [ids[row] for row in bits]
         return end, sets
 
+    def exec_batch_eager_trace(self, data: np.ndarray, lens: Optional[np.ndarray] = None, off: Optional[np.ndarray] = None, cap: int = 64):
+        """fsm_exec's eager-output callback stream per input, order and repeats kept: (end u32[n], count u32[n],
+        [(ids, positions) of the first min(count, cap) emissions]).  data: (n, stride) rows (+ lens), or a flat byte
+        array with off[n + 1]."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if off is not None:
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+            n, stride = len(off) - 1, 0
+        else:
+            n, stride = data.shape
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        end, cnt = np.empty(n, np.uint32), np.zeros(n, np.uint32)
+        ids, pos = np.zeros((n, max(cap, 1)), np.uint32), np.zeros((n, max(cap, 1)), np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_eager_trace(C.c_void_p(self._h), _ptr(data) if data.size else None, C.c_size_t(stride), _ptr(lens), _ptr(off),
+                                                    C.c_size_t(n), C.c_size_t(cap), _ptr(end), _ptr(cnt), _ptr(ids), _ptr(pos)) != 0:
+            raise _oserr("fsm_hip_exec_batch_eager_trace")
+        k = np.minimum(cnt, cap)
+        return end, cnt, [(ids[i, :k[i]].copy(), pos[i, :k[i]].copy()) for i in range(n)]
+
+    def exec_batch_eager_trace_device(self, d_base: int, stride: int, n: int, cap: int, d_count: int, d_ids: int, d_pos: int = 0, d_end: int = 0,
+                                      d_len: int = 0, d_off: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_eager_trace_device(C.c_void_p(self._h), C.c_void_p(d_base or None), C.c_size_t(stride), C.c_void_p(d_len or None),
+                                                           C.c_void_p(d_off or None), C.c_size_t(n), C.c_size_t(cap), C.c_void_p(d_end or None),
+                                                           C.c_void_p(d_count), C.c_void_p(d_ids or None), C.c_void_p(d_pos or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_eager_trace_device")
+
     # ---- the same three fronts over packed inputs (base + off[n + 1]) -----------
     def exec_offsets_ids(self, base: np.ndarray, off: np.ndarray, mode: int) -> np.ndarray:
         base = np.ascontiguousarray(base, dtype=np.uint8)

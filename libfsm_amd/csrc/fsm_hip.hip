@@ -22,6 +22,7 @@
 #include "launch.h"
 #include "gen_kernels.h"
 #include "walk_aux.h"
+#include "trace_kernel.h"
 
 using namespace fsmhip;
 
@@ -53,6 +54,9 @@ struct fsm_hip_dfa {
 	uint64_t *d_emask = nullptr;                     /* eager-output masks, indexed like fin */
 	uint32_t *d_ew_off = nullptr, *d_ew_word = nullptr; /* wide eager sets (> 64 ids) */
 	uint64_t *d_ew_mask = nullptr;
+	/* the eager-output stream (trace_kernel.h; built on first use): plain renumbered table, byte classes, id lists (CSR), fin */
+	uint32_t *d_tr_dense = nullptr, *d_tr_cls4 = nullptr, *d_tr_eoff = nullptr, *d_tr_eids = nullptr, *d_tr_fin = nullptr;
+	bool trace_ready = false;
 	/* device-side choice between walk_generic and walk_ragged: a ring of flags, one per launch (launches on several streams
 	 * may be in flight; PICK_FLAGS of them never are), allocated with the dfa */
 	uint32_t *d_pick = nullptr;
@@ -472,6 +476,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 	if (d->d_ew_off) (void)hipFree(d->d_ew_off);
 	if (d->d_ew_word) (void)hipFree(d->d_ew_word);
 	if (d->d_ew_mask) (void)hipFree(d->d_ew_mask);
+	for (uint32_t *q : { d->d_tr_dense, d->d_tr_cls4, d->d_tr_eoff, d->d_tr_eids, d->d_tr_fin }) if (q) (void)hipFree(q);
 	if (d->d_pick) (void)hipFree(d->d_pick);
 	if (d->tb_scratch) (void)hipFree(d->tb_scratch);
 	for (void *q : d->tb_scratch_old) (void)hipFree(q);
@@ -1897,4 +1902,96 @@ extern "C" int fsm_hip_exec_batch_eager_offsets(const struct fsm_hip_dfa *d,
 {
 	if (n != 0 && off == nullptr) { errno = EINVAL; return -1; }
 	return eager_host(d, base, 0, nullptr, off, n, end_out, eager_out);
+}
+
+/* ---- the emission stream (order and repeats kept): trace_kernel.h ---- */
+
+static int ensure_trace(fsm_hip_dfa *d)
+{
+	DfaLock lk(d->mu);
+	if (d->trace_ready) return 0;
+	const Plan &p = d->plan;
+	if (p.dense.size() != (size_t)p.S1 * p.C) { errno = ENOTSUP; return -1; }
+	/* id lists per renumbered state, ascending (fsm_eager_output_get order: eager_output.c:317-329) */
+	std::vector<uint32_t> eoff(p.S1 + 1, 0), eids;
+	for (uint32_t n = 0; n < p.S1; n++) {
+		if (!p.emask.empty() && p.emask[n] != 0) {
+			if (p.eager_words <= 1) {
+				for (unsigned b = 0; b < 64; b++) if (p.emask[n] >> b & 1u) eids.push_back(p.eager_ids[b]);
+			} else {
+				const size_t first = eids.size();
+				for (uint32_t k = p.ew_off[n]; k < p.ew_off[n + 1]; k++)
+					for (unsigned b = 0; b < 64; b++) if (p.ew_mask[k] >> b & 1u) eids.push_back(p.eager_ids[(size_t)p.ew_word[k] * 64u + b]);
+				std::sort(eids.begin() + (ptrdiff_t)first, eids.end());
+			}
+		}
+		eoff[n + 1] = (uint32_t)eids.size();
+	}
+	std::vector<uint32_t> cls4(64, 0);
+	for (unsigned b = 0; b < 256; b++) cls4[b >> 2] |= (uint32_t)p.cls[b] << ((b & 3u) * 8u);
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HIP_TRY(upload(&d->d_tr_dense, p.dense));
+	HIP_TRY(upload(&d->d_tr_cls4, cls4));
+	HIP_TRY(upload(&d->d_tr_eoff, eoff));
+	HIP_TRY(upload(&d->d_tr_eids, eids));
+	HIP_TRY(upload(&d->d_tr_fin, p.fin));
+	d->trace_ready = true;
+	return 0;
+fail:
+	return -1;
+}
+
+extern "C" int fsm_hip_exec_batch_eager_trace_device(const struct fsm_hip_dfa *cd,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n, size_t cap,
+	uint32_t *d_end_out, uint32_t *d_count_out, uint32_t *d_ids_out, uint32_t *d_pos_out, void *hip_stream)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(cd);
+	if (d == nullptr || d_count_out == nullptr || (cap != 0 && d_ids_out == nullptr) || cap > 0xFFFFFFFFu ||
+	    (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (ensure_trace(d) != 0) return -1;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	TraceArgs a;
+	a.base = static_cast<const uint8_t *>(d_base);
+	a.stride = d_off ? 0 : stride;
+	a.len = d_off ? nullptr : d_len;
+	a.off = d_off;
+	a.n = n;
+	a.dense = d->d_tr_dense; a.cls4 = d->d_tr_cls4; a.eoff = d->d_tr_eoff; a.eids = d->d_tr_eids; a.fin = d->d_tr_fin;
+	a.C = d->plan.C; a.start = d->plan.start; a.dead = d->plan.S1 - 1u;
+	a.cap = (uint32_t)cap;
+	a.end_out = d_end_out; a.count_out = d_count_out; a.ids_out = d_ids_out; a.pos_out = d_pos_out;
+	const uint64_t blocks = (n + 255u) / 256u;
+	if (blocks > 0x7FFFFFFFull) { errno = EINVAL; return -1; }
+	hipLaunchKernelGGL(eager_trace_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	return 0;
+}
+
+extern "C" int fsm_hip_exec_batch_eager_trace(const struct fsm_hip_dfa *d,
+	const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n, size_t cap,
+	uint32_t *end_out, uint32_t *count_out, uint32_t *ids_out, uint32_t *pos_out)
+{
+	size_t in_bytes = 0;
+	if (d == nullptr || count_out == nullptr || (cap != 0 && ids_out == nullptr) || cap > 0xFFFFFFFFu ||
+	    check_host_batch(base, stride, len, off, n, &in_bytes) != 0) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	if (n > ((size_t)1 << 40) / (cap ? cap : 1)) { errno = EINVAL; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_len = len ? hc.add(HostCall::IN, len, nullptr, n * sizeof(uint32_t)) : -1;
+	const int p_off = off ? hc.add(HostCall::IN, off, nullptr, (n + 1) * sizeof(uint64_t)) : -1;
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	const int p_cnt = hc.add(HostCall::OUT, nullptr, count_out, n * sizeof(uint32_t));
+	const int p_ids = hc.add(HostCall::OUT, nullptr, ids_out, n * cap * sizeof(uint32_t));
+	const int p_pos = hc.add(HostCall::OUT, nullptr, pos_out, n * cap * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	if (fsm_hip_exec_batch_eager_trace_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n, cap,
+	                                          hc.dev<uint32_t>(p_end), hc.dev<uint32_t>(p_cnt), hc.dev<uint32_t>(p_ids), hc.dev<uint32_t>(p_pos), hc.d->hs) != 0) return -1;
+	return hc.end();
 }

@@ -477,3 +477,41 @@ oracle_exec_eager_stride(const struct oracle_dfa *d, const uint32_t *eager_off, 
 		counts[i] = used;
 	}
 }
+
+/*
+ * The callback STREAM of the same walk, nothing folded: one record per callback call of exec.c:62-78, in call
+ * order, repeats included -- ids[i*cap + k] the id, pos[i*cap + k] the bytes consumed when it fired (0 for the
+ * start state's, exec.c:126-130; t + 1 for the state entered on byte t, :140-144).  counts[i] = number of calls
+ * (may exceed cap: only the first cap are recorded).  Within one state the ids come in eager_ids[] order.
+ */
+void
+oracle_exec_eager_trace(const struct oracle_dfa *d, const uint32_t *eager_off, const uint32_t *eager_ids,
+	const unsigned char *base, const uint64_t *off, size_t stride, const uint32_t *len, size_t n,
+	int8_t *ret, uint32_t *end, uint32_t *ids, uint32_t *pos, uint32_t *counts, uint32_t cap)
+{
+	size_t i;
+	for (i = 0; i < n; i++) {
+		const unsigned char *p = off ? base + off[i] : base + i * stride;
+		size_t l = off ? (size_t) (off[i + 1] - off[i]) : len ? len[i] : stride, t;
+		uint32_t st = d->start, used = 0, k;
+		int r = 1;
+		for (k = eager_off[st]; k < eager_off[st + 1]; k++, used++) {
+			if (used < cap) { ids[i * cap + used] = eager_ids[k]; pos[i * cap + used] = 0; }
+		}
+		for (t = 0; t < l; t++) {
+			if (!edge_set_transition(&d->states[st], p[t], &st)) {
+				r = 0;
+				break;
+			}
+			for (k = eager_off[st]; k < eager_off[st + 1]; k++, used++) {
+				if (used < cap) { ids[i * cap + used] = eager_ids[k]; pos[i * cap + used] = (uint32_t) (t + 1); }
+			}
+		}
+		if (r && !d->states[st].end) {
+			r = 0;
+		}
+		ret[i] = (int8_t) r;
+		end[i] = r ? st : 0xFFFFFFFFu;
+		counts[i] = used;
+	}
+}

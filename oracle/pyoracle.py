@@ -70,6 +70,8 @@ class Oracle:
             L.oracle_isend.argtypes = [vp, C.c_uint32]
             L.oracle_exec_eager_stride.restype = None
             L.oracle_exec_eager_stride.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, C.c_uint32]
+            L.oracle_exec_eager_trace.restype = None
+            L.oracle_exec_eager_trace.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, C.c_uint32]
             L.oracle_endid_count.restype = sz
             L.oracle_endid_count.argtypes = [vp, C.c_uint32]
             L.oracle_endid_get.argtypes = [vp, C.c_uint32, sz, vp]
@@ -169,6 +171,26 @@ class Oracle:
                                             _p(ret), _p(end), _p(ids), _p(cnt), cap)
         return ret, end, [np.sort(ids[i, :cnt[i]]) for i in range(n)]
 
+    def exec_eager_trace(self, data: np.ndarray, lens=None, off=None, cap: int = 64):
+        """fsm_exec's eager-output callback stream: (ret, end, counts, [(ids, positions) in call order, repeats kept])."""
+        flat = self.flat
+        data = np.ascontiguousarray(data, np.uint8)
+        if off is not None:
+            off = np.ascontiguousarray(off, np.uint64)
+            n, stride = len(off) - 1, 0
+        else:
+            n, stride = data.shape
+        eo = flat.eager_off if flat.eager_off is not None else np.zeros(flat.nstates + 1, np.uint32)
+        ei = flat.eager_ids if flat.eager_off is not None and len(flat.eager_ids) else np.zeros(1, np.uint32)
+        ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
+        ids, pos, cnt = np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, np.uint32)
+        self.lib().oracle_exec_eager_trace(self._h, _p(eo), _p(ei), _p(data) if data.size else None, _p(off), stride, _p(lens), n,
+                                           _p(ret), _p(end), _p(ids), _p(pos), _p(cnt), cap)
+        k = np.minimum(cnt, cap)
+        return ret, end, cnt, [(ids[i, :k[i]].copy(), pos[i, :k[i]].copy()) for i in range(n)]
+
     def isend(self, state: int) -> bool:
         return bool(self.lib().oracle_isend(self._h, int(state)))
 
@@ -231,6 +253,8 @@ class Ref:
             H.rh_union_repeated.argtypes = [C.c_int, vp, sz, C.c_uint, C.c_int]
             H.rh_exec_eager_batch.restype = None
             H.rh_exec_eager_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint]
+            H.rh_exec_eager_stream_batch.restype = None
+            H.rh_exec_eager_stream_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint]
             ref.fsm_setendid.argtypes = [vp, C.c_uint]
             ref.fsm_union.restype = vp
             ref.fsm_union.argtypes = [vp, vp, vp]
@@ -311,6 +335,18 @@ class RefFsm:
         ids, cnt = np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
         H.rh_exec_eager_batch(self.ptr, _p(base), _p(off), n, _p(ret), _p(end), _p(ids), _p(cnt), cap)
         return ret, end, [np.sort(ids[i, :cnt[i]]) for i in range(n)]
+
+    def exec_eager_stream_strings(self, strings, cap: int = 64):
+        """Literal fsm_exec, the raw callback stream: (ret, end, counts, [ids in call order, repeats kept])."""
+        _, H = Ref.libs()
+        off = np.zeros(len(strings) + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in strings])
+        base = np.frombuffer(b"".join(strings) + b"\0", np.uint8)
+        n = len(strings)
+        ret, end = np.zeros(n, np.int8), np.zeros(n, np.uint32)
+        ids, cnt = np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
+        H.rh_exec_eager_stream_batch(self.ptr, _p(base), _p(off), n, _p(ret), _p(end), _p(ids), _p(cnt), cap)
+        return ret, end, cnt, [ids[i, :min(cnt[i], cap)].copy() for i in range(n)]
 
     # -- queries ----------------------------------------------------------------
     @property

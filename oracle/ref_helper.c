@@ -366,6 +366,43 @@ rh_exec_eager_batch(struct fsm *fsm, const unsigned char *base, const uint64_t *
 	fsm_eager_output_set_cb(fsm, NULL, NULL);
 }
 
+struct eager_stream {
+	uint32_t *ids;
+	uint32_t used, cap;
+};
+
+static void
+eager_stream_cb(fsm_output_id_t id, void *opaque)
+{
+	struct eager_stream *acc = opaque;
+	if (acc->used < acc->cap) {
+		acc->ids[acc->used] = id;
+	}
+	acc->used++;
+}
+
+/* the raw callback stream of literal fsm_exec: every call, in call order (ids[i*cap .. ], counts[i] = calls made) */
+void
+rh_exec_eager_stream_batch(struct fsm *fsm, const unsigned char *base, const uint64_t *off, size_t n,
+	int8_t *ret, uint32_t *end, uint32_t *ids, uint32_t *counts, uint32_t cap)
+{
+	size_t i;
+	for (i = 0; i < n; i++) {
+		struct eager_stream acc;
+		unsigned e = 0xFFFFFFFFu;
+		int r;
+		acc.ids = ids + i * cap;
+		acc.used = 0;
+		acc.cap = cap;
+		fsm_eager_output_set_cb(fsm, eager_stream_cb, &acc);
+		r = rh_exec(fsm, base + off[i], (size_t) (off[i + 1] - off[i]), &e);
+		ret[i] = (int8_t) r;
+		end[i] = r == 1 ? e : 0xFFFFFFFFu;
+		counts[i] = acc.used;
+	}
+	fsm_eager_output_set_cb(fsm, NULL, NULL);
+}
+
 size_t
 rh_eager_output_count(const struct fsm *fsm, unsigned state)
 {
