@@ -510,7 +510,10 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	c.prefetch = d->knob_prefetch >= 0 ? (d->knob_prefetch != 0) : (layout == FSM_HIP_LAYOUT_COMBSELF || layout == FSM_HIP_LAYOUT_SPARSE ? 0 : 1);
 	/* ragged / packed / unaligned inputs: the coalesced, lane-refilling kernel whenever at least four
 	 * waves' tiles and rings fit next to the table, else per-lane loads (walk_generic) */
-	const bool ragged_fits = d->table_lds + 4u * FSMHIP_RAGGED_WAVE_LDS <= d->lds_limit;
+	/* the 5-bit column table keeps the ragged kernel's ring and row records in its own holes (walk_kernels.h ragged_aux_in_holes) */
+	const bool ragged_holes = layout == FSM_HIP_LAYOUT_TINY && !d->plan.tiny5_col.empty() && !eager;
+	const uint32_t ragged_wave_lds = ragged_holes ? 8192u : FSMHIP_RAGGED_WAVE_LDS;
+	const bool ragged_fits = d->table_lds + 4u * ragged_wave_lds <= d->lds_limit;
 	int mode = ragged_fits && !per_lane && !huge ? IN_RAGGED : IN_GENERIC;
 	if (d->knob_input_mode == IN_GENERIC || (d->knob_input_mode == IN_RAGGED && ragged_fits && !huge)) mode = d->knob_input_mode;
 	else if (fast_ok) {
@@ -555,14 +558,14 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	}
 	if (c.sparse_fast == 3) c.sparse_fast = d->sparse_fast_ok ? 1 : 0;
 	c.mode = mode;
-	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? FSMHIP_RAGGED_WAVE_LDS : 0u;
+	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? ragged_wave_lds : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
 	 * 64 KiB column table (one private copy per lane / bank), which leaves 12 x 8 KiB tiles of the 160 KiB.
 	 * combself behind LDS-DMA: 12 waves measured best at 10^8 x 1 KiB (6.09 TB/s; 14: 5.82, 10: 5.80, 8: 5.72).
 	 * Kernels compiled for fewer threads (their register budget): ragged 12 waves, eager LDS-DMA on the 64-bit column
 	 * table 12 (launch.h eager_dma_threads), eager ragged / generic 8. */
 	int wmax = 16;
-	if (mode == IN_RAGGED) wmax = eager ? 8 : 12;
+	if (mode == IN_RAGGED) wmax = eager ? 8 : ragged_holes ? (int)FSMHIP_RAGGED_HOLE_WAVES : 12;
 	else if (eager && mode == IN_GENERIC) wmax = 8;
 	else if (eager && mode == IN_LDSDMA) wmax = ((layout == FSM_HIP_LAYOUT_TINY && d->plan.tiny5_col.empty()) || layout == FSM_HIP_LAYOUT_COMB ||
 		                                            layout == FSM_HIP_LAYOUT_COMBSELF || layout == FSM_HIP_LAYOUT_LDSSELF) ? 12 : 16;   /* launch.h eager_dma_threads */

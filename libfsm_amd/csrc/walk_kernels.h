@@ -268,6 +268,9 @@ struct Tiny5Pol {
 		if (base != 0u) __builtin_trap();
 		lanebase = (threadIdx.x & 63u) << 2;
 	}
+	/* lanes 32-63 read copies 0-31 (a ds_read_b32 wave is served in two 32-lane groups: no conflict between l and l + 32):
+	 * the upper half of every 256-byte row is then never read -- walk_ragged keeps its ring there (ragged_aux_in_holes) */
+	__device__ __forceinline__ void half_copies() { lanebase &= 0x7Cu; }
 	__device__ __forceinline__ P pre(uint32_t b) const { return *(lds_u32p)(uintptr_t)((b << 8) | lanebase); }
 	/* byte k of the input dword d -> address bytes [0, 0, d.byte[k], lanebase.byte[0]] */
 	__device__ __forceinline__ P pre_dw(uint32_t d, int k) const
@@ -1699,6 +1702,16 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
 #define FSMHIP_RAGGED_RING 128u                                  /* staged (offset, length) pairs per wave */
 #define FSMHIP_RAGGED_WAVE_LDS (8192u + FSMHIP_RAGGED_RING * 16u + 1024u) /* 8 KiB tile + the ring + one 16-byte row record per lane */
 
+/* Tiny5Pol's column table is 256 rows of 256 bytes (64 dword copies: the lookup address is formed by one byte
+ * permutation, (byte << 8) | lane * 4) -- but a ds_read_b32 wave is served in two 32-lane groups over 32 banks
+ * (MI355X_MICROARCH.md, LDS), so lanes l and l + 32 can share a copy: lanes 32-63 read copies 0-31 and the upper
+ * 128 bytes of every row are HOLES that no lookup touches.  walk_ragged keeps its ring and row records there
+ * (192 16-byte entries = 24 holes per wavefront), which leaves 8 KiB of LDS per wavefront next to the 64 KiB table:
+ * 10 wavefronts per workgroup instead of 8 (the holes hold 10 wavefronts' worth). */
+template <class Pol> struct ragged_aux_in_holes { static constexpr bool value = false; };
+template <> struct ragged_aux_in_holes<Tiny5Pol> { static constexpr bool value = true; };
+#define FSMHIP_RAGGED_HOLE_WAVES 10u
+
 /*
  * The retest / rx front: inputs of any length at any byte offset (packed back to back with an offsets
  * array, or fixed stride + lengths).  walk_generic gives every lane its own 16-byte loads with two
@@ -1738,16 +1751,22 @@ walk_ragged(const WalkArgs a)
 	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
 	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
+	constexpr bool HOLES = ragged_aux_in_holes<Pol>::value;
 	Pol pol;
 	pol.setup(lds, a);
+	if constexpr (HOLES) pol.half_copies();
 	__syncthreads();
 
 	/* the wavefront's index as a SCALAR: everything derived from it (tile slot, input range, ring cursors) is then
 	 * wave-uniform to the compiler too and lives in SGPRs / on the scalar unit */
 	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * FSMHIP_RAGGED_WAVE_LDS;
-	uint64_t *ring = reinterpret_cast<uint64_t *>(stg + 8192u);   /* [RING][2]: byte offset, length */
-	unsigned char *rows = stg + 8192u + RING * 16u;               /* [64] row records for the loaders */
+	unsigned char *stg = lds + Pol::lds_bytes(a.tab_bytes) + wave * (HOLES ? 8192u : FSMHIP_RAGGED_WAVE_LDS);
+	/* the wavefront's 16-byte auxiliary entries: [0, RING) the ring of (byte offset, length) pairs, [RING, RING + 64) the
+	 * row records for the loaders -- behind the tile, or in the table's holes (8 entries per hole) */
+	auto aux = [&](uint32_t e) -> unsigned char * {
+		if (HOLES) return lds + (wave * ((RING + 64u) / 8u) + (e >> 3)) * 256u + 128u + (e & 7u) * 16u;
+		return stg + 8192u + e * 16u;
+	};
 
 	/* contiguous range of whole bitmap words per wavefront */
 	const uint64_t nwaves = (uint64_t)gridDim.x * nw, gw = (uint64_t)blockIdx.x * nw + wave;
@@ -1801,8 +1820,9 @@ walk_ragged(const WalkArgs a)
 					b = i * a.stride;
 					l = a.len != nullptr ? slen : a.stride;
 				}
-				ring[(i & (RING - 1u)) * 2u] = b;
-				ring[(i & (RING - 1u)) * 2u + 1u] = l;
+				uint64_t *re = reinterpret_cast<uint64_t *>(aux((uint32_t)i & (RING - 1u)));
+				re[0] = b;
+				re[1] = l;
 			}
 			staged += spend;
 			spend = 0;
@@ -1835,7 +1855,8 @@ walk_ragged(const WalkArgs a)
 			const uint64_t want = (uint64_t)__builtin_popcountll(need);
 			next = next + want < staged ? next + want : staged;
 			if (take) {
-				const uint64_t beg = ring[(idx & (RING - 1u)) * 2u], len = ring[(idx & (RING - 1u)) * 2u + 1u];
+				const uint64_t *re = reinterpret_cast<const uint64_t *>(aux((uint32_t)idx & (RING - 1u)));
+				const uint64_t beg = re[0], len = re[1];
 				np0 = reinterpret_cast<uint64_t>(a.base) + beg;
 				nnfull = (uint32_t)(len >> 4);
 				ntail = (uint32_t)len & 15u;
@@ -1896,11 +1917,11 @@ walk_ragged(const WalkArgs a)
 		if (more) {
 			const uint64_t lbase = lsrc - ladj;
 			const u32x4 rec = {(uint32_t)lbase, (uint32_t)(lbase >> 32), lrem, ladj};
-			*reinterpret_cast<u32x4 *>(rows + lane * 16u) = rec;
+			*reinterpret_cast<u32x4 *>(aux(RING + lane)) = rec;
 			u32x4 rr[8];
 #pragma unroll
 			for (uint32_t j = 0; j < 8; j++)
-				rr[j] = *reinterpret_cast<const u32x4 *>(rows + (j * 8u + lr) * 16u);
+				rr[j] = *reinterpret_cast<const u32x4 *>(aux(RING + j * 8u + lr));
 #pragma unroll
 			for (uint32_t j = 0; j < 8; j++) {
 				const uint32_t piece = (lq - ((j * 4u + (lr >> 1)) & 7u)) & 7u;   /* rotation of row j * 8 + lr: (row >> 1) & 7 */
