@@ -205,6 +205,19 @@ int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, const uint32_t *d_len, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
 
+/* Every output of one PACKED batch from one walk, whatever the metadata form: what the generated matchers with ids return
+ * (`int fsm_main(const char *b, const char *e, unsigned *id)` and the ids / count form, src/libfsm/print/c.c:569-619) for a
+ * batch of (b, e) lines, without widening their offsets first.  meta_form says what `meta` is: u64 offsets [n + 1], u32 offsets
+ * [n + 1], or u32 lengths [n].  end_out / accept_bitmap / id_out (ids_mode = FSM_HIP_IDS_*) / eager_out as in
+ * fsm_hip_exec_batch_all_device, whichever are not NULL. */
+enum { FSM_HIP_META_OFF64 = 0, FSM_HIP_META_OFF32 = 1, FSM_HIP_META_LENGTHS = 2 };
+int fsm_hip_exec_batch_packed_all(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, int meta_form, const void *meta, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap, int ids_mode, uint32_t *id_out, uint64_t *eager_out);
+int fsm_hip_exec_batch_packed_all_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, int meta_form, const void *d_meta, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream);
+
 /* Time of the most recent *_device launch on this dfa, measured with HIP
  * events recorded on the launch stream around the walk kernel only.
  * Blocks until that launch finished.  Returns milliseconds, or <0 on error. */

@@ -20,6 +20,7 @@ STATE_START = 0xFFFFFFFD
 STATE_DEAD = 0xFFFFFFFC
 
 LAYOUT_AUTO, LAYOUT_TINY, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_GLOBAL, LAYOUT_COMB256, LAYOUT_COMBSELF, LAYOUT_SPARSE, LAYOUT_LDSSELF, LAYOUT_LDS2 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+META_OFF64, META_OFF32, META_LENGTHS = 0, 1, 2   # fsm_hip_exec_batch_packed_all: what the metadata array is
 LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself", 7: "sparse", 8: "ldsself", 9: "lds2"}
 ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_LDS2, LAYOUT_COMB256, LAYOUT_LDSSELF, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
@@ -575,6 +576,30 @@ class HipDfa:
                                                            C.c_void_p(d_count), C.c_void_p(d_ids or None), C.c_void_p(d_pos or None), C.c_void_p(stream or None)) != 0:
             raise _oserr("fsm_hip_exec_batch_eager_trace_device")
 
+    def exec_packed_all_form(self, base: np.ndarray, meta_form: int, meta: np.ndarray, n: int, ids_mode: int = 0, want_end=True, want_bitmap=False,
+                             want_eager=False):
+        """fsm_hip_exec_batch_packed_all: returns dict(end=, bitmap=, ids=, eager=) with the outputs asked for."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64 if meta_form == 0 else np.uint32)
+        end = np.empty(n, np.uint32) if want_end else None
+        bm = np.zeros((n + 63) // 64, np.uint64) if want_bitmap else None
+        ids = np.empty(n, np.uint32) if ids_mode else None
+        W = self.eager_words()
+        eo = np.zeros((n, W), np.uint64) if want_eager else None
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_packed_all(C.c_void_p(self._h), _ptr(base) if base.size else None, C.c_int(meta_form), _ptr(meta), C.c_size_t(n),
+                                                   _ptr(end), _ptr(bm), C.c_int(ids_mode), _ptr(ids), _ptr(eo)) != 0:
+            raise _oserr("fsm_hip_exec_batch_packed_all")
+        return {"end": end, "bitmap": bm, "ids": ids, "eager": eo}
+
+    def exec_packed_all_device(self, d_base: int, meta_form: int, d_meta: int, n: int, d_end: int = 0, d_bitmap: int = 0, ids_mode: int = 0, d_ids: int = 0,
+                               d_eager: int = 0, stream: int = 0):
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_packed_all_device(C.c_void_p(self._h), C.c_void_p(d_base or None), C.c_int(meta_form), C.c_void_p(d_meta or None), C.c_size_t(n),
+                                                          C.c_void_p(d_end or None), C.c_void_p(d_bitmap or None), C.c_int(ids_mode), C.c_void_p(d_ids or None),
+                                                          C.c_void_p(d_eager or None), C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_packed_all_device")
+
     # ---- the same three fronts over packed inputs (base + off[n + 1]) -----------
     def exec_offsets_ids(self, base: np.ndarray, off: np.ndarray, mode: int) -> np.ndarray:
         base = np.ascontiguousarray(base, dtype=np.uint8)
@@ -634,6 +659,10 @@ class HipDfa:
     def eager_id_count(self) -> int:
         self._lib.fsm_hip_eager_id_count.restype = C.c_size_t
         return int(self._lib.fsm_hip_eager_id_count(C.c_void_p(self._h)))
+
+    def eager_id(self, bit: int) -> int:
+        self._lib.fsm_hip_eager_id.restype = C.c_uint32
+        return int(self._lib.fsm_hip_eager_id(C.c_void_p(self._h), C.c_uint(bit)))
 
     def ret_sets(self):
         """The de-duplicated end-id sets, in retlist order."""

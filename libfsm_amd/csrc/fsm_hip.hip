@@ -1829,12 +1829,14 @@ extern "C" int fsm_hip_exec_batch_eager_offsets_device(const struct fsm_hip_dfa 
 /* Every output of one batch from ONE walk: end states and / or the accept bitmap, device-side end-ids (ids_mode, d_id_out) and
  * eager sets (d_eager_out), whichever are asked for -- the walk kernels write all of them in one pass (the multi-device front used
  * to launch one walk per output) */
-extern "C" int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *dc,
-	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
-	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream)
+static int all_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, const uint32_t *d_off32, bool lens_only, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream, const BatchHint &hint)
 {
 	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
-	if (d == nullptr || (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0) || (d_off != nullptr && d_len != nullptr)) { errno = EINVAL; return -1; }
+	const bool packed = d_off != nullptr || d_off32 != nullptr || lens_only;
+	if (d == nullptr || (n != 0 && !packed && d_base == nullptr && stride != 0) || (d_off != nullptr && d_len != nullptr) ||
+	    (lens_only && n != 0 && d_len == nullptr)) { errno = EINVAL; return -1; }
 	if (d_id_out != nullptr) {
 		if (ids_mode != FSM_HIP_IDS_EARLIEST && ids_mode != FSM_HIP_IDS_RET && ids_mode != FSM_HIP_IDS_ERROR) { errno = EINVAL; return -1; }
 		if (ensure_ids(d) != 0) return -1;
@@ -1843,14 +1845,16 @@ extern "C" int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *dc,
 			ids_mode = FSM_HIP_IDS_EARLIEST;
 		}
 	}
+	if (n == 0) return 0;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	hipStream_t s = static_cast<hipStream_t>(hip_stream);
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
-	a.stride = d_off ? 0 : stride;
-	a.len = d_off ? nullptr : d_len;
+	a.stride = packed ? 0 : stride;
+	a.len = d_off != nullptr || d_off32 != nullptr ? nullptr : d_len;
 	a.off = d_off;
+	a.off32 = d_off == nullptr ? d_off32 : nullptr;
 	a.n = n;
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
@@ -1867,9 +1871,83 @@ extern "C" int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *dc,
 		}
 		if (!d->plan.emask.empty()) a.eager_out = d_eager_out;
 	}
-	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+	const bool lo = lens_only && d_off == nullptr && d_off32 == nullptr;
+	if (lo && tile_bases(d, d_len, n, s, &a.tbase) != 0) return -1;
+	const bool fast = !packed && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, s, BatchHint());
+	const int r = launch_walk(d, a, fast, s, hint);
+	if (lo) tile_bases_done(d, s);
+	return r;
+}
+
+extern "C" int fsm_hip_exec_batch_all_device(const struct fsm_hip_dfa *d,
+	const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	return all_device(d, d_base, stride, d_len, d_off, nullptr, false, n, d_end_out, d_accept_bitmap, ids_mode, d_id_out, d_eager_out, hip_stream, BatchHint());
+}
+
+/* the same over packed inputs whose metadata is u64 offsets, u32 offsets or lengths alone */
+extern "C" int fsm_hip_exec_batch_packed_all_device(const struct fsm_hip_dfa *d,
+	const void *d_base, int meta_form, const void *d_meta, size_t n,
+	uint32_t *d_end_out, uint64_t *d_accept_bitmap, int ids_mode, uint32_t *d_id_out, uint64_t *d_eager_out, void *hip_stream)
+{
+	if (n != 0 && d_meta == nullptr) { errno = EINVAL; return -1; }
+	switch (meta_form) {
+	case FSM_HIP_META_OFF64:
+		return all_device(d, d_base, 0, nullptr, static_cast<const uint64_t *>(d_meta), nullptr, false, n, d_end_out, d_accept_bitmap, ids_mode, d_id_out, d_eager_out, hip_stream, BatchHint());
+	case FSM_HIP_META_OFF32:
+		return all_device(d, d_base, 0, nullptr, nullptr, static_cast<const uint32_t *>(d_meta), false, n, d_end_out, d_accept_bitmap, ids_mode, d_id_out, d_eager_out, hip_stream, BatchHint());
+	case FSM_HIP_META_LENGTHS:
+		return all_device(d, d_base, 0, static_cast<const uint32_t *>(d_meta), nullptr, nullptr, true, n, d_end_out, d_accept_bitmap, ids_mode, d_id_out, d_eager_out, hip_stream, BatchHint());
+	default:
+		errno = EINVAL;
+		return -1;
+	}
+}
+
+/* host pointers: the metadata is checked (non-decreasing offsets, the lengths' sum is the batch) */
+extern "C" int fsm_hip_exec_batch_packed_all(const struct fsm_hip_dfa *d,
+	const unsigned char *base, int meta_form, const void *meta, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap, int ids_mode, uint32_t *id_out, uint64_t *eager_out)
+{
+	if (d == nullptr || (n != 0 && meta == nullptr) || (meta_form != FSM_HIP_META_OFF64 && meta_form != FSM_HIP_META_OFF32 && meta_form != FSM_HIP_META_LENGTHS)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	size_t in_bytes = 0, meta_bytes = 0;
+	uint64_t sum = 0;
+	if (meta_form == FSM_HIP_META_OFF64) {
+		const uint64_t *o = static_cast<const uint64_t *>(meta);
+		for (size_t i = 0; i < n; i++) if (o[i + 1] < o[i]) { errno = EINVAL; return -1; }
+		in_bytes = (size_t)o[n]; meta_bytes = (n + 1) * sizeof(uint64_t);
+	} else if (meta_form == FSM_HIP_META_OFF32) {
+		const uint32_t *o = static_cast<const uint32_t *>(meta);
+		for (size_t i = 0; i < n; i++) if (o[i + 1] < o[i]) { errno = EINVAL; return -1; }
+		in_bytes = o[n]; meta_bytes = (n + 1) * sizeof(uint32_t);
+	} else {
+		const uint32_t *l = static_cast<const uint32_t *>(meta);
+		for (size_t i = 0; i < n; i++) sum += l[i];
+		in_bytes = (size_t)sum; meta_bytes = n * sizeof(uint32_t);
+	}
+	if (in_bytes != 0 && base == nullptr) { errno = EINVAL; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_meta = hc.add(HostCall::IN, meta, nullptr, meta_bytes);
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	const int p_bm = hc.add(HostCall::OUT, nullptr, accept_bitmap, ((n + 63) / 64) * sizeof(uint64_t));
+	const int p_id = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
+	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
+	if (hc.begin() != 0) return -1;
+	BatchHint hint;
+	hint.bytes = in_bytes;
+	hint.short_mean = in_bytes / n < 96;
+	const void *dm = hc.dev<unsigned char>(p_meta);
+	if (all_device(d, hc.dev<unsigned char>(p_in), 0, meta_form == FSM_HIP_META_LENGTHS ? static_cast<const uint32_t *>(dm) : nullptr,
+	               meta_form == FSM_HIP_META_OFF64 ? static_cast<const uint64_t *>(dm) : nullptr,
+	               meta_form == FSM_HIP_META_OFF32 ? static_cast<const uint32_t *>(dm) : nullptr, meta_form == FSM_HIP_META_LENGTHS, n,
+	               hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_bm), ids_mode, hc.dev<uint32_t>(p_id), hc.dev<uint64_t>(p_eo), hc.d->hs, hint) != 0) return -1;
+	return hc.end();
 }
 
 static int eager_host(const struct fsm_hip_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, const uint64_t *off, size_t n,

@@ -143,3 +143,91 @@ def test_lazy_walk_is_the_default_for_configs4(hip):
     end, _ = dfa.exec_batch(rows)
     assert np.array_equal(end, want)
     dfa.close()
+
+
+def test_packed_all_every_metadata_form(hip):
+    """fsm_hip_exec_batch_packed_all{,_device}: end states, accept bitmap, device-side end-ids (EARLIEST and RET) and eager
+    sets from ONE walk over packed lines whose metadata is u64 offsets, u32 offsets or lengths alone -- the (b, e) lines the
+    generated matchers take (print/c.c:569-619), ids included.  Short lines (the per-lane kernel) and long ones (the
+    lane-refilling kernel); end-ids against the oracle's fsm_endid_get sets on the C3 automaton, eager sets against the
+    golden ids of tests/eager_output programs; host and device pointers; every form must give the same answers."""
+    import torch
+    from common import eager_golden_paths
+    from oracle.pyoracle import Oracle
+    g = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g.flat)
+    rng = np.random.RandomState(41)
+    a = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    pats = bytes(np.load(os.path.join(GOLDEN, "c3.npz"))["patterns"]).split(b"\n")
+
+    def line(k):
+        if rng.randint(3):
+            return bytes(a[rng.randint(0, len(a), k)])
+        p = pats[rng.randint(len(pats))]
+        return p[1:p.index(b"[")] + bytes(rng.randint(48, 58, max(1, k - 6)).astype(np.uint8)) + b"yz"
+
+    def metas(strings):
+        lens = np.array([len(s) for s in strings], np.uint32)
+        off = np.zeros(len(strings) + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        base = np.frombuffer(b"".join(strings) + b"\0", np.uint8)
+        return base, ((hip.META_OFF64, off), (hip.META_OFF32, off.astype(np.uint32)), (hip.META_LENGTHS, lens))
+
+    dfa = hip.HipDfa(g.flat)
+    sets = dfa.ret_sets()
+    for lo, hi, n in ((0, 60, 6001), (0, 700, 3000), (5, 6, 1), (0, 1, 130)):
+        strings = [line(rng.randint(lo, hi)) for _ in range(n)]
+        ret, want = o.exec_strings(strings)
+        base, forms = metas(strings)
+        for mode in (1, 2):
+            for form, meta in forms:
+                r = dfa.exec_packed_all_form(base, form, meta, n, ids_mode=mode, want_bitmap=True)
+                assert np.array_equal(r["end"], want), (lo, hi, mode, form)
+                assert np.array_equal(np.unpackbits(r["bitmap"].view(np.uint8), bitorder="little")[:n].astype(bool), want != NO)
+                ids = r["ids"]
+                assert (ids[want == NO] == NO).all()
+                for i in np.nonzero(want != NO)[0][:300]:
+                    e = o.endids(int(want[i]))
+                    if mode == 1:
+                        assert ids[i] == (int(e[0]) if len(e) else 0xFFFFFFFE)
+                    else:
+                        assert np.array_equal(sets[ids[i]], e)
+                # device pointers, ids only (no end states, no bitmap)
+                d_base = torch.from_numpy(base.copy()).cuda()
+                d_meta = torch.from_numpy(meta.view(np.int64) if form == hip.META_OFF64 else meta.view(np.int32)).cuda()
+                d_ids = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+                dfa.exec_packed_all_device(d_base.data_ptr(), form, d_meta.data_ptr(), n, ids_mode=mode, d_ids=d_ids.data_ptr())
+                torch.cuda.synchronize()
+                assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ids), (lo, hi, mode, form)
+    dfa.close()
+    checked = 0
+    for path in eager_golden_paths():
+        ge = Golden(path)
+        strs = ge.strings()
+        strs = strs + [s * 9 for s in strs]                        # long lines too
+        eo = Oracle(ge.flat)
+        d = hip.HipDfa(ge.flat)
+        rows = np.zeros((len(strs), max(1, max(len(s) for s in strs))), np.uint8)
+        lens = np.array([len(s) for s in strs], np.uint32)
+        for i, s in enumerate(strs):
+            rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+        _, wend, wsets = eo.exec_eager(rows, lens)
+        base, forms = metas(strs)
+        k = d.eager_id_count()
+        idv = np.array([d.eager_id(b) for b in range(k)], np.uint32)
+        for form, meta in forms:
+            r = d.exec_packed_all_form(base, form, meta, len(strs), want_eager=True)
+            assert np.array_equal(r["end"], np.where(wend == NO, NO, wend)), (path, form)
+            bits = np.unpackbits(r["eager"].view(np.uint8).reshape(len(strs), -1), axis=1, bitorder="little")[:, :k].astype(bool)
+            for i in range(len(strs)):
+                assert np.array_equal(idv[bits[i]], wsets[i]), (path, form, i)
+            checked += len(strs)
+        d.close()
+    assert checked >= 500
+    # error contracts: a bad form, NULL metadata, decreasing offsets
+    dfa = hip.HipDfa(g.flat)
+    with pytest.raises(OSError):
+        dfa.exec_packed_all_form(np.zeros(4, np.uint8), 7, np.zeros(2, np.uint32), 1)
+    with pytest.raises(OSError):
+        dfa.exec_packed_all_form(np.zeros(8, np.uint8), hip.META_OFF32, np.array([4, 2, 8], np.uint32), 2)
+    dfa.close()
