@@ -791,6 +791,23 @@ def main():
             res["parity_sample"] = f"{len(idx)} lines: seeded stratified sample + first/last 64; the other metadata forms reproduce all {n_l} end states"
             if res["parity_vs_cpu_sample"] != "bit-exact":
                 res["value"] = None
+            # ... and EVERY line: the rows stream back in 2 GiB slices and the oracle walks the first len[i] bytes of each on all
+            # granted host cores (the bytes walked are the rows' own: the packed copy was made from them on the device and is
+            # spot-checked above and byte-for-byte in tests/test_gpu_round4.py)
+            if not a.no_full_parity:
+                ncores, _ = host_cores()
+                w = hi if hi <= 64 else L
+                step = max(1, (2 << 30) // w)
+                bad, t0, t_cpu = 0, time.perf_counter(), 0.0
+                for r0 in range(0, n_l, step):
+                    r1 = min(n_l, r0 + step)
+                    want_all = o.table_walk_mt(rows[r0:r1, :w].contiguous().cpu().numpy(), ncores, lens[r0:r1].cpu().numpy().astype(np.uint32))
+                    t_cpu += o.last_seconds
+                    bad += int((end[r0:r1].cpu().numpy().view(np.uint32) != want_all).sum())
+                res["full_parity"] = {"rows": n_l, "mismatches": bad, "cpu_threads": ncores, "seconds": round(time.perf_counter() - t0, 1),
+                                      "cpu_walk_GBps": round(total / 1e9 / max(t_cpu, 1e-9), 2), "checker": "oracle dense-table walker (oracle/dfa_oracle.c), all lines"}
+                if bad:
+                    res["value"] = None
         dfa.close()
         del packed, off, lens, end2, bm
         return res

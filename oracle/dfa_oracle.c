@@ -305,6 +305,7 @@ struct walk_job {
 	const struct oracle_dfa *d;
 	const unsigned char *base;
 	size_t stride, first, count;
+	const uint32_t *len;      /* or NULL: every input is `stride` bytes */
 	uint32_t *end;
 };
 
@@ -317,8 +318,9 @@ walk_worker(void *opaque)
 	size_t i, t;
 	for (i = j->first; i < j->first + j->count; i++) {
 		const unsigned char *p = j->base + i * j->stride;
+		const size_t l = j->len ? j->len[i] : j->stride;
 		uint32_t st = d->start;
-		for (t = 0; t < j->stride; t++) {
+		for (t = 0; t < l; t++) {
 			st = d->dense[(size_t) st * 256 + p[t]];
 		}
 		j->end[i] = (st < S && d->states[st].end) ? st : 0xFFFFFFFFu;
@@ -326,8 +328,17 @@ walk_worker(void *opaque)
 	return NULL;
 }
 
+double oracle_table_walk_lens_mt(struct oracle_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, size_t n, uint32_t *end, int nthreads);
+
 double
 oracle_table_walk_stride_mt(struct oracle_dfa *d, const unsigned char *base, size_t stride, size_t n, uint32_t *end, int nthreads)
+{
+	return oracle_table_walk_lens_mt(d, base, stride, NULL, n, end, nthreads);
+}
+
+/* the same with per-input lengths (len[i] <= stride; NULL: whole rows): the lines of the packed-lines bench legs */
+double
+oracle_table_walk_lens_mt(struct oracle_dfa *d, const unsigned char *base, size_t stride, const uint32_t *len, size_t n, uint32_t *end, int nthreads)
 {
 	pthread_t th[256];
 	struct walk_job jobs[256];
@@ -350,6 +361,7 @@ oracle_table_walk_stride_mt(struct oracle_dfa *d, const unsigned char *base, siz
 		jobs[t].stride = stride;
 		jobs[t].first = n * (size_t) t / (size_t) nthreads;
 		jobs[t].count = n * (size_t) (t + 1) / (size_t) nthreads - jobs[t].first;
+		jobs[t].len = len;
 		jobs[t].end = end;
 		if (pthread_create(&th[t], NULL, walk_worker, &jobs[t]) != 0) {
 			walk_worker(&jobs[t]);   /* no thread to be had: walk the slice here */

@@ -133,17 +133,20 @@ class Oracle:
             raise RuntimeError("oracle_table_walk_stride")
         return end
 
-    def table_walk_mt(self, data: np.ndarray, nthreads: int) -> np.ndarray:
-        """table_walk on nthreads host threads (contiguous slices); uniform rows only."""
+    def table_walk_mt(self, data: np.ndarray, nthreads: int, lens=None) -> np.ndarray:
+        """table_walk on nthreads host threads (contiguous slices); whole rows, or the first lens[i] bytes of row i."""
         lib = self.lib()
-        lib.oracle_table_walk_stride_mt.restype = C.c_double
-        lib.oracle_table_walk_stride_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        lib.oracle_table_walk_lens_mt.restype = C.c_double
+        lib.oracle_table_walk_lens_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         data = np.ascontiguousarray(data, np.uint8)
         n, stride = data.shape
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, np.uint32)
+            assert len(lens) == n and (n == 0 or int(lens.max()) <= stride)
         end = np.zeros(n, np.uint32)
-        self.last_seconds = lib.oracle_table_walk_stride_mt(self._h, _p(data), stride, n, _p(end), int(nthreads))
+        self.last_seconds = lib.oracle_table_walk_lens_mt(self._h, _p(data), stride, _p(lens), n, _p(end), int(nthreads))
         if self.last_seconds < 0:
-            raise RuntimeError("oracle_table_walk_stride_mt")
+            raise RuntimeError("oracle_table_walk_lens_mt")
         return end
 
     def state_walk(self, data: np.ndarray, state_io: np.ndarray, lens=None) -> np.ndarray:

@@ -49,6 +49,10 @@ def test_table_walker_equals_group_scan(name):
     end2 = o.table_walk(data, lens)
     assert np.array_equal(end, end2)
     assert np.array_equal(ret == 1, end != NO)
+    # the threaded walker of bench.py's full-parity legs: whole rows and the first lens[i] bytes of each row
+    for nt in (1, 3, 16):
+        assert np.array_equal(o.table_walk_mt(data, nt, lens), end2)
+        assert np.array_equal(o.table_walk_mt(data, nt), o.table_walk(data))
 
 
 def test_oracle_semantics_edge_cases():
