@@ -162,7 +162,13 @@ int fsm_hip_exec_batch_offsets(const struct fsm_hip_dfa *dfa,
  * len[i] <= stride and off[i] <= off[i + 1], a device front cannot without a synchronising copy.  d_len[i] <= stride,
  * d_off[] non-decreasing.  The kernels read an input 16 bytes at a time from its own first byte: up to 15 bytes past
  * an input's end are READ (never past the batch's last byte, base + n * stride or base + d_off[n]), and the bytes
- * between inputs (stride > len) must therefore be addressable.  Bad metadata is undefined behaviour, not EINVAL. */
+ * between inputs (stride > len) must therefore be addressable.  Bad metadata is undefined behaviour, not EINVAL.
+ * HIP GRAPHS: once a dfa is warm (one call of the same front and size class has run: lazily built tables and scratch
+ * blocks exist) a *_device call allocates nothing and synchronises nothing, so it can be captured into a HIP graph on
+ * the capturing stream and replayed on new bytes / metadata in the same buffers (tests/test_gpu_round4.py; small batches
+ * are launch-bound: 13 us per replay against 23 us per launch at 4 096 inputs).  A captured launch keeps the slot of the
+ * per-dfa rings (device-side kernel choice, tile counters: 64 slots) it was captured with: replay one graph at a time per
+ * dfa, not concurrently with other launches on the same dfa.  fsm_hip_last_kernel_ms is meaningless for replays. */
 int fsm_hip_exec_batch_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, size_t stride, const uint32_t *d_len, size_t n,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);

@@ -231,3 +231,65 @@ def test_packed_all_every_metadata_form(hip):
     with pytest.raises(OSError):
         dfa.exec_packed_all_form(np.zeros(8, np.uint8), hip.META_OFF32, np.array([4, 2, 8], np.uint32), 2)
     dfa.close()
+
+
+def test_device_fronts_capture_into_a_hip_graph(hip):
+    """The device-pointer fronts allocate nothing and synchronise nothing once a dfa is warm, so a serving loop can capture
+    them into a HIP graph (small batches are launch-bound: 13 us per replay against 23 us per launch at 4 096 inputs):
+    every front captured on torch's capture stream, the graph replayed on CHANGED inputs, against the oracle."""
+    import torch
+    from oracle.pyoracle import Oracle
+    for name in ("c3.npz", "c1.npz"):
+        g_ = Golden(os.path.join(GOLDEN, name))
+        o = Oracle(g_.flat)
+        dfa = hip.HipDfa(g_.flat)
+        rng = np.random.RandomState(3)
+        n, L = 4096 + 5, 256
+        alpha = np.frombuffer(b"abcdwxyzLlibfsm0123456789", np.uint8)
+
+        def batch():
+            rows = alpha[rng.randint(0, len(alpha), (n, L))]
+            lens = rng.randint(0, L + 1, n).astype(np.uint32)
+            off = np.zeros(n + 1, np.uint64)
+            off[1:] = np.cumsum(lens)
+            packed = np.concatenate([rows[i, :lens[i]] for i in range(n)] + [np.zeros(16, np.uint8)])
+            return rows, lens, off, packed
+
+        rows, lens, off, packed = batch()
+        d_rows = torch.from_numpy(rows).cuda()
+        d_len = torch.from_numpy(lens.view(np.int32)).cuda()
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        d_packed = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+        d_packed[:len(packed)] = torch.from_numpy(packed).cuda()
+        d_end = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        fronts = {
+            "stride": (lambda s: dfa.exec_batch_device(d_rows.data_ptr(), L, n, d_end.data_ptr(), d_bm.data_ptr(), stream=s), False),
+            "stride+len": (lambda s: dfa.exec_batch_device(d_rows.data_ptr(), L, n, d_end.data_ptr(), d_bm.data_ptr(), d_len=d_len.data_ptr(), stream=s), True),
+            "offsets": (lambda s: dfa.exec_batch_offsets_device(d_packed.data_ptr(), d_off.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr(), stream=s), True),
+            "lengths": (lambda s: dfa.exec_batch_lengths_device(d_packed.data_ptr(), d_len.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr(), stream=s), True),
+        }
+        graphs = {}
+        for fname, (call, _) in fronts.items():
+            call(torch.cuda.current_stream().cuda_stream)      # warm: lazily built tables, scratch blocks
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                call(torch.cuda.current_stream().cuda_stream)
+            graphs[fname] = gr
+        for rep in range(3):                                    # new bytes, lengths and offsets in the SAME device buffers
+            rows, lens, off, packed = batch()
+            d_rows.copy_(torch.from_numpy(rows))
+            d_len.copy_(torch.from_numpy(lens.view(np.int32)))
+            d_off.copy_(torch.from_numpy(off.view(np.int64)))
+            d_packed[:len(packed)] = torch.from_numpy(packed).cuda()
+            for fname, (_, ragged) in fronts.items():
+                want = o.table_walk(rows, lens if ragged else None)
+                d_end.fill_(7)
+                d_bm.fill_(-1)
+                graphs[fname].replay()
+                torch.cuda.synchronize()
+                assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (name, fname, rep)
+                bits = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+                assert np.array_equal(bits, want != NO), (name, fname, rep)
+        dfa.close()
