@@ -1611,7 +1611,11 @@ walk_generic(const WalkArgs a)
 		};
 		u32x4 wq[NC];
 #pragma unroll
-		for (uint32_t j = 0; j < NC; j++) wq[j] = load_chunk(j);
+		for (uint32_t j = 0; j < NC; j++) {
+			/* a chunk that NO input of this step has is not asked for (wave-uniform: 8-16 byte lines need one load, not four) */
+			wq[j] = u32x4{0u, 0u, 0u, 0u};
+			if (j == 0 || (a.early & 16u) || __any(j < nchunks)) wq[j] = load_chunk(j);   /* (a.early & 16: always, for A/B runs) */
+		}
 		/* the previous step's results: their fin[] lookup is in flight with this step's chunks */
 		if (pend) result(ptile, pi, pvalid, pcode);
 		if (tail_in_step<Pol>(0)) {
