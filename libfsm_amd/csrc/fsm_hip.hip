@@ -671,10 +671,10 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	hipError_t e = hipSuccess;
 	std::string picked;
 	/* the ragged kernel sets bitmap bits one input at a time */
-	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = hipMemsetAsync(a.bitmap, 0, ntiles * sizeof(uint64_t), s);
+	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = zero_async(a.bitmap, ntiles * sizeof(uint64_t), s);
 	if (e == hipSuccess && c.mode == IN_LAZY && d->knob_lazy_dyn && d->d_lazy_ctr != nullptr) {
 		a.tile_ctr = d->d_lazy_ctr + (md->lazy_ctr_next++ % LAZY_CTRS);
-		e = hipMemsetAsync(a.tile_ctr, 0, sizeof(uint32_t), s);
+		e = zero_async(a.tile_ctr, sizeof(uint32_t), s);
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
 	if (e == hipSuccess && pick) {
@@ -1788,14 +1788,14 @@ static int eager_device(const struct fsm_hip_dfa *d, const void *d_base, size_t 
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	if (d->plan.emask.empty()) {
 		/* no state emits anything: the answer is all zeros, the walk is the plain one */
-		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
+		hipError_t e = zero_async(d_eager_out, n * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
 		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 		if (d_off != nullptr) return exec_offsets_device(d, d_base, d_off, n, d_end_out, nullptr, hip_stream, hint);
 		return exec_stride_device(d, d_base, stride, d_len, n, d_end_out, nullptr, hip_stream, hint);
 	}
 	if (d->plan.eager_words > 1) {
 		/* wide sets are OR-ed in place by the kernel: start from zero */
-		hipError_t e = hipMemsetAsync(d_eager_out, 0, n * d->plan.eager_words * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
+		hipError_t e = zero_async(d_eager_out, n * d->plan.eager_words * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
 		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 	}
 	WalkArgs a = d->proto;
@@ -1866,7 +1866,7 @@ static int all_device(const struct fsm_hip_dfa *dc,
 		if (d->plan.emask.empty() || d->plan.eager_words > 1) {
 			/* no state emits anything: all zeros; wide sets are OR-ed in place: start from zero */
 			const size_t w = d->plan.emask.empty() ? 1 : d->plan.eager_words;
-			hipError_t e = hipMemsetAsync(d_eager_out, 0, n * w * sizeof(uint64_t), s);
+			hipError_t e = zero_async(d_eager_out, n * w * sizeof(uint64_t), s);
 			if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 		}
 		if (!d->plan.emask.empty()) a.eager_out = d_eager_out;

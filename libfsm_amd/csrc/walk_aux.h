@@ -113,6 +113,25 @@ tile_bases_pass3(uint64_t *tbase, uint64_t ntiles1, const uint64_t *btot)
 		tbase[t] += btot[t >> 10];
 }
 
+/* Clearing an output before a kernel that ORs into it (the ragged kernel's accept bitmap, wide eager sets, the lazy walk's tile
+ * counter).  A kernel, not hipMemsetAsync: as the first node of a captured graph a memset node was seen to run before the work
+ * that precedes the graph launch on the same stream had finished (stale bits survived the clear in tests/test_gpu_round4.py's
+ * graph test, in a long session only): a kernel node is ordered like every other kernel. */
+__global__ void __launch_bounds__(256) zero_u32_kernel(uint32_t *p, uint64_t n32)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+static inline hipError_t zero_async(void *p, uint64_t bytes, hipStream_t s)
+{
+	const uint64_t n32 = bytes / 4u;
+	if (n32 == 0) return hipSuccess;
+	uint64_t blocks = (n32 + 255u) / 256u;
+	if (blocks > 4096u) blocks = 4096u;
+	hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t *>(p), n32);
+	return hipGetLastError();
+}
+
 } // namespace fsmhip
 
 #endif

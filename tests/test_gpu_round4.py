@@ -291,5 +291,5 @@ def test_device_fronts_capture_into_a_hip_graph(hip):
                 torch.cuda.synchronize()
                 assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (name, fname, rep)
                 bits = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
-                assert np.array_equal(bits, want != NO), (name, fname, rep)
+                assert np.array_equal(bits, want != NO), (name, fname, rep, int((bits & ~(want != NO)).sum()), int((~bits & (want != NO)).sum()), dfa.last_kernel_name())
         dfa.close()
