@@ -1710,11 +1710,11 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
  * permutation, (byte << 8) | lane * 4) -- but a ds_read_b32 wave is served in two 32-lane groups over 32 banks
  * (MI355X_MICROARCH.md, LDS), so lanes l and l + 32 can share a copy: lanes 32-63 read copies 0-31 and the upper
  * 128 bytes of every row are HOLES that no lookup touches.  walk_ragged keeps its ring and row records there
- * (192 16-byte entries = 24 holes per wavefront), which leaves 8 KiB of LDS per wavefront next to the 64 KiB table:
- * 10 wavefronts per workgroup instead of 8 (the holes hold 10 wavefronts' worth). */
+ * (a 64-entry ring there: 128 16-byte entries = 16 holes per wavefront), which leaves 8 KiB of LDS per wavefront next to the
+ * 64 KiB table: 12 wavefronts per workgroup instead of 8 -- exactly the 160 KiB. */
 template <class Pol> struct ragged_aux_in_holes { static constexpr bool value = false; };
 template <> struct ragged_aux_in_holes<Tiny5Pol> { static constexpr bool value = true; };
-#define FSMHIP_RAGGED_HOLE_WAVES 10u
+#define FSMHIP_RAGGED_HOLE_WAVES 12u
 
 /*
  * The retest / rx front: inputs of any length at any byte offset (packed back to back with an offsets
@@ -1738,7 +1738,8 @@ template <> struct ragged_aux_in_holes<Tiny5Pol> { static constexpr bool value =
  *    early exit, exec.c:133-138) claims the next unclaimed input of the range -- ballot, popcount
  *    rank, no atomics -- so lanes stay busy whatever the length distribution.  The (offset, length)
  *    pairs of the next <= 128 inputs wait in an LDS ring that is topped up 64 at a time, one
- *    iteration ahead of their use.
+ *    iteration ahead of their use (64 and 32 where the ring lives in the 5-bit table's holes).  With lengths
+ *    alone, the byte offset of the next input to stage is carried along from the tile base the range starts at.
  * Results are written per lane when its input ends.  (Holding them back one iteration, so that the stores
  * go out right after the wait for the tile, measured no faster -- profiles/r02t_ragged_variants.txt -- and
  * that build of walk_ragged<EagerPol<TinyPol<u64>>> returned a wrong result in ~3 % of launches with two
@@ -1752,7 +1753,7 @@ walk_ragged(const WalkArgs a)
 	const bool f_off = FRONT == FR_ANY ? a.off != nullptr : FRONT == FR_OFF64;
 	const bool f_off32 = FRONT == FR_ANY ? a.off == nullptr && a.off32 != nullptr : FRONT == FR_OFF32;
 	const bool f_lens = FRONT == FR_ANY ? a.off == nullptr && a.off32 == nullptr && a.tbase != nullptr : FRONT == FR_LENS;
-	constexpr uint32_t RING = FSMHIP_RAGGED_RING;
+	constexpr uint32_t RING = ragged_aux_in_holes<Pol>::value ? FSMHIP_RAGGED_RING / 2u : FSMHIP_RAGGED_RING, TOP = RING / 2u;   /* top-up granularity */
 	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	constexpr bool HOLES = ragged_aux_in_holes<Pol>::value;
@@ -1789,7 +1790,7 @@ walk_ragged(const WalkArgs a)
 	uint64_t staged = w_lo, next = w_lo;      /* wave-uniform: ring holds [next, staged) */
 	u32x4 soff = {0u, 0u, 0u, 0u};            /* staging loads in flight: this lane's off[i], off[i + 1] ... */
 	uint32_t slen = 0, s32a = 0, s32b = 0;    /* ... or its len[i], or its off32[i], off32[i + 1] */
-	uint64_t stb = 0;                         /* lengths only: the byte offset of the first input being staged (staged is a multiple of 64) */
+	uint64_t stb = f_lens ? a.tbase[w_lo >> 6] : 0;   /* lengths only: the byte offset of the next input to be staged, carried along (w_lo is a multiple of 64) */
 	uint32_t spend = 0;                       /* wave-uniform: how many pairs they are */
 
 	bool have = false;                        /* this lane holds an input whose segment is in the tile */
@@ -1807,7 +1808,12 @@ walk_ragged(const WalkArgs a)
 		if (spend != 0) {
 			/* lengths only: where each of the staged inputs starts (every lane takes part in the prefix sum) */
 			uint64_t pfx = 0;
-			if (f_lens) pfx = stb + wave_excl_prefix(lane < spend ? slen : 0u, lane);
+			if (f_lens) {
+				const uint32_t sl = lane < spend ? slen : 0u;
+				pfx = stb + wave_excl_prefix(sl, lane);
+				const uint64_t after = pfx + sl;      /* lane 63's: one past the last staged input */
+				stb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(after >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)after, 63);
+			}
 			if (lane < spend) {
 				const uint64_t i = staged + lane;
 				uint64_t b, l;
@@ -1890,8 +1896,8 @@ walk_ragged(const WalkArgs a)
 
 		/* top the ring up, one iteration ahead of the claims that will read it -- and BEFORE this iteration's tile
 		 * requests go out: whatever wait the compiler attaches to these loads then has nothing of the tile to wait for */
-		if (staged - next < 64u && staged < w_hi) {
-			const uint64_t c = w_hi - staged < 64u ? w_hi - staged : 64u;
+		if (staged - next < TOP && staged < w_hi) {
+			const uint64_t c = w_hi - staged < TOP ? w_hi - staged : TOP;
 			/* The loads land in registers of their own and nothing is computed from them here: any arithmetic
 			 * (or a copy into a variable shared by the two fronts) makes the compiler wait for them -- and with
 			 * them for the tile requests issued just above -- on the spot. */
@@ -1905,7 +1911,6 @@ walk_ragged(const WalkArgs a)
 				else if (f_off32) { s32a = p32[0]; s32b = p32[1]; }
 				else if (a.len != nullptr) slen = *pl;
 			}
-			if (f_lens) stb = a.tbase[staged >> 6];
 			spend = (uint32_t)c;
 		}
 
