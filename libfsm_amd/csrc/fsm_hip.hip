@@ -582,7 +582,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	int waves = d->knob_waves > 0 && d->knob_waves < wmax ? d->knob_waves : wmax;
 	if (!eager && mode != IN_RAGGED && d->knob_waves > wmax && d->knob_waves <= 16 &&
 	    !(layout == FSM_HIP_LAYOUT_COMBSELF && mode == IN_LDSDMA)) waves = d->knob_waves;   /* that kernel is compiled for 12 */
-	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 ? 2 : 1);
+	while (waves > 1 && d->table_lds + (uint32_t)waves * per_wave > d->lds_limit) waves -= (waves > 8 && mode != IN_RAGGED ? 2 : 1);
 	c.waves = waves;
 	c.lds = d->table_lds + (uint32_t)waves * per_wave;
 	int bpc = (int)(d->lds_limit / (c.lds ? c.lds : 1u));

@@ -1703,7 +1703,7 @@ __device__ __forceinline__ void write_result_lane(const WalkArgs &a, uint64_t i,
 		atomicOr(reinterpret_cast<unsigned long long *>(a.bitmap + (i >> 6)), 1ull << (i & 63u));
 }
 
-#define FSMHIP_RAGGED_RING 128u                                  /* staged (offset, length) pairs per wave */
+#define FSMHIP_RAGGED_RING 64u                                   /* staged (offset, length) pairs per wave (round 4: 64, topped up 32 at a time: 1 KiB less per wave) */
 #define FSMHIP_RAGGED_WAVE_LDS (8192u + FSMHIP_RAGGED_RING * 16u + 1024u) /* 8 KiB tile + the ring + one 16-byte row record per lane */
 
 /* Tiny5Pol's column table is 256 rows of 256 bytes (64 dword copies: the lookup address is formed by one byte
@@ -1737,8 +1737,8 @@ template <> struct ragged_aux_in_holes<Tiny5Pol> { static constexpr bool value =
  *    a lane whose input ends with the segment in hand (or sits in an absorbing state: fsm_exec's own
  *    early exit, exec.c:133-138) claims the next unclaimed input of the range -- ballot, popcount
  *    rank, no atomics -- so lanes stay busy whatever the length distribution.  The (offset, length)
- *    pairs of the next <= 128 inputs wait in an LDS ring that is topped up 64 at a time, one
- *    iteration ahead of their use (64 and 32 where the ring lives in the 5-bit table's holes).  With lengths
+ *    pairs of the next <= 64 inputs wait in an LDS ring that is topped up 32 at a time, one
+ *    iteration ahead of their use (round 4: 64 and 32 -- a kilobyte less per wavefront).  With lengths
  *    alone, the byte offset of the next input to stage is carried along from the tile base the range starts at.
  * Results are written per lane when its input ends.  (Holding them back one iteration, so that the stores
  * go out right after the wait for the tile, measured no faster -- profiles/r02t_ragged_variants.txt -- and
@@ -1753,7 +1753,7 @@ walk_ragged(const WalkArgs a)
 	const bool f_off = FRONT == FR_ANY ? a.off != nullptr : FRONT == FR_OFF64;
 	const bool f_off32 = FRONT == FR_ANY ? a.off == nullptr && a.off32 != nullptr : FRONT == FR_OFF32;
 	const bool f_lens = FRONT == FR_ANY ? a.off == nullptr && a.off32 == nullptr && a.tbase != nullptr : FRONT == FR_LENS;
-	constexpr uint32_t RING = ragged_aux_in_holes<Pol>::value ? FSMHIP_RAGGED_RING / 2u : FSMHIP_RAGGED_RING, TOP = RING / 2u;   /* top-up granularity */
+	constexpr uint32_t RING = FSMHIP_RAGGED_RING, TOP = RING / 2u;   /* top-up granularity */
 	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	constexpr bool HOLES = ragged_aux_in_holes<Pol>::value;
