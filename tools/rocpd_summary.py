@@ -39,10 +39,11 @@ def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib):
         # walk_ragged fetches 128-byte segments that start at any byte: a segment spans two memory lines and the counter tallies such
         # requests at anything between half and all of their bytes.  Calibrated, as MI355X_MICROARCH.md (HBM) asks for access patterns
         # other than the aligned 16-byte-per-lane stream, on a known byte count in this very pattern: the same kernels over 6e6 packed
-        # lines of 0-1024 bytes with early retire OFF (every byte of every line is fetched): true bytes / FETCH_SIZE = 1.135 (column
-        # table) and 1.319 (C3 table); whole aligned 1 KiB rows through the same kernel: 2.000 (profiles/r06n_ragged_fetch_calib.txt).
+        # lines of 0-1024 bytes with early retire OFF (every byte of every line is fetched): true bytes / FETCH_SIZE = 1.067 (column
+        # table) and 1.135 (C3 table) on the final kernels (profiles/r06u_ragged_fetch_calib.txt; 1.135 / 1.319 on the 8- / 10-wave
+        # kernels of r06n: the tally moves with the kernel's timing); whole aligned 1 KiB rows through the same kernel: 2.000.
         # With early retire ON (the default) a line that can no longer change state is not read on: traffic < algorithmic is real then.
-        calib = {"c2": 1.135, "c3": 1.319}.get(w_)
+        calib = {"c2": 1.067, "c3": 1.135}.get(w_)
         if calib is not None:
             read = raw * calib
     hbm = read + write_kib * 1024
