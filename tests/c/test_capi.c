@@ -12,6 +12,7 @@
  * the GPU box.  Exit status 0 = PASS, like the reference's tests/ *.c programs.
  */
 #include <assert.h>
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -111,6 +112,36 @@ main(void)
 		}
 	}
 	assert(npass >= 6);
+
+	/* round 4: the same lines with u32 offsets, with their lengths alone, and every output from one walk (the `*id` the
+	 * generated matchers return with AMBIG_EARLIEST, print/c.c:67-85: the lowest end-id of the end state) */
+	{
+		uint32_t off32[NI + 1], len[NI], e32[NI], el[NI], ea[NI], ids[NI];
+		uint64_t bm2[(NI + 63) / 64];
+		for (i = 0; i <= NI; i++) {
+			off32[i] = (uint32_t) off[i];
+		}
+		for (i = 0; i < NI; i++) {
+			len[i] = (uint32_t) (off[i + 1] - off[i]);
+		}
+		assert(fsm_hip_exec_batch_offsets32(dfa, buf, off32, NI, e32, NULL) == 0);
+		assert(fsm_hip_exec_batch_lengths(dfa, buf, len, NI, el, bm2) == 0);
+		assert(memcmp(end, e32, sizeof end) == 0 && memcmp(end, el, sizeof end) == 0 && bm2[0] == bitmap[0]);
+		assert(fsm_hip_exec_batch_packed_all(dfa, buf, FSM_HIP_META_LENGTHS, len, NI, ea, NULL, FSM_HIP_IDS_EARLIEST, ids, NULL) == 0);
+		assert(memcmp(end, ea, sizeof end) == 0);
+		for (i = 0; i < NI; i++) {
+			if (end[i] == FSM_HIP_NO_MATCH) {
+				assert(ids[i] == FSM_HIP_NO_MATCH);
+			} else {
+				fsm_end_id_t a[16];
+				size_t n = fsm_endid_count(fsm, end[i]);
+				assert(n >= 1 && n <= 16 && fsm_endid_get(fsm, end[i], n, a) == 1);
+				assert(ids[i] == a[0]); /* fsm_endid_get sorts ascending */
+			}
+		}
+		errno = 0;
+		assert(fsm_hip_exec_batch_packed_all(dfa, buf, 7, len, NI, ea, NULL, 0, NULL, NULL) == -1 && errno == EINVAL);
+	}
 
 	/* the node front: one replica per listed device (this rig lists its one GPU twice), the batch sharded
 	 * over them, results in the caller's arrays: identical to the single-dfa batch */
