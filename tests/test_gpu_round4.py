@@ -293,3 +293,40 @@ def test_device_fronts_capture_into_a_hip_graph(hip):
                 bits = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
                 assert np.array_equal(bits, want != NO), (name, fname, rep, int((bits & ~(want != NO)).sum()), int((~bits & (want != NO)).sum()), dfa.last_kernel_name())
         dfa.close()
+
+
+def test_lazy_walk_captures_into_a_hip_graph(hip):
+    """The lazy walk claims its tiles from a device counter that every launch zeroes first (a kernel node): captured once,
+    replayed on three different row sets, against the oracle."""
+    import torch
+    from oracle.pyoracle import Oracle
+    rng = np.random.RandomState(99)
+    alpha_b = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-"
+    words, flat = literal_set(hip, rng, alpha_b, 20000, 8, 16, 2)
+    o = Oracle(flat)
+    dfa = hip.HipDfa(flat, hip.LAYOUT_SPARSE)
+    dfa.tune(KNOB_SPARSE_FAST, 3)
+    n, L = 6000 + 17, 256
+    d_rows = torch.zeros((n, L), dtype=torch.uint8, device="cuda")
+    d_end = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    call = lambda s: dfa.exec_batch_device(d_rows.data_ptr(), L, n, d_end.data_ptr(), d_bm.data_ptr(), stream=s)   # noqa: E731
+    call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert "walk_lazy" in dfa.last_kernel_name()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        call(torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        rows = rows_over(rng, alpha_b, n, L, words, every=3, foreign=0.001)
+        want = o.table_walk(rows)
+        d_rows.copy_(torch.from_numpy(rows))
+        d_end.fill_(7)
+        d_bm.fill_(-1)
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), rep
+        bits = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert np.array_equal(bits, want != NO), rep
+    dfa.close()
