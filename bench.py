@@ -420,6 +420,119 @@ def node_front(a):
     print(json.dumps(out), flush=True)
 
 
+LINE_LIMIT = 6000   # the driver keeps ~8 KB of stdout: the last line must stay well under it (tests/test_bench_line.py)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short_kernel(name, width=72):
+    """rocprofv3's kernel name without the namespace, cut to `width` characters"""
+    if not name:
+        return name
+    name = str(name).replace("fsmhip::", "").replace(" (mean length < 96 B, decided on the device)", "")
+    return name if len(name) <= width else name[:width - 1] + "~"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d and d[k] is not None} if isinstance(d, dict) else d
+
+
+def compact_sub(s):
+    """One sub-result as the driver's line carries it: numbers only (the reference's own compact report,
+    src/retest/reperf.c:804-954, is the model); everything else is in bench_detail.json."""
+    roof = s.get("roofline") or {}
+    alg = roof.get("algorithmic_bytes_per_launch")
+    out = {"workload": s.get("workload"), "value": s.get("value"), "ms_per_step": s.get("ms_per_step"),
+           "frac": roof.get("frac"), "kernel_ms": roof.get("kernel_ms_avg"), "kernel": _short_kernel(roof.get("kernel"), 56)}
+    if roof.get("traffic") and alg:
+        out["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 4)
+    if roof.get("frac_on_bytes_moved") is not None:
+        out["frac_on_bytes_moved"] = roof["frac_on_bytes_moved"]
+    for k in ("lds_chain_ceiling", "gather_ceiling"):
+        c = roof.get(k)
+        if isinstance(c, dict) and c.get("implied_GBps") is not None:
+            out[k + "_GBps"] = c["implied_GBps"]
+    par = s.get("parity_vs_cpu_sample") or s.get("parity_vs_main_run")
+    if par is not None:
+        out["parity"] = "bit-exact" if str(par).startswith("bit-exact") else "MISMATCH"
+    if "full_parity" in s:
+        out["full_parity_mismatches"] = s["full_parity"].get("mismatches")
+        out["full_parity_rows"] = s["full_parity"].get("rows")
+    cb = s.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("value") is not None:
+        out["cpu_GBps"] = cb["value"]
+    return {k: v for k, v in out.items() if v is not None or k in ("value",)}
+
+
+def compact_line(res, detail_path=DETAIL_FILE, limit=LINE_LIMIT):
+    """The ONE stdout line: headline + roofline + cpu_baseline + parity + one small entry per sub-result.
+    The full record (every form, every sample description, every note) goes to `detail_path` and stderr."""
+    out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    cfg = res.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "inputs_per_gpu", "input_len", "lines", "mean_len", "dfa_states", "byte_classes", "table_layout", "table_bytes",
+                                "sharding", "accepted_inputs", "world_size"))
+    if isinstance(out["config"].get("workload"), str) and len(out["config"]["workload"]) > 260:
+        out["config"]["workload"] = out["config"]["workload"][:259] + "~"
+    roof = res.get("roofline") or {}
+    out["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if isinstance(out["roofline"]["bound"], str) and len(out["roofline"]["bound"]) > 8:
+        out["roofline"]["bound"] = "hbm"
+    out["roofline"].update(_pick(roof, ("kernel_ms_avg", "algorithmic_bytes_per_launch", "measured_read_stream_GBps", "frac_of_measured_stream", "frac_on_bytes_moved")))
+    out["roofline"]["kernel"] = _short_kernel(roof.get("kernel"))
+    if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+        out["roofline"]["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 4)
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "sample", "fsm_exec_hoisted_value", "vm_v2_value", "vm_v2_allcores_value", "vm_v2_allcores_cores", "codegen_vmc_value"))
+        if isinstance(c.get("sample"), str) and len(c["sample"]) > 150:
+            c["sample"] = c["sample"][:149] + "~"
+        out["cpu_baseline"] = c
+    if "parity_vs_cpu_sample" in res:
+        out["parity_vs_cpu_sample"] = res["parity_vs_cpu_sample"]
+    if "full_parity" in res:
+        out["full_parity"] = _pick(res["full_parity"], ("rows", "mismatches", "cpu_threads", "seconds"))
+    if "multi_gpu" in res:
+        out["multi_gpu"] = _pick(res["multi_gpu"], ("walk_kernel_ms_per_rank", "exchange_exposed_ms_per_step", "backend", "world_size"))
+    if isinstance(res.get("node_front"), dict):
+        out["node_front"] = _pick(res["node_front"], ("devices", "uses_rccl", "ms_per_step", "value_GBps", "async_ms_per_step", "async_value_GBps", "error"))
+    if isinstance(res.get("multi_dfa"), dict):
+        out["multi_dfa"] = _pick(res["multi_dfa"], ("dfas", "lines", "launches", "ms_per_call_multi", "ms_per_call_one_by_one", "speedup", "parity"))
+    if res.get("sub_results"):
+        out["sub_results"] = [compact_sub(s) for s in res["sub_results"]]
+    out["detail"] = detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    # never let the line outgrow the driver's window: shed the least important fields first
+    for drop in ("kernel", "kernel_ms", "cpu_GBps", "full_parity_rows", "traffic_over_algorithmic"):
+        if len(line) <= limit:
+            break
+        for s_ in out.get("sub_results", []):
+            s_.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > limit:
+        out.pop("node_front", None)
+        out["config"].pop("workload", None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > limit and out.get("sub_results"):
+        out["sub_results"] = [_pick(s_, ("workload", "value", "frac", "parity")) for s_ in out["sub_results"]]
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def emit(res):
+    """Full record -> bench_detail.json (+ stderr); compact line -> stdout, last."""
+    path = os.environ.get("FSM_BENCH_DETAIL", os.path.join(ROOT, DETAIL_FILE))
+    try:
+        with open(path, "w") as fh:
+            json.dump(res, fh, indent=1)
+            fh.write("\n")
+        shown = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        shown = f"(not written: {e})"
+    print(json.dumps(res), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(res, shown), flush=True)
+
+
 WORKLOAD_TEXT = {
     "c2": "c2: BASELINE configs[1] -- PCRE [Ll]ibf+(sm)* DFA (5 states, absorbing accept), ",
     "c3": "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, ",
@@ -438,10 +551,22 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without WORLD_SIZE: re-launching as %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if world != a.gpus:   # the launcher's word wins; the line reports what ran
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} ranks", file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
     # FSM_BENCH_BACKEND=gloo lets the N > 1 plumbing be exercised on a box with fewer GPUs than ranks
     # (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu); the real runs use RCCL.
@@ -619,7 +744,7 @@ def main():
                              if world > 1 else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
-            **({"multi_gpu": {"walk_kernel_ms_per_rank": rank_kms,
+            **({"multi_gpu": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "walk_kernel_ms_per_rank": rank_kms,
                               "exchange_exposed_ms_per_step": round(max(0.0, ms_step - max(rank_kms)), 4),
                               "note": "ms_per_step minus the slowest rank's walk kernel: what the RCCL all-gather of the accept bitmap (overlapped with the next step's walk) and the host loop add"}}
                if rank_kms else {}),
@@ -819,7 +944,7 @@ def main():
                  vs_baseline=None, dtype="u8", data="synthetic")
         r["config"]["inputs_per_gpu"] = r["config"]["lines"]
         r["config"]["input_len"] = r["config"]["mean_len"]
-        print(json.dumps(r), flush=True)
+        emit(r)
         return
     main_res = run(a.workload)
     subs = []
@@ -896,7 +1021,7 @@ def main():
         res["sub_results"] = subs
         if any(s.get("parity_vs_cpu_sample") == "MISMATCH" for s in subs):
             res["value"] = None
-    print(json.dumps(res), flush=True)
+    emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
