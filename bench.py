@@ -997,7 +997,7 @@ def main():
                          measured_read_stream_GBps=None if stream_gbps is None else round(stream_gbps, 1),
                          frac_of_measured_stream=None if not stream_gbps else round(main_res["roofline"]["achieved"] / stream_gbps, 4)),
     }
-    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity"):
+    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity", "multi_gpu"):
         if k in main_res:
             res[k] = main_res[k]
     # N = 1 on a box that shows several GPUs: the C multi-device front on all of them, in a subprocess of its own

@@ -99,7 +99,9 @@ enum {
 	FSM_HIP_LAYOUT_LDSSELF = 8,  /* dense table in LDS + self-loop mask per state (<= 32 classes) */
 	FSM_HIP_LAYOUT_LDS2   = 9,   /* dense table over PAIRS of byte classes in LDS: one lookup per two input bytes (plain walks) */
 	FSM_HIP_LAYOUT_MASK   = 0xf,
-	FSM_HIP_NO_EARLY_RETIRE = 0x10  /* never stop a wavefront early on absorbing states */
+	FSM_HIP_NO_EARLY_RETIRE = 0x10, /* never stop a wavefront early on absorbing states */
+	FSM_HIP_DEFER_UPLOAD  = 0x20    /* plan now, upload the layout's device image at the first call that needs it: a dfa used only
+	                                 * through fsm_hip_exec_multi (a new DFA per retest record, src/retest/main.c:1056) never does */
 };
 
 struct fsm_hip_dfa;   /* opaque: device-resident transition table + host-side end-id table */
@@ -435,6 +437,40 @@ size_t fsm_hip_eager_words(const struct fsm_hip_dfa *dfa);   /* ceil(id_count / 
 uint32_t fsm_hip_eager_id(const struct fsm_hip_dfa *dfa, unsigned bit);
 
 /* ------------------------------------------------------------------ */
+/* many-DFA front: K automata x their own lines, ONE submission        */
+/* ------------------------------------------------------------------ */
+
+/* retest compiles a DFA per record and runs a handful of lines through it (src/retest/main.c:1056-1058
+ * fsm_runner_initialize + fsm_free, :1114 fsm_runner_run; tests/retest/ *.tst: 37 DFAs x ~3 lines): one table upload and
+ * one launch per DFA is all overhead.  fsm_hip_exec_multi takes K (dfa, lines, outputs) jobs at once.  Every small job
+ * (<= 65 536 lines, <= 1 MiB of text, a plain table <= 1 MiB) rides in ONE host-to-device copy -- descriptors, the
+ * automaton's plain next-state table, offsets, lines -- ONE kernel whose workgroups map to (dfa, tile of 64 lines), and
+ * ONE copy back; a bigger job goes through its dfa's own walk (fsm_hip_exec_batch_offsets).  A dfa created with
+ * FSM_HIP_DEFER_UPLOAD and used only here never uploads a table of its own.
+ * Job q: input i is bytes off[i]..off[i+1] of base (as fsm_hip_exec_batch_offsets); end_out (n entries) and
+ * accept_bitmap (ceil(n/64) words) are optional and get exactly what fsm_hip_exec_batch_offsets gives.
+ * 0 / -1 + errno (EINVAL: NULL dfa, decreasing offsets; ENODEV; ENOMEM).  The dfas may live on several devices. */
+struct fsm_hip_multi_batch {
+	const unsigned char *base;
+	const uint64_t *off;          /* n + 1 */
+	size_t n;
+	uint32_t *end_out;
+	uint64_t *accept_bitmap;
+};
+int fsm_hip_exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k);
+/* the same with DEVICE pointers inside b[] (the array itself is host memory); enqueued on hip_stream, not waited for.
+ * Not capturable into a HIP graph (the descriptors ride in a staging block that the next call reuses). */
+int fsm_hip_exec_multi_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k, void *hip_stream);
+/* kernels the last fsm_hip_exec_multi* call of this process launched (1 when every job was small), and how many jobs rode
+ * in the fused one */
+unsigned fsm_hip_multi_last_launches(void);
+unsigned fsm_hip_multi_last_fused_jobs(void);
+/* Which device takes which job when a submission is sharded BY DFA over ndev devices: largest cost first,
+ * each to the device with the least work so far (ties: the lower device; equal costs keep their order).  Pure host
+ * arithmetic -- every rank of a multi-process run computes the same split.  dev_of[k] receives 0..ndev-1. */
+int fsm_hip_multi_assign(const uint64_t *cost, size_t k, int ndev, int *dev_of);
+
+/* ------------------------------------------------------------------ */
 /* multi-device front: one table replica per GPU of the node           */
 /* ------------------------------------------------------------------ */
 
@@ -472,6 +508,13 @@ int fsm_hip_node_exec_batch(struct fsm_hip_node *node,
 	uint32_t *end_out, uint64_t *accept_bitmap);
 int fsm_hip_node_exec_batch_offsets(struct fsm_hip_node *node,
 	const unsigned char *base, const uint64_t *off, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+/* ... and the compact packed forms of fsm_hip_exec_batch_offsets32 / _lengths, sharded the same way (round 5) */
+int fsm_hip_node_exec_batch_offsets32(struct fsm_hip_node *node,
+	const unsigned char *base, const uint32_t *off32, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap);
+int fsm_hip_node_exec_batch_lengths(struct fsm_hip_node *node,
+	const unsigned char *base, const uint32_t *len, size_t n,
 	uint32_t *end_out, uint64_t *accept_bitmap);
 
 /* Device-resident shards (inputs generated or loaded on the GPUs): d_base[k] = shard k's rows on device k,
@@ -521,6 +564,11 @@ int fsm_hip_node_exec_batch_ids(struct fsm_hip_node *node,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, int mode, uint32_t *id_out);
 int fsm_hip_node_exec_batch_eager(struct fsm_hip_node *node,
 	const unsigned char *base, size_t stride, const uint32_t *len, size_t n, uint32_t *end_out, uint64_t *eager_out);
+
+/* A many-DFA submission sharded BY DFA over the node's devices: nodes[q] holds job q's automaton (every node over the same
+ * device list), fsm_hip_multi_assign(cost = text bytes + 64 per line) picks the device, each device runs ONE
+ * fsm_hip_exec_multi over its jobs on its replicas (its own host thread), results land in the caller's arrays. */
+int fsm_hip_node_exec_multi(struct fsm_hip_node *const *nodes, const struct fsm_hip_multi_batch *b, size_t k);
 
 /* ------------------------------------------------------------------ */
 /* synthetic input generator (benchmarks and parity tests)            */

@@ -24,6 +24,7 @@ META_OFF64, META_OFF32, META_LENGTHS = 0, 1, 2   # fsm_hip_exec_batch_packed_all
 LAYOUT_NAMES = {1: "tiny", 2: "lds", 3: "comb", 4: "global", 5: "comb256", 6: "combself", 7: "sparse", 8: "ldsself", 9: "lds2"}
 ALL_LAYOUTS = (LAYOUT_TINY, LAYOUT_COMBSELF, LAYOUT_LDS2, LAYOUT_COMB256, LAYOUT_LDSSELF, LAYOUT_LDS, LAYOUT_COMB, LAYOUT_SPARSE, LAYOUT_GLOBAL)
 NO_EARLY_RETIRE = 0x10
+DEFER_UPLOAD = 0x20      # plan now, upload the layout's device image at the first call that needs it (fsm_hip_exec_multi never does)
 
 KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_RETIRE, KNOB_MASK, KNOB_HOT_BYTES, KNOB_SEG, KNOB_PREFETCH, KNOB_NT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 KNOB_NOSKIP = 13
@@ -777,42 +778,30 @@ class HipNode:
         return end, bm
 
     def exec_batch_offsets32(self, base: np.ndarray, off32: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
-        """fsm_hip_exec_batch_offsets32: u32 offsets (batches below 4 GiB)."""
+        """fsm_hip_node_exec_batch_offsets32: u32 offsets (batches below 4 GiB), sharded over the devices."""
         base = np.ascontiguousarray(base, dtype=np.uint8)
         off32 = np.ascontiguousarray(off32, dtype=np.uint32)
         n = len(off32) - 1
         end = np.empty(n, dtype=np.uint32) if want_end else None
         bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
         C.set_errno(0)
-        if self._lib.fsm_hip_exec_batch_offsets32(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(off32.ctypes.data),
+        if self._lib.fsm_hip_node_exec_batch_offsets32(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(off32.ctypes.data),
                                                   C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
-            raise _oserr("fsm_hip_exec_batch_offsets32")
+            raise _oserr("fsm_hip_node_exec_batch_offsets32")
         return end, bm
 
     def exec_batch_lengths(self, base: np.ndarray, lens: np.ndarray, want_bitmap: bool = True, want_end: bool = True):
-        """fsm_hip_exec_batch_lengths: inputs packed back to back, their lengths and nothing else."""
+        """fsm_hip_node_exec_batch_lengths: inputs packed back to back, their lengths and nothing else, sharded over the devices."""
         base = np.ascontiguousarray(base, dtype=np.uint8)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         n = len(lens)
         end = np.empty(n, dtype=np.uint32) if want_end else None
         bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
         C.set_errno(0)
-        if self._lib.fsm_hip_exec_batch_lengths(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(lens.ctypes.data if n else None),
+        if self._lib.fsm_hip_node_exec_batch_lengths(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_void_p(lens.ctypes.data if n else None),
                                                 C.c_size_t(n), C.c_void_p(end.ctypes.data if want_end else None), C.c_void_p(bm.ctypes.data if want_bitmap else None)) != 0:
-            raise _oserr("fsm_hip_exec_batch_lengths")
+            raise _oserr("fsm_hip_node_exec_batch_lengths")
         return end, bm
-
-    def exec_batch_offsets32_device(self, d_base: int, d_off32: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
-        C.set_errno(0)
-        if self._lib.fsm_hip_exec_batch_offsets32_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_off32), C.c_size_t(n), C.c_void_p(d_end or None),
-                                                         C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
-            raise _oserr("fsm_hip_exec_batch_offsets32_device")
-
-    def exec_batch_lengths_device(self, d_base: int, d_len: int, n: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
-        C.set_errno(0)
-        if self._lib.fsm_hip_exec_batch_lengths_device(C.c_void_p(self._h), C.c_void_p(d_base), C.c_void_p(d_len), C.c_size_t(n), C.c_void_p(d_end or None),
-                                                       C.c_void_p(d_bitmap or None), C.c_void_p(stream or None)) != 0:
-            raise _oserr("fsm_hip_exec_batch_lengths_device")
 
     def exec_strings(self, strings: Sequence[bytes]):
         off = np.zeros(len(strings) + 1, dtype=np.uint64)
@@ -893,6 +882,78 @@ def _node_exec_batch_ids(self, data: np.ndarray, mode: int, lens: Optional[np.nd
 HipNode.exec_device = _node_exec_device
 HipNode.wait = _node_wait
 HipNode.exec_batch_ids = _node_exec_batch_ids
+
+
+class MultiBatch(C.Structure):
+    """struct fsm_hip_multi_batch (include/fsm_hip.h)"""
+    _fields_ = [("base", C.c_void_p), ("off", C.c_void_p), ("n", C.c_size_t), ("end_out", C.c_void_p), ("accept_bitmap", C.c_void_p)]
+
+
+def exec_multi(dfas: Sequence["HipDfa"], jobs: Sequence[Sequence[bytes]], want_bitmap: bool = True, nodes: Optional[Sequence["HipNode"]] = None):
+    """fsm_hip_exec_multi: job q = the strings jobs[q] through dfas[q]; ONE submission.  Returns [(end, bitmap), ...].
+    nodes: fsm_hip_node_exec_multi instead (the list sharded by DFA over the nodes' devices)."""
+    lib = load_library()
+    k = len(jobs)
+    keep, arr = [], (MultiBatch * max(k, 1))()
+    outs = []
+    for q, strs in enumerate(jobs):
+        n = len(strs)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in strs])
+        base = np.frombuffer(b"".join(strs) or b"\0", dtype=np.uint8)
+        end = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64) if want_bitmap else None
+        keep += [off, base, end, bm]
+        arr[q].base, arr[q].off, arr[q].n = base.ctypes.data, off.ctypes.data, n
+        arr[q].end_out = end.ctypes.data if n else None
+        arr[q].accept_bitmap = bm.ctypes.data if (want_bitmap and n) else None
+        outs.append((end, bm))
+    C.set_errno(0)
+    if nodes is not None:
+        hs = (C.c_void_p * max(k, 1))(*[nd._h for nd in nodes])
+        if lib.fsm_hip_node_exec_multi(hs, arr, C.c_size_t(k)) != 0:
+            raise _oserr("fsm_hip_node_exec_multi")
+    else:
+        hs = (C.c_void_p * max(k, 1))(*[d._h for d in dfas])
+        if lib.fsm_hip_exec_multi(hs, arr, C.c_size_t(k)) != 0:
+            raise _oserr("fsm_hip_exec_multi")
+    return outs
+
+
+def exec_multi_device(dfas: Sequence["HipDfa"], jobs: Sequence[tuple], stream: int = 0):
+    """fsm_hip_exec_multi_device: jobs[q] = (d_base, d_off, n, d_end, d_bitmap) device pointers (0 = NULL)."""
+    lib = load_library()
+    k = len(jobs)
+    arr = (MultiBatch * max(k, 1))()
+    for q, (b, o, n, e, m) in enumerate(jobs):
+        arr[q].base, arr[q].off, arr[q].n, arr[q].end_out, arr[q].accept_bitmap = b or None, o or None, n, e or None, m or None
+    hs = (C.c_void_p * max(k, 1))(*[d._h for d in dfas])
+    C.set_errno(0)
+    if lib.fsm_hip_exec_multi_device(hs, arr, C.c_size_t(k), C.c_void_p(stream or None)) != 0:
+        raise _oserr("fsm_hip_exec_multi_device")
+
+
+def multi_last_launches() -> int:
+    lib = load_library()
+    lib.fsm_hip_multi_last_launches.restype = C.c_uint
+    return int(lib.fsm_hip_multi_last_launches())
+
+
+def multi_last_fused_jobs() -> int:
+    lib = load_library()
+    lib.fsm_hip_multi_last_fused_jobs.restype = C.c_uint
+    return int(lib.fsm_hip_multi_last_fused_jobs())
+
+
+def multi_assign(cost: Sequence[int], ndev: int) -> np.ndarray:
+    """fsm_hip_multi_assign: which device takes which job of a many-DFA submission (largest first, least loaded device).  Host arithmetic only."""
+    lib = load_library()
+    c = np.ascontiguousarray(cost, dtype=np.uint64)
+    out = np.zeros(len(c), dtype=np.int32)
+    C.set_errno(0)
+    if lib.fsm_hip_multi_assign(C.c_void_p(c.ctypes.data if len(c) else None), C.c_size_t(len(c)), C.c_int(ndev), C.c_void_p(out.ctypes.data if len(c) else None)) != 0:
+        raise _oserr("fsm_hip_multi_assign")
+    return out
 
 
 def _gen_args(alphabet, plant):

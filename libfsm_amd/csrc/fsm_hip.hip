@@ -14,11 +14,13 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/fsm_hip.h"
 #include "../../include/fsm_hip_plan.h"
 #include "plan.h"
+#include "dfa_access.h"
 #include "launch.h"
 #include "gen_kernels.h"
 #include "walk_aux.h"
@@ -98,6 +100,7 @@ struct fsm_hip_dfa {
 	bool sparse_fast_ok = true;  /* the record array sits inside one 4 GiB window (SparseFastPol::enter) */
 	int knob_pick_mean = 96;     /* variable-length batches whose mean input length is below this many bytes go to walk_generic */
 	unsigned flags = 0;
+	bool uploaded = false;       /* the layout's tables are on the device (FSM_HIP_DEFER_UPLOAD: not before the first single-dfa call) */
 };
 
 /* GLOBAL layout: how much of the table head (rows nearest the start state) every workgroup
@@ -149,7 +152,14 @@ struct DevGuard {
 
 typedef std::lock_guard<std::recursive_mutex> DfaLock;
 
-extern "C" int fsm_hip_version(void) { return 200; }
+extern "C" int fsm_hip_version(void) { return 210; }
+
+/* for multi.hip (dfa_access.h): the host-side plan and the device of a dfa */
+namespace fsmhip {
+const Plan *dfa_plan(const fsm_hip_dfa *d) { return &d->plan; }
+int dfa_device(const fsm_hip_dfa *d) { return d->device; }
+int dfa_ncu(const fsm_hip_dfa *d) { return d->ncu; }
+}
 
 /* ------------------------------------------------------------------ */
 /* create / free / info                                               */
@@ -167,27 +177,13 @@ static hipError_t upload(T **dst, const std::vector<T> &src)
 	return e;
 }
 
-extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc *desc, unsigned flags)
+/* the layout's device image + the per-dfa launch resources (events, private stream).  fsm_hip_dfa_create does this at once
+ * unless FSM_HIP_DEFER_UPLOAD asks to wait for the first call that needs it: a dfa that is only ever used through
+ * fsm_hip_exec_multi (retest: a new DFA per record, a few lines each) never needs it -- its plain table rides in that call's
+ * one host-to-device copy */
+static int dfa_upload(fsm_hip_dfa *d)
 {
-	int ndev = 0;
-	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-		errno = ENODEV; /* no CPU fallback by design */
-		return nullptr;
-	}
-	fsm_hip_dfa *d = new (std::nothrow) fsm_hip_dfa();
-	if (d == nullptr) { errno = ENOMEM; return nullptr; }
-	d->flags = flags;
-	{
-		int v = 0;
-		HIP_TRY(hipGetDevice(&d->device));
-		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) d->ncu = v;
-		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) == hipSuccess && v > 0) d->lds_limit = (uint32_t)v;
-		if (d->lds_limit > 160u * 1024u) d->lds_limit = 160u * 1024u;
-	}
-	{
-		int r = build_plan(desc, flags, d->lds_limit, d->plan);
-		if (r != 0) { errno = r; goto fail; }
-	}
+	const unsigned flags = d->flags;
 	{
 		Plan &p = d->plan;
 		WalkArgs &a = d->proto;
@@ -450,6 +446,45 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 	HIP_TRY(hipEventCreate(&d->ev0));
 	HIP_TRY(hipEventCreate(&d->ev1));
 	HIP_TRY(hipStreamCreateWithFlags(&d->hs, hipStreamNonBlocking));
+	d->uploaded = true;
+	return 0;
+fail:
+	return -1;
+}
+
+static int ensure_uploaded(const fsm_hip_dfa *cd)
+{
+	if (cd->uploaded) return 0;
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(cd);
+	DfaLock lk(d->mu);
+	if (d->uploaded) return 0;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	return dfa_upload(d);
+}
+
+extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc *desc, unsigned flags)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		errno = ENODEV; /* no CPU fallback by design */
+		return nullptr;
+	}
+	fsm_hip_dfa *d = new (std::nothrow) fsm_hip_dfa();
+	if (d == nullptr) { errno = ENOMEM; return nullptr; }
+	d->flags = flags;
+	{
+		int v = 0;
+		HIP_TRY(hipGetDevice(&d->device));
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) d->ncu = v;
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) == hipSuccess && v > 0) d->lds_limit = (uint32_t)v;
+		if (d->lds_limit > 160u * 1024u) d->lds_limit = 160u * 1024u;
+	}
+	{
+		int r = build_plan(desc, flags, d->lds_limit, d->plan);
+		if (r != 0) { errno = r; goto fail; }
+	}
+	if (!(flags & FSM_HIP_DEFER_UPLOAD) && dfa_upload(d) != 0) goto fail;
 	return d;
 fail:
 	{
@@ -498,7 +533,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
  * ragged kernel's 32-bit piece count cannot (>= 2^36 bytes) */
 static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false, bool resumed = false)
 {
-	LaunchCfg c;
+	LaunchCfg c = LaunchCfg();    /* kfn = nullptr until a launch sets it */
 	const uint32_t layout = d->plan.layout;
 	c.nb = 8;
 	c.seg = 128;
@@ -623,6 +658,13 @@ static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg
 static std::string kernel_name(const void *kfn, hipStream_t s)
 {
 	if (kfn == nullptr) return "?";
+	/* resolved once per kernel: the lookup + demangling is ~10 us, a small batch's walk is 20 */
+	static std::mutex cache_mu;
+	static std::vector<std::pair<const void *, std::string>> cache;
+	{
+		std::lock_guard<std::mutex> lk(cache_mu);
+		for (const auto &e : cache) if (e.first == kfn) return e.second;
+	}
 	const char *m = hipKernelNameRefByPtr(kfn, s);
 	if (m == nullptr) return "?";
 	int st = 0;
@@ -632,6 +674,8 @@ static std::string kernel_name(const void *kfn, hipStream_t s)
 	const size_t p = r.find("(fsmhip::WalkArgs");
 	if (p != std::string::npos) r.resize(p);
 	if (r.compare(0, 5, "void ") == 0) r.erase(0, 5);
+	std::lock_guard<std::mutex> lk(cache_mu);
+	cache.emplace_back(kfn, r);
 	return r;
 }
 
@@ -689,7 +733,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 			ag.skip_flag = a.pick_flag;
 			ag.skip_when = 0u;
 			e = launch_layout(d, eager, g, ag, dim3((unsigned)(gb0 < gcap ? gb0 : gcap)), dim3((unsigned)g.waves * 64u), s);
-			picked = kernel_name(g.kfn, s) + " (mean length < " + std::to_string(d->knob_pick_mean) + " B, decided on the device) | ";
+			if (e == hipSuccess) picked = kernel_name(g.kfn, s) + " (mean length < " + std::to_string(d->knob_pick_mean) + " B, decided on the device) | ";
 			a.skip_flag = a.pick_flag;
 			a.skip_when = 1u;   /* long: walk_ragged, below */
 		}
@@ -697,7 +741,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (e == hipSuccess) {
 		c.kfn = nullptr;
 		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
-		md->last_kernel = picked + kernel_name(c.kfn, s);
+		if (e == hipSuccess) md->last_kernel = picked + kernel_name(c.kfn, s);
 		debug_stage(s, "walk");
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
@@ -758,6 +802,7 @@ static int exec_stride_device(const struct fsm_hip_dfa *d,
 	if (d == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = stride;
@@ -788,6 +833,7 @@ static int exec_packed_device(const struct fsm_hip_dfa *d,
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = 0;
@@ -798,6 +844,9 @@ static int exec_packed_device(const struct fsm_hip_dfa *d,
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
 	const bool lenonly = d_off == nullptr && d_off32 == nullptr;
+	/* ONE critical section over the pre-pass, the walk and the "block busy until here" event: another host thread's call on
+	 * this dfa must not refill the tile-base block between them (the mutex is recursive: the three take it again) */
+	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
 	if (lenonly) {
 		a.len = d_len;
 		if (tile_bases(const_cast<fsm_hip_dfa *>(d), d_len, n, s, &a.tbase) != 0) return -1;
@@ -898,6 +947,7 @@ struct HostCall {
 
 	int begin()
 	{
+		if (ensure_uploaded(d) != 0) return -1;   /* FSM_HIP_DEFER_UPLOAD: the private stream and the tables come with the first call */
 		size_t o = 0;
 		h2d_end = 0;
 		d2h_begin = (size_t)-1;
@@ -1048,6 +1098,7 @@ extern "C" int fsm_hip_exec_batch_lengths(const struct fsm_hip_dfa *d,
 extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_info *out)
 {
 	if (d == nullptr || out == nullptr) { errno = EINVAL; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
 	memset(out, 0, sizeof *out);
 	const Plan &p = d->plan;
 	out->nstates = p.nstates;
@@ -1075,6 +1126,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 {
 	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
@@ -1470,6 +1522,7 @@ fail:
  *             (src/libfsm/vm/retlist.c:93-138, cmp_ret). */
 static int ensure_ids(fsm_hip_dfa *d)
 {
+	if (ensure_uploaded(d) != 0) return -1;
 	DfaLock lk(d->mu);
 	if (d->ids_ready) return 0;
 	const Plan &p = d->plan;
@@ -1528,6 +1581,7 @@ static int ids_device(fsm_hip_dfa *d, const void *d_base, size_t stride, const u
 	}
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = d_off ? 0 : stride;
@@ -1557,7 +1611,7 @@ extern "C" int fsm_hip_exec_batch_ids_offsets_device(const struct fsm_hip_dfa *d
 }
 
 /* what the host fronts know about their batch (launch_walk picks the kernel from it) */
-static BatchHint host_hint(size_t in_bytes, const uint32_t *len, const uint64_t *off, size_t n)
+static BatchHint host_hint(size_t in_bytes, const uint32_t *len, const uint64_t *off, size_t n, int pick_mean)
 {
 	BatchHint hint;
 	hint.bytes = in_bytes;
@@ -1565,9 +1619,9 @@ static BatchHint host_hint(size_t in_bytes, const uint32_t *len, const uint64_t 
 	if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
 		uint64_t sum = 0;
 		for (size_t i = 0; i < n; i++) sum += len[i];
-		hint.short_mean = sum / n < 96u;
+		hint.short_mean = sum / n < (uint64_t)pick_mean;
 	} else if (off != nullptr) {
-		hint.short_mean = in_bytes / n < 96u;
+		hint.short_mean = in_bytes / n < (size_t)pick_mean;
 	}
 	return hint;
 }
@@ -1604,7 +1658,7 @@ static int ids_host(const struct fsm_hip_dfa *d, const unsigned char *base, size
 	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (ids_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n, mode,
-	               hc.dev<uint32_t>(p_out), hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	               hc.dev<uint32_t>(p_out), hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
 	return hc.end();
 }
 
@@ -1658,6 +1712,7 @@ extern "C" int fsm_hip_ret_get(const struct fsm_hip_dfa *dc, uint32_t ret_index,
 
 static int ensure_resume(fsm_hip_dfa *d)
 {
+	if (ensure_uploaded(d) != 0) return -1;
 	DfaLock lk(d->mu);
 	if (d->resume_ready) return 0;
 	const Plan &p = d->plan;
@@ -1693,6 +1748,7 @@ static int resume_device(fsm_hip_dfa *d, const void *d_base, size_t stride, cons
 	if (ensure_resume(d) != 0) return -1;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = d_off ? 0 : stride;
@@ -1741,7 +1797,7 @@ static int resume_host(const struct fsm_hip_dfa *d, const unsigned char *base, s
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (resume_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
-	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
 	return hc.end();
 }
 
@@ -1798,6 +1854,7 @@ static int eager_device(const struct fsm_hip_dfa *d, const void *d_base, size_t 
 		hipError_t e = zero_async(d_eager_out, n * d->plan.eager_words * sizeof(uint64_t), static_cast<hipStream_t>(hip_stream));
 		if (e != hipSuccess) { errno = hip_errno(e); return -1; }
 	}
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = d_off ? 0 : stride;
@@ -1849,6 +1906,7 @@ static int all_device(const struct fsm_hip_dfa *dc,
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
 	a.base = static_cast<const uint8_t *>(d_base);
 	a.stride = packed ? 0 : stride;
@@ -1872,6 +1930,7 @@ static int all_device(const struct fsm_hip_dfa *dc,
 		if (!d->plan.emask.empty()) a.eager_out = d_eager_out;
 	}
 	const bool lo = lens_only && d_off == nullptr && d_off32 == nullptr;
+	DfaLock lk(d->mu);   /* pre-pass, walk and the block's event in one critical section (see exec_packed_device) */
 	if (lo && tile_bases(d, d_len, n, s, &a.tbase) != 0) return -1;
 	const bool fast = !packed && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
@@ -1941,7 +2000,7 @@ extern "C" int fsm_hip_exec_batch_packed_all(const struct fsm_hip_dfa *d,
 	if (hc.begin() != 0) return -1;
 	BatchHint hint;
 	hint.bytes = in_bytes;
-	hint.short_mean = in_bytes / n < 96;
+	hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
 	const void *dm = hc.dev<unsigned char>(p_meta);
 	if (all_device(d, hc.dev<unsigned char>(p_in), 0, meta_form == FSM_HIP_META_LENGTHS ? static_cast<const uint32_t *>(dm) : nullptr,
 	               meta_form == FSM_HIP_META_OFF64 ? static_cast<const uint64_t *>(dm) : nullptr,
@@ -1966,7 +2025,7 @@ static int eager_host(const struct fsm_hip_dfa *d, const unsigned char *base, si
 	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
 	if (eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
-	                 hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs, host_hint(in_bytes, len, off, n)) != 0) return -1;
+	                 hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
 	return hc.end();
 }
 
@@ -1989,6 +2048,7 @@ extern "C" int fsm_hip_exec_batch_eager_offsets(const struct fsm_hip_dfa *d,
 
 static int ensure_trace(fsm_hip_dfa *d)
 {
+	if (ensure_uploaded(d) != 0) return -1;
 	DfaLock lk(d->mu);
 	if (d->trace_ready) return 0;
 	const Plan &p = d->plan;

@@ -311,6 +311,57 @@ extern "C" int fsm_hip_node_exec_batch_offsets(struct fsm_hip_node *nd,
 	});
 }
 
+/* the compact packed forms (u32 offsets below 4 GiB; lengths alone): each shard goes to its replica's own front */
+extern "C" int fsm_hip_node_exec_batch_offsets32(struct fsm_hip_node *nd,
+	const unsigned char *base, const uint32_t *off32, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (nd == nullptr || (n != 0 && off32 == nullptr)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	std::lock_guard<std::mutex> lk(nd->mu);
+	return per_device(nd, [&](int k) {
+		size_t first, count;
+		fsm_hip_node_shard(nd, n, k, &first, &count);
+		if (count == 0) return 0;
+		std::vector<uint32_t> o(count + 1);
+		for (size_t i = 0; i <= count; i++) {
+			if (off32[first + i] < off32[first]) { errno = EINVAL; return -1; }
+			o[i] = off32[first + i] - off32[first];
+		}
+		return fsm_hip_exec_batch_offsets32(nd->dfa[(size_t)k], base ? base + off32[first] : nullptr, o.data(), count,
+		                                    end_out ? end_out + first : nullptr, accept_bitmap ? accept_bitmap + first / 64 : nullptr);
+	});
+}
+
+extern "C" int fsm_hip_node_exec_batch_lengths(struct fsm_hip_node *nd,
+	const unsigned char *base, const uint32_t *len, size_t n,
+	uint32_t *end_out, uint64_t *accept_bitmap)
+{
+	if (nd == nullptr || (n != 0 && len == nullptr)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	std::lock_guard<std::mutex> lk(nd->mu);
+	/* where each shard's bytes start: one pass over the lengths */
+	const size_t g = nd->dev.size();
+	std::vector<uint64_t> sbeg(g + 1, 0);
+	{
+		size_t k = 0, first = 0, count = 0;
+		uint64_t run = 0;
+		fsm_hip_node_shard(nd, n, 0, &first, &count);
+		for (size_t i = 0; i < n; i++) {
+			while (k + 1 < g && i >= first + count) { k++; fsm_hip_node_shard(nd, n, (int)k, &first, &count); sbeg[k] = run; }
+			run += len[i];
+		}
+		for (k++; k <= g; k++) sbeg[k] = run;
+	}
+	return per_device(nd, [&](int k) {
+		size_t first, count;
+		fsm_hip_node_shard(nd, n, k, &first, &count);
+		if (count == 0) return 0;
+		return fsm_hip_exec_batch_lengths(nd->dfa[(size_t)k], base ? base + sbeg[(size_t)k] : nullptr, len + first, count,
+		                                  end_out ? end_out + first : nullptr, accept_bitmap ? accept_bitmap + first / 64 : nullptr);
+	});
+}
+
 /* accepted inputs of the whole batch after an exchange: device 0's reduced count (RCCL) or the sum of the devices' */
 static int read_count(fsm_hip_node *nd, int slot, unsigned long long *total)
 {
@@ -493,5 +544,30 @@ extern "C" int fsm_hip_node_exec_batch_eager(struct fsm_hip_node *nd,
 		if (count == 0) return 0;
 		return fsm_hip_exec_batch_eager(nd->dfa[(size_t)k], base + first * stride, stride, len ? len + first : nullptr, count,
 		                                end_out ? end_out + first : nullptr, eager_out + first * W);
+	});
+}
+
+/* many DFAs, sharded by DFA (include/fsm_hip.h) */
+extern "C" int fsm_hip_node_exec_multi(struct fsm_hip_node *const *nodes, const struct fsm_hip_multi_batch *b, size_t k)
+{
+	if (k == 0) return 0;
+	if (nodes == nullptr || b == nullptr || nodes[0] == nullptr) { errno = EINVAL; return -1; }
+	fsm_hip_node *nd0 = nodes[0];
+	const size_t g = nd0->dev.size();
+	std::vector<uint64_t> cost(k);
+	for (size_t q = 0; q < k; q++) {
+		if (nodes[q] == nullptr || nodes[q]->dev != nd0->dev || (b[q].n != 0 && b[q].off == nullptr)) { errno = EINVAL; return -1; }
+		cost[q] = b[q].n ? b[q].off[b[q].n] + 64u * (uint64_t)b[q].n : 0u;
+	}
+	std::vector<int> dev_of(k);
+	if (fsm_hip_multi_assign(cost.data(), k, (int)g, dev_of.data()) != 0) return -1;
+	std::lock_guard<std::mutex> lk(nd0->mu);
+	return per_device(nd0, [&](int dv) {
+		std::vector<const fsm_hip_dfa *> dl;
+		std::vector<fsm_hip_multi_batch> bl;
+		for (size_t q = 0; q < k; q++)
+			if (dev_of[q] == dv) { dl.push_back(nodes[q]->dfa[(size_t)dv]); bl.push_back(b[q]); }
+		if (dl.empty()) return 0;
+		return fsm_hip_exec_multi(dl.data(), bl.data(), dl.size());
 	});
 }

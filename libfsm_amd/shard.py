@@ -52,3 +52,22 @@ def gather_bitmap_ragged(local_words, counts, group=None):
     out = torch.empty(mx * world, dtype=local_words.dtype, device=local_words.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * mx: r * mx + words[r]] for r in range(world)])
+
+
+def assign_by_dfa(costs, world: int):
+    """Many-DFA submissions shard BY DFA: job q goes to rank assign_by_dfa(costs, world)[q] -- largest cost
+    first, each to the rank with the least work so far, ties to the lower rank.  The same rule as the C front's
+    fsm_hip_multi_assign (tests/test_dist.py holds them equal), so every rank computes the same split without talking."""
+    order = sorted(range(len(costs)), key=lambda q: -int(costs[q]))      # stable: equal costs keep their order
+    load = [0] * world
+    out = [0] * len(costs)
+    for q in order:
+        best = min(range(world), key=lambda g: (load[g], g))
+        out[q] = best
+        load[best] += int(costs[q]) or 1
+    return out
+
+
+def job_cost(n_lines: int, n_bytes: int) -> int:
+    """what fsm_hip_node_exec_multi charges a job: its text bytes + 64 per line"""
+    return int(n_bytes) + 64 * int(n_lines)

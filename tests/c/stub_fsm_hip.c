@@ -25,13 +25,13 @@ struct fsm_hip_dfa { struct fsm_dfavm *vm; const struct fsm *fsm; /* valid while
 struct span { const unsigned char *p, *e; };
 static int span_getc(void *o) { struct span *s = o; return s->p == s->e ? -1 : *s->p++; }
 
-static unsigned long n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs;
+static unsigned long n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs, n_multi, n_multi_jobs, n_multi_inputs;
 
 static void
 report(void)
 {
-	fprintf(stderr, "stub_fsm_hip: compile=%lu batch_calls=%lu batch_inputs=%lu single_calls=%lu stride_calls=%lu stride_inputs=%lu\n",
-		n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs);
+	fprintf(stderr, "stub_fsm_hip: compile=%lu batch_calls=%lu batch_inputs=%lu single_calls=%lu stride_calls=%lu stride_inputs=%lu multi_calls=%lu multi_jobs=%lu multi_inputs=%lu\n",
+		n_compile, n_batch, n_batch_inputs, n_single, n_stride, n_stride_inputs, n_multi, n_multi_jobs, n_multi_inputs);
 }
 
 struct fsm_hip_dfa *
@@ -106,6 +106,34 @@ fsm_hip_exec_batch(const struct fsm_hip_dfa *d, const unsigned char *base, size_
 	}
 	return 0;
 }
+
+/* the many-DFA front (`retest -l hip`: a whole .tst file per submission): job by job through the reference's VM */
+struct fsm_hip_multi_batch {
+	const unsigned char *base;
+	const uint64_t *off;
+	size_t n;
+	uint32_t *end_out;
+	uint64_t *accept_bitmap;
+};
+
+int
+fsm_hip_exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k)
+{
+	size_t q, i;
+	n_multi++;
+	n_multi_jobs += k;
+	for (q = 0; q < k; q++) {
+		n_multi_inputs += b[q].n;
+		for (i = 0; i < b[q].n; i++) {
+			if (b[q].accept_bitmap != NULL && fsm_vm_match_buffer(dfa[q]->vm, (const char *) b[q].base + b[q].off[i], (size_t) (b[q].off[i + 1] - b[q].off[i]))) {
+				b[q].accept_bitmap[i / 64] |= (uint64_t) 1 << (i % 64);
+			}
+		}
+	}
+	return 0;
+}
+
+unsigned fsm_hip_multi_last_launches(void) { return 1; }
 
 int
 fsm_hip_match_file(const struct fsm_hip_dfa *d, FILE *f)

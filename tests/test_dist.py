@@ -87,3 +87,69 @@ def test_two_rank_gather_equals_single_process(tmp_path, built, n_total, ragged)
     whole = Oracle(g.flat).table_walk(gen_inputs_host(n_total, 128, 0, 99, None, b"Libfsm", 8))
     assert np.array_equal(got[:-1], _bitmap(whole))
     assert int(got[-1]) == int((whole != 0xFFFFFFFF).sum())
+
+
+# ---- many-DFA submissions shard BY DFA (fsm_hip_node_exec_multi / fsm_hip_multi_assign) ---------------------
+
+def test_assign_by_dfa_is_the_c_fronts_rule(built):
+    """libfsm_amd.shard.assign_by_dfa == fsm_hip_multi_assign (largest first, least loaded device, ties low), and the split is
+    balanced: no device carries more than the mean plus the largest job."""
+    import libfsm_amd as hip
+    from libfsm_amd.shard import assign_by_dfa
+    rng = np.random.RandomState(3)
+    for _ in range(300):
+        k, world = rng.randint(0, 60), rng.randint(1, 9)
+        cost = (rng.randint(0, 5000, k) * rng.randint(0, 2, k)).astype(np.uint64)
+        a = hip.multi_assign(cost, world)
+        assert list(a) == assign_by_dfa(list(cost), world)
+        if k:
+            load = np.bincount(a, weights=np.maximum(cost, 1).astype(np.float64), minlength=world)
+            assert load.max() <= np.maximum(cost, 1).sum() / world + max(int(cost.max()), 1)
+
+
+def _multi_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from common import Golden, all_golden_paths
+    from libfsm_amd.shard import assign_by_dfa, job_cost
+    from oracle.pyoracle import Oracle
+    gs = [Golden(p) for p in all_golden_paths() if "/retest/" in p]
+    jobs = [g.strings() for g in gs]
+    owner = assign_by_dfa([job_cost(len(j), sum(len(x) for x in j)) for j in jobs], world)
+    nmax = max(len(j) for j in jobs)
+    mine = torch.full((len(jobs), nmax), -2, dtype=torch.int64)          # -2: not mine
+    for q, g in enumerate(gs):
+        if owner[q] != rank:
+            continue
+        rows, lens = g.padded_rows()
+        end = Oracle(g.flat).table_walk(rows, lens)                          # (on GPUs: this rank's fsm_hip_exec_multi over its jobs)
+        mine[q, :len(end)] = torch.from_numpy(end.astype(np.int64))
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)                                             # the "trivial gather of match results"
+    if rank == 0:
+        full = torch.stack(parts).max(dim=0).values.numpy()                  # every job was walked by exactly one rank
+        assert all(sum(int(parts[r][q, 0] != -2) for r in range(world)) == 1 for q in range(len(jobs)) if len(jobs[q]))
+        np.save(out_path, np.concatenate([full.reshape(-1), np.array(owner)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_retest_goldens_by_dfa(tmp_path, built):
+    """world_size 2, gloo: the 37 retest automata split by DFA with the C front's rule, each rank walks its own jobs, one
+    all_gather of the per-job results: every line's end state equals the reference's frozen answer, both ranks got work."""
+    from common import Golden, all_golden_paths
+    out = str(tmp_path / "multi.npy")
+    mp.spawn(_multi_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    gs = [Golden(p) for p in all_golden_paths() if "/retest/" in p]
+    assert len(gs) == 37
+    nmax = max(len(g.strings()) for g in gs)
+    ends, owner = got[:len(gs) * nmax].reshape(len(gs), nmax), got[len(gs) * nmax:]
+    assert set(owner.tolist()) == {0, 1}
+    for q, g in enumerate(gs):
+        want = np.where(g.ret == 1, g.end, 0xFFFFFFFF).astype(np.int64)
+        assert np.array_equal(ends[q, :len(want)], want), g.name

@@ -557,8 +557,9 @@ def test_retest_l_hip(hip, tmp_path):
     (integration/retest/impl_hip.patch; built by integration/retest/build.sh against the reference archive).
     `retest -l hip` over the reference's tests/retest cases (37 regexps / 115 +/- lines, re-emitted in .tst
     format from the frozen goldens): one fsm_hip_compile per regexp -- in the forked child, so the HIP context
-    is created after the fork.  `-l hip` reads ahead to the end of each record and matches its test lines in
-    ONE launch (fsm_hip_exec_batch_offsets; a [BATCH ] line per record says how many), `-l hip-line` keeps one
+    is created after the fork.  `-l hip` (round 5) reads the whole file ahead and matches every record's lines in ONE
+    fsm_hip_exec_multi; `-l hip-record` reads ahead to the end of each record and matches its test lines in
+    one launch (fsm_hip_exec_batch_offsets; a [BATCH ] line per record says how many), `-l hip-line` keeps one
     fsm_hip_match_buffer launch per test line.  0 errors; the same file through `-l vm` (the reference's own
     interpreter) prints the same [OK] lines; a flipped expectation is reported by all three.  The read-ahead's
     control flow is also covered without a GPU in tests/test_retest_patch.py."""
@@ -573,20 +574,24 @@ def test_retest_l_hip(hip, tmp_path):
     tst.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     oks = {}
-    for impl in ("hip", "hip-line", "vm"):
+    for impl in ("hip", "hip-record", "hip-line", "vm"):
         out = subprocess.run([exe, "-l", impl, str(tst)], capture_output=True, text=True, errors="replace", env=env, timeout=600)
         tail = out.stdout.strip().splitlines()[-2:]
         assert out.returncode == 0, (impl, out.stdout[-1500:], out.stderr[-1500:])
         assert tail[0].endswith("37 regexps, 115 test cases") and tail[1].endswith("0 re errors, 0 errors"), (impl, tail)
         assert out.stdout.count("[OK    ]") == 115 and "[NOT OK]" not in out.stdout
         oks[impl] = [l for l in out.stdout.splitlines() if l.startswith("[OK")]
-        held = [int(l.split(":")[1].split()[0]) for l in out.stdout.splitlines() if l.startswith("[BATCH ]")]
-        assert sum(held) == (115 if impl == "hip" else 0), (impl, held)
-    assert oks["hip"] == oks["vm"] == oks["hip-line"]
+        batch = [l for l in out.stdout.splitlines() if l.startswith("[BATCH ]")]
+        if impl == "hip":      # round 5: the whole file in ONE fsm_hip_exec_multi -- one copy in, ONE kernel, one copy out
+            assert len(batch) == 1 and "37 records, 115 test lines matched in 1 launch," in batch[0], batch
+        else:                  # a record per launch (hip-record), a launch per line, the reference's VM
+            held = [int(l.split(":")[1].split()[0]) for l in batch]
+            assert sum(held) == (115 if impl == "hip-record" else 0), (impl, held)
+    assert oks["hip"] == oks["vm"] == oks["hip-line"] == oks["hip-record"]
     lines[flip] = "-" + lines[flip][1:]
     bad = tmp_path / "bad.tst"
     bad.write_bytes(("\n".join(lines) + "\n").encode("latin1"))
-    for impl in ("hip", "hip-line", "vm"):
+    for impl in ("hip", "hip-record", "hip-line", "vm"):
         out = subprocess.run([exe, "-l", impl, str(bad)], capture_output=True, text=True, errors="replace", env=env, timeout=600)
         assert out.returncode == 1 and out.stdout.count("[NOT OK]") == 1, (impl, out.stdout[-800:])
         assert out.stdout.strip().splitlines()[-1].endswith("0 re errors, 1 errors")

@@ -1,0 +1,305 @@
+"""GPU (-m gpu), round 5: the many-DFA front (fsm_hip_exec_multi*), the lazy walk on the variable-length fronts, the compact
+fronts' resume, edge cases the round-4 review asked for.  Everything through the C ABI, compared with the oracle (the plain-C
+restatement of fsm_exec) or the committed golden answers of the real reference -- never with itself."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, Golden, all_golden_paths
+
+pytestmark = pytest.mark.gpu
+
+NO = 0xFFFFFFFF
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    torch.cuda.set_device(0)
+    import libfsm_amd
+    libfsm_amd.load_library()   # raises if the HIP extension is missing: no silent fallback
+    return libfsm_amd
+
+
+def _pack(strs):
+    off = np.zeros(len(strs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strs])
+    return np.frombuffer(b"".join(strs) + b"", np.uint8).copy(), off
+
+
+@pytest.mark.parametrize("table", ["c1.npz", "c3.npz"])
+def test_generic_inputs_ending_in_the_batch_last_bytes(hip, table):
+    """walk_generic reads through a buffer resource bounded 8 bytes short of the batch: an input that ends within the last 8
+    bytes must still get all of its bytes (the out-of-line byte assembly).  Deterministic: the LAST input ends exactly at
+    total - d for d = 0..8 (padding inputs behind it), starts at every alignment 0..15 and has tails of 1..15 bytes (+ whole chunks);
+    device-pointer fronts on an allocation of EXACTLY the batch's size, so an over-read would also be out of bounds."""
+    import torch
+    from oracle.pyoracle import Oracle
+    flat = hip.FlatDfa.load(os.path.join(GOLDEN, table))
+    orc = Oracle(flat)
+    dfa = hip.HipDfa(flat)
+    dfa.tune(hip.KNOB_INPUT_MODE, 2)        # IN_GENERIC
+    rng = np.random.RandomState(11)
+    rowsrc = bytes(Golden(os.path.join(GOLDEN, table)).strings()[0]) if False else None
+    alpha = np.frombuffer(b"Libfsmabcxyz0123456789", np.uint8)
+    cases = 0
+    for d in range(0, 9):                    # bytes between the last input's end and the batch's end
+        for align in (0, 1, 3, 7, 8, 13, 15):
+            for tail in (1, 2, 7, 8, 9, 15, 16, 17, 31, 33):
+                strs = [bytes(alpha[rng.randint(0, len(alpha), rng.randint(0, 40))]) for _ in range(rng.randint(1, 70))]
+                # pad so that the probed input starts at the wanted alignment
+                cur = sum(len(s) for s in strs)
+                strs.append(b"x" * ((align - cur) % 16))
+                probe = b"Libfsm"[:min(tail, 6)] + bytes(alpha[rng.randint(0, len(alpha), max(0, tail - 6))])
+                strs.append(probe)
+                if d:                        # d bytes of further (tiny) inputs behind it
+                    strs += [b"y"] * d
+                base, off = _pack(strs)
+                n = len(strs)
+                want = orc.table_walk_packed(base, off) if hasattr(orc, "table_walk_packed") else None
+                if want is None:
+                    L = max(16, max(len(s) for s in strs))
+                    rows = np.zeros((n, L), np.uint8)
+                    lens = np.array([len(s) for s in strs], np.uint32)
+                    for i, s in enumerate(strs):
+                        rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+                    want = orc.table_walk(rows, lens)
+                tb = torch.from_numpy(base).cuda() if len(base) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+                assert tb.numel() == max(1, len(base))
+                to = torch.from_numpy(off.astype(np.int64)).cuda()
+                to32 = torch.from_numpy(off.astype(np.int32)).cuda()
+                tl = torch.from_numpy(np.diff(off).astype(np.int32)).cuda()
+                end = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+                for form in ("off64", "off32", "len"):
+                    end.fill_(7)
+                    if form == "off64":
+                        dfa.exec_batch_offsets_device(tb.data_ptr(), to.data_ptr(), n, end.data_ptr(), 0)
+                    elif form == "off32":
+                        dfa.exec_batch_offsets32_device(tb.data_ptr(), to32.data_ptr(), n, end.data_ptr(), 0)
+                    else:
+                        dfa.exec_batch_lengths_device(tb.data_ptr(), tl.data_ptr(), n, end.data_ptr(), 0)
+                    torch.cuda.synchronize()
+                    got = end.cpu().numpy().view(np.uint32)
+                    assert np.array_equal(got, want), (table, d, align, tail, form, np.flatnonzero(got != want)[:5])
+                cases += 1
+    assert cases == 9 * 7 * 10
+    dfa.close()
+
+
+def test_hipnode_every_public_method(hip):
+    """Every public method of the Python HipNode wrapper against the oracle (round 4's review found four of them calling
+    fsm_hip_dfa entry points with a node handle).  One GPU: the node has two replicas on device 0."""
+    import torch
+    from oracle.pyoracle import Oracle
+    flat = hip.FlatDfa.load(os.path.join(GOLDEN, "c1.npz"))
+    orc = Oracle(flat)
+    node = hip.HipNode(flat, [0, 0])
+    assert node.ndev == 2 and isinstance(node.uses_rccl(), bool) and isinstance(node.rccl_path(), str)
+    n, L = 1000, 64
+    rows = hip.gen_inputs_host(n, L, 0, 5, None, b"Libfsm", 4)
+    want = orc.table_walk(rows)
+    f0, c0 = node.shard(n, 0)
+    f1, c1 = node.shard(n, 1)
+    assert (f0, c0 + c1) == (0, n) and f1 == c0 and c0 % 64 == 0 and node.bitmap_words(n) >= (n + 63) // 64
+    end, bm = node.exec_batch(rows)
+    assert np.array_equal(end, want)
+    lens = (np.arange(n) * 7 % (L + 1)).astype(np.uint32)
+    wantl = orc.table_walk(rows, lens)
+    end, bm = node.exec_batch(rows, lens)
+    assert np.array_equal(end, wantl)
+    strs = [bytes(rows[i, :lens[i]]) for i in range(n)]
+    base, off = _pack(strs)
+    bits = lambda b: np.unpackbits(b.view(np.uint8), bitorder="little")[:n].astype(bool)
+    end, bm = node.exec_strings(strs)
+    assert np.array_equal(end, wantl) and np.array_equal(bits(bm), wantl != NO)
+    end, bm = node.exec_batch_offsets32(base, off.astype(np.uint32))
+    assert np.array_equal(end, wantl) and np.array_equal(bits(bm), wantl != NO)
+    end, bm = node.exec_batch_lengths(base, lens)
+    assert np.array_equal(end, wantl) and np.array_equal(bits(bm), wantl != NO)
+    end, bm = node.exec_batch_lengths(base, lens, want_bitmap=False)
+    assert np.array_equal(end, wantl) and bm is None
+    ids = node.exec_batch_ids(rows, 1)                      # c1 carries end-id 0 on its accepting state
+    z = np.load(os.path.join(GOLDEN, "c1.npz"))
+    first_id = np.array([z["endids"][z["endid_off"][q]] if z["endid_off"][q + 1] > z["endid_off"][q] else NO for q in range(int(z["nstates"]))] + [NO], np.uint32)
+    assert np.array_equal(ids, first_id[np.where(want != NO, want, int(z["nstates"]))]) and (ids != NO).sum() == (want != NO).sum()
+    r = node.replica(1)
+    e1, _ = r.exec_batch(rows)
+    assert np.array_equal(e1, want)
+    # device-resident shards
+    W = node.bitmap_words(n)
+    bufs, ends, bms = [], [], []
+    for k in range(2):
+        f, c = node.shard(n, k)
+        bufs.append(torch.from_numpy(rows[f:f + c].copy()).cuda())
+        ends.append(torch.empty(max(c, 1), dtype=torch.int32, device="cuda"))
+        bms.append(torch.zeros(W, dtype=torch.int64, device="cuda"))
+    cnt = node.exec_batch_device([b.data_ptr() for b in bufs], L, n, [e.data_ptr() for e in ends], [m.data_ptr() for m in bms], want_count=True)
+    assert cnt == int((want != NO).sum())
+    got = np.concatenate([ends[k].cpu().numpy().view(np.uint32)[:node.shard(n, k)[1]] for k in range(2)])
+    assert np.array_equal(got, want)
+    for m in bms:
+        assert np.array_equal(np.unpackbits(m.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool), want != NO)
+    node.exec_device(n, [b.data_ptr() for b in bufs], stride=L, d_end=[e.data_ptr() for e in ends], d_bitmap_all=[m.data_ptr() for m in bms], want_count=True, async_=True)
+    assert node.wait(want_count=True) == cnt
+    public = [m for m in dir(node) if not m.startswith("_") and callable(getattr(node, m))]
+    covered = {"close", "uses_rccl", "rccl_path", "replica", "shard", "bitmap_words", "exec_batch", "exec_batch_offsets32", "exec_batch_lengths", "exec_strings",
+               "exec_batch_device", "exec_device", "wait", "exec_batch_ids", "exec_batch_eager", "exec_multi"}
+    assert set(public) <= covered, sorted(set(public) - covered)
+    node.close()
+
+
+def test_bench_relaunches_itself_for_two_ranks(hip):
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE): bench.py becomes the launcher (torch.distributed.run, one
+    rank per GPU, 127.0.0.1) instead of asserting; two ranks share this box's GPU over gloo.  One parsable compact line."""
+    env = dict(os.environ, FSM_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2", "--inputs", "262144"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert len(last) < 6000
+    r = json.loads(last)
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0 and r["config"]["inputs_per_gpu"] == 262144
+    assert r["multi_gpu"]["world_size"] == 2 and r["multi_gpu"]["backend"] == "gloo" and len(r["multi_gpu"]["walk_kernel_ms_per_rank"]) == 2
+    assert abs(r["config"]["accepted_inputs"] - 2 * 262144 // 8) < 64
+
+
+# ---- the many-DFA front (fsm_hip_exec_multi*, multi.hip) ---------------------------------------------------------------------
+
+def _retest_goldens():
+    gs = [Golden(p) for p in all_golden_paths() if "/retest/" in p]
+    assert len(gs) == 37 and sum(len(g.strings()) for g in gs) == 115
+    return gs
+
+
+def _want(g):
+    return np.where(g.ret == 1, g.end, NO).astype(np.uint32)
+
+
+def _bits(bm, n):
+    return np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def test_multi_all_37_retest_goldens_in_one_call(hip):
+    """The reference's whole tests/retest corpus -- 37 automata, 115 lines -- in ONE fsm_hip_exec_multi: one launch, every
+    end state and accept bit equal to the real fsm_exec's frozen answers.  The dfas are created with FSM_HIP_DEFER_UPLOAD:
+    none of them uploads a table of its own (retest frees each fsm right after fsm_runner_initialize, src/retest/main.c:1056-1058)."""
+    gs = _retest_goldens()
+    dfas = [hip.HipDfa(g.flat, hip.DEFER_UPLOAD) for g in gs]
+    outs = hip.exec_multi(dfas, [g.strings() for g in gs])
+    assert hip.multi_last_launches() == 1 and hip.multi_last_fused_jobs() == 37
+    for g, (end, bm) in zip(gs, outs):
+        assert np.array_equal(end, _want(g)), g.name
+        assert np.array_equal(_bits(bm, len(end)), g.ret == 1), g.name
+    # again (the staging block is reused), bitmap not asked for, jobs in another order
+    order = list(range(36, -1, -1))
+    outs = hip.exec_multi([dfas[q] for q in order], [gs[q].strings() for q in order], want_bitmap=False)
+    for q, (end, bm) in zip(order, outs):
+        assert np.array_equal(end, _want(gs[q])) and bm is None
+    # a deferred dfa still serves the single-dfa fronts: its tables are uploaded at that first call
+    end, _ = dfas[5].exec_strings(gs[5].strings())
+    assert np.array_equal(end, _want(gs[5]))
+    for d in dfas:
+        d.close()
+
+
+def test_multi_every_golden_and_edge_cases(hip):
+    """Every golden vector of the suite as one submission (retest, eager, recorded, reperf, c1 / c3 tables: some too big for the
+    LDS form of the fused kernel, all small enough to ride in it), plus: a job without lines, empty lines, a job of exactly
+    64 and 65 lines, and one BIG job (200 000 lines on the c3 table) that must take its dfa's own walk beside the fused launch."""
+    from oracle.pyoracle import Oracle
+    gs = [Golden(p) for p in all_golden_paths()]
+    dfas = [hip.HipDfa(g.flat, hip.DEFER_UPLOAD) for g in gs]
+    jobs = [g.strings() for g in gs]
+    wants = [_want(g) for g in gs]
+    # edge jobs on the c1 automaton
+    c1 = Golden(os.path.join(GOLDEN, "c1.npz"))
+    orc = Oracle(c1.flat)
+    rng = np.random.RandomState(2)
+
+    def rnd(n):
+        return [bytes(rng.choice(np.frombuffer(b"Libfsmx", np.uint8), rng.randint(0, 40))) for _ in range(n)]
+
+    def oracle_of(strs):
+        L = max(16, max([len(x) for x in strs] + [1]))
+        rows = np.zeros((len(strs), L), np.uint8)
+        for i, x in enumerate(strs):
+            rows[i, :len(x)] = np.frombuffer(x, np.uint8)
+        return orc.table_walk(rows, np.array([len(x) for x in strs], np.uint32))
+
+    for strs in ([], [b""], [b"", b"", b"Libfsm"], rnd(64), rnd(65), rnd(1000)):
+        dfas.append(hip.HipDfa(c1.flat, hip.DEFER_UPLOAD))
+        jobs.append(strs)
+        wants.append(oracle_of(strs) if strs else np.zeros(0, np.uint32))
+    # the big job: 200 000 lines (the c3 golden's rows cut to 0..64 bytes, repeated) -- beyond MULTI_FUSE_LINES
+    c3 = Golden(os.path.join(GOLDEN, "c3.npz"))
+    src = c3.strings()
+    unit = [src[i % len(src)][:rng.randint(0, 65)] for i in range(4000)]
+    rows = np.zeros((4000, 64), np.uint8)
+    for i, x in enumerate(unit):
+        rows[i, :len(x)] = np.frombuffer(x, np.uint8)
+    w4k = Oracle(c3.flat).table_walk(rows, np.array([len(x) for x in unit], np.uint32))
+    dfas.append(hip.HipDfa(c3.flat))
+    jobs.append(unit * 50)
+    wants.append(np.tile(w4k, 50))
+    outs = hip.exec_multi(dfas, jobs)
+    assert hip.multi_last_launches() == 2 and hip.multi_last_fused_jobs() == len(jobs) - 2     # (the job without lines is no job)
+    for q, ((end, bm), want) in enumerate(zip(outs, wants)):
+        assert np.array_equal(end, want), (q, np.flatnonzero(end != want)[:5])
+        if len(end):
+            assert np.array_equal(_bits(bm, len(end)), want != NO), q
+    for d in dfas:
+        d.close()
+
+
+def test_multi_device_pointers(hip):
+    """fsm_hip_exec_multi_device: the jobs' lines, offsets and outputs are device memory (allocations of exactly their size:
+    the fused kernel may not read past a job's last byte), enqueued on a stream, twice back to back."""
+    import torch
+    gs = _retest_goldens() + [Golden(os.path.join(GOLDEN, "c1.npz"))]
+    dfas = [hip.HipDfa(g.flat, hip.DEFER_UPLOAD) for g in gs]
+    st = torch.cuda.Stream()
+    keep, jobs = [], []
+    for g in gs:
+        base, off = g.packed()
+        n = len(off) - 1
+        tb = torch.from_numpy(np.ascontiguousarray(base)).cuda() if len(base) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        to = torch.from_numpy(off.astype(np.int64)).cuda()
+        te = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+        tm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        keep.append((tb, to, te, tm))
+        jobs.append((tb.data_ptr(), to.data_ptr(), n, te.data_ptr(), tm.data_ptr()))
+    torch.cuda.synchronize()
+    for rep in range(2):
+        hip.exec_multi_device(dfas, jobs, stream=st.cuda_stream)
+    st.synchronize()
+    assert hip.multi_last_launches() == 1
+    for g, (tb, to, te, tm) in zip(gs, keep):
+        end = te.cpu().numpy().view(np.uint32)
+        assert np.array_equal(end, _want(g)), g.name
+        assert np.array_equal(_bits(tm.cpu().numpy(), len(end)), g.ret == 1), g.name
+    for d in dfas:
+        d.close()
+
+
+def test_node_multi_shards_by_dfa(hip):
+    """fsm_hip_node_exec_multi: 37 node handles (two replicas each on this box's one GPU), the jobs split by DFA with
+    fsm_hip_multi_assign, one fsm_hip_exec_multi per device on its own host thread; results land in the caller's arrays."""
+    gs = _retest_goldens()
+    nodes = [hip.HipNode(g.flat, [0, 0], hip.DEFER_UPLOAD) for g in gs]
+    outs = hip.exec_multi(None, [g.strings() for g in gs], nodes=nodes)
+    for g, (end, bm) in zip(gs, outs):
+        assert np.array_equal(end, _want(g)), g.name
+        assert np.array_equal(_bits(bm, len(end)), g.ret == 1), g.name
+    from libfsm_amd.shard import job_cost
+    a = hip.multi_assign([job_cost(len(g.strings()), sum(len(x) for x in g.strings())) for g in gs], 2)
+    assert set(a.tolist()) == {0, 1}
+    for nd in nodes:
+        nd.close()

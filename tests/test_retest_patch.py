@@ -1,9 +1,10 @@
 """integration/retest/impl_hip.patch, control flow only (no GPU): the patched copy of the reference's retest
 is run against a stand-in libfsm_hip.so (tests/c/stub_fsm_hip.c: the four entry points the patch calls,
 answered by the reference's DFAVM and counted).  What is checked here is what the patch adds to main.c /
-runner.c: `-l hip` reads ahead to the end of each record and matches its '+' / '-' lines with ONE
-fsm_hip_exec_batch_offsets() call, fsm_runner_run() then hands out the held results in order; `-l hip-line`
-keeps one call per line.  The GPU suite (tests/test_gpu_round2.py::test_retest_l_hip) runs the same binary
+runner.c: `-l hip` (round 5) reads the WHOLE file ahead -- the main loop itself, run once with the runner collecting --
+and matches every line of every record with ONE fsm_hip_exec_multi() call, the ordinary pass then gets its automata and
+answers from the held results; `-l hip-record` (round 2's form) reads ahead to the end of each record and matches its
+'+' / '-' lines with one fsm_hip_exec_batch_offsets() call; `-l hip-line` keeps one call per line.  The GPU suite (tests/test_gpu_round2.py::test_retest_l_hip) runs the same binary
 against the real library."""
 import os
 import re
@@ -37,10 +38,11 @@ def stub_dir(tmp_path_factory):
 def run(stub_dir, impl, path):
     env = dict(os.environ, LD_LIBRARY_PATH=stub_dir)      # searched before the binary's RUNPATH
     out = subprocess.run([EXE, "-l", impl, str(path)], capture_output=True, text=True, errors="replace", env=env, timeout=300)
-    m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=(\d+) batch_inputs=(\d+) single_calls=(\d+) stride_calls=\d+ stride_inputs=\d+", out.stderr)
+    m = re.findall(r"stub_fsm_hip: compile=(\d+) batch_calls=(\d+) batch_inputs=(\d+) single_calls=(\d+) stride_calls=\d+ stride_inputs=\d+ multi_calls=(\d+) multi_jobs=(\d+) multi_inputs=(\d+)", out.stderr)
     assert m, out.stderr[-500:]
     # retest forks one child per file: one report
-    return out, tuple(int(x) for x in m[-1])
+    run.multi = tuple(int(x) for x in m[-1][4:])
+    return out, tuple(int(x) for x in m[-1][:4])
 
 
 def test_record_lines_go_out_in_one_call(stub_dir, tmp_path):
@@ -56,12 +58,23 @@ def test_record_lines_go_out_in_one_call(stub_dir, tmp_path):
             in_rec = True
             records_with_cases += 1
 
+    # the whole file in ONE submission: 37 automata compiled once, one fsm_hip_exec_multi of 37 jobs / 115 lines, nothing else
     out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip", tst)
     tail = out.stdout.strip().splitlines()[-2:]
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
     assert tail[0].endswith("37 regexps, 115 test cases") and tail[1].endswith("0 re errors, 0 errors")
     assert out.stdout.count("[OK    ]") == 115 and "[NOT OK]" not in out.stdout
-    assert (ncomp, nbatch, nin, nsingle) == (37, records_with_cases, 115, 0)
+    assert (ncomp, nbatch, nin, nsingle) == (37, 0, 0, 0) and run.multi == (1, 37, 115)
+    assert out.stdout.count("[BATCH ]") == 1 and "37 records, 115 test lines matched in 1 launch" in out.stdout
+    # ... and what it prints is, but for that line, what the reference's own VM prints
+    ref = subprocess.run([EXE, "-l", "vm", str(tst)], capture_output=True, text=True, errors="replace", timeout=300)
+    strip_b = lambda s: [l for l in s.splitlines() if not l.startswith("[BATCH ]")]
+    assert strip_b(out.stdout) == strip_b(ref.stdout)
+
+    # a record per launch (round 2's form)
+    out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip-record", tst)
+    assert out.returncode == 0 and out.stdout.count("[OK    ]") == 115 and "[NOT OK]" not in out.stdout
+    assert (ncomp, nbatch, nin, nsingle) == (37, records_with_cases, 115, 0) and run.multi == (0, 0, 0)
     assert out.stdout.count("[BATCH ]") == records_with_cases
 
     out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip-line", tst)
@@ -108,6 +121,9 @@ def test_lines_the_read_ahead_did_not_see_fall_back(stub_dir, tmp_path):
     strip = lambda s: [l for l in s.splitlines() if not l.startswith("[BATCH ]")]
     assert strip(out.stdout) == strip(ref.stdout)          # line for line what the reference's own VM reports
     assert out.returncode == ref.returncode
+    assert ncomp == 2 and nbatch == 0 and nsingle == 0 and run.multi[:2] == (1, 2), (ncomp, nbatch, nin, nsingle, run.multi)
+    out, (ncomp, nbatch, nin, nsingle) = run(stub_dir, "hip-record", tst)
+    assert strip(out.stdout) == strip(ref.stdout) and out.returncode == ref.returncode
     assert ncomp == 2 and nbatch == 2 and nsingle == 0, (ncomp, nbatch, nin, nsingle)
 
 
