@@ -115,13 +115,17 @@ __device__ __forceinline__ LazyState lazy_enter(const LazyCtx &cx, uint32_t id, 
  * written over 0 / 1 integers the compiler does it with vector selects.  The dependent chain from one own-record gather to
  * the next is: shift, sign test, (scalar or), select of the offset -- the filter word of the next state was read for the
  * LDS answer `ev` while the gather was in flight. */
-template <bool ABS>
-__device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint32_t sh, uint32_t &bacc)
+/* TAIL (the variable-length fronts, walk_lazy_lines): `live` = the byte belongs to the lane's input.  A byte beyond the input's
+ * end keeps the state (as the ABS form keeps an absorbing one) and asks for no own record; every later byte of that lane is
+ * beyond the end too, so what happens to E / fw / A / D no longer matters. */
+template <bool ABS, bool TAIL = false>
+__device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint32_t sh, uint32_t &bacc, bool live = true)
 {
 	const u32x4 rb = *(lazy_rec_p)(uintptr_t)(cx.recbase + s.E * 16u);
 	/* the own record, for the lanes that may have an exception here: the others' offset is out of range (zeros, no request).
 	 * The filter: one 32-bit word per state id (modulo the filter's size), bit sh % 32 of it */
-	const bool pos = s.A | (s.D & (__builtin_amdgcn_ubfe(s.fw, sh, 1u) != 0u));   /* (no short circuit) */
+	bool pos = s.A | (s.D & (__builtin_amdgcn_ubfe(s.fw, sh, 1u) != 0u));   /* (no short circuit) */
+	if (TAIL) pos = pos & live;
 	const uint32_t off = pos ? s.id << 4 : 0xFFFFFFF0u;
 	const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(cx.own, (int)off, 0, 0);
 	/* E's answer */
@@ -139,8 +143,8 @@ __device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint3
 	const bool hA = lazy_probe(g.x, g.y, 0u, sh, nA);
 	nA = (uint32_t)(__mul24((int)nA, (int)g.w) + (int)g.z);
 	uint32_t m = hA ? nA : ev;
-	if (ABS) {
-		const bool ab = s.id >= cx.abs_min;
+	if (ABS || TAIL) {
+		const bool ab = (ABS && s.id >= cx.abs_min) | (TAIL && !live);
 		m = ab ? s.id : m;
 		rep = ab ? s.E : rep;
 	}
@@ -161,10 +165,10 @@ __device__ __forceinline__ uint32_t byte_dyn(const u32x4 &w, uint32_t k)
 
 /* the exact re-walk of a chunk, from the state (id, E) it began in, for the lanes that met a sentinel in it */
 template <bool ABS>
-__device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *simg, const uint32_t *car, uint32_t &id, uint32_t &E, const u32x4 &w)
+__device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *simg, const uint32_t *car, uint32_t &id, uint32_t &E, const u32x4 &w, uint32_t cnt = 16u)
 {
 #pragma unroll 1
-	for (uint32_t k = 0; k < 16u; k++) {
+	for (uint32_t k = 0; k < cnt; k++) {
 		const uint32_t byte = byte_dyn(w, k);
 		const uint32_t sh = *(lazy_u32_p)(uintptr_t)(byte * 4u);
 		LazyState c = lazy_enter(cx, id, E);
@@ -287,6 +291,211 @@ walk_lazy(const WalkArgs a)
 		}
 #pragma unroll
 		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + (uint32_t)r, i[r], i[r] < a.n, st[r].id);
+	}
+}
+
+/*
+ * walk_lazy_lines: the lazy walk on the fronts retest / rx drive (src/retest/main.c:1114 a line at a time, rx's literal path
+ * src/rx/main.c:405-434): inputs of ANY length -- packed lines located by u64 offsets, u32 offsets or their lengths alone, fixed
+ * stride + lengths, strides that are not a multiple of 64 --, and resumed walks (state_io: a state beyond the LDS set re-enters
+ * with what plan.cpp's car[] says it carries).
+ *
+ * One input per lane SLOT, ROWS slots per lane, and a slot whose input has ended takes the next one (lane refill): the
+ * wavefronts claim pieces of LAZY_PIECE consecutive inputs from the launch's counter, a slot in need takes the piece's next
+ * input by its rank among the needy lanes (one ballot + mbcnt; the lengths-only front adds a wavefront prefix sum over the
+ * takers' lengths to a running byte offset), so the 64 x ROWS inputs in flight stay within a few KB of one another whatever
+ * their lengths.  Per turn every slot loads its next NB 16-byte chunks from its own byte address (global loads: an input
+ * starts anywhere; the chunk that would reach beyond the batch's last byte is assembled byte by byte) and the chunks are
+ * walked in lockstep; a chunk in which some lane's input ends takes the TAIL form of the step.  Results are written by the
+ * lane when its input ends (the accept bitmap by atomic OR: cleared on the launch stream).
+ */
+#define FSMHIP_LAZY_PIECE 256u
+
+template <bool ABS, int ROWS, int NB>
+__global__ void __launch_bounds__(1024)
+walk_lazy_lines(const WalkArgs a)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	const uint32_t *lz = static_cast<const uint32_t *>(a.lazy);
+	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
+	const uint32_t *car = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(lz) + lz[14]);
+	LazyCtx cx;
+	cx.H = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[1]);
+	cx.F = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[2]);
+	cx.fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[3] - 1u) << 2));
+	cx.recbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[4]);
+	cx.abs_min = a.abs_min;
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(lz + 16);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+		const uint32_t nv = lz[6] / 16u;
+		for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) dst[i] = src[i];
+	}
+	if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
+	{
+		const uint64_t ob = reinterpret_cast<uint64_t>(lz) + lz[7];
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32));
+		const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lz[13] * 16u));
+		cx.own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)nrec, 0x00020000);
+	}
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool f_off = a.off != nullptr, f_off32 = !f_off && a.off32 != nullptr, f_lens = !f_off && !f_off32 && a.tbase != nullptr;
+	const uint64_t base = reinterpret_cast<uint64_t>(a.base), limit = base + batch_bytes(a);
+	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);
+	typedef u32x4 __attribute__((aligned(1))) u32x4_any;
+	typedef const u32x4_any __attribute__((address_space(1))) *glb_chunk_p;
+
+	/* the wavefront's piece: inputs [pnext, pend); run = byte offset of input pnext (lengths-only front) */
+	uint64_t pnext = 0, pend = 0, run = 0;
+	bool more = true;
+
+	uint64_t li[ROWS], cur[ROWS], rem[ROWS];
+	bool act[ROWS];
+	LazyState st[ROWS];
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) {
+		li[r] = 0; cur[r] = safe; rem[r] = 0; act[r] = false;
+		st[r] = lazy_enter(cx, a.start, a.start);
+	}
+
+	for (;;) {
+		/* ---- refill: ended inputs are written, free slots take the next inputs of the piece ---- */
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) {
+			for (;;) {
+				if (act[r] && rem[r] == 0u) {
+					write_result_lane(a, li[r], st[r].id);
+					act[r] = false;
+				}
+				const uint64_t needm = __ballot(!act[r]);
+				if (needm == 0u) break;
+				if (pnext == pend) {
+					if (!more) break;
+					uint32_t t = 0;
+					if (lane == 0) t = atomicAdd(a.tile_ctr, 1u);
+					t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+					const uint64_t p0 = (uint64_t)t * FSMHIP_LAZY_PIECE;
+					if (p0 >= a.n) { more = false; break; }
+					pnext = p0;
+					pend = p0 + FSMHIP_LAZY_PIECE < a.n ? p0 + FSMHIP_LAZY_PIECE : a.n;
+					if (f_lens) run = a.tbase[p0 / 64u];
+				}
+				const uint32_t avail = (uint32_t)(pend - pnext);
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(needm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needm, 0u));
+				const bool take = !act[r] && rank < avail;
+				const uint64_t i = pnext + rank;
+				uint64_t beg = 0, len = 0;
+				if (f_lens) {
+					const uint32_t l = take ? a.len[i] : 0u;
+					const uint64_t ex = wave_excl_prefix(l, lane);
+					beg = run + ex;
+					len = l;
+					const uint64_t tot = ex + l;       /* lane 63 holds the takers' total */
+					run += ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tot >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tot, 63);
+				} else if (take) {
+					if (f_off) { beg = a.off[i]; len = a.off[i + 1u] - beg; }
+					else if (f_off32) { const uint32_t b32 = a.off32[i]; beg = b32; len = a.off32[i + 1u] - b32; }
+					else { beg = i * a.stride; len = a.len != nullptr ? a.len[i] : a.stride; }
+				}
+				if (take) {
+					li[r] = i;
+					cur[r] = base + beg;
+					rem[r] = len;
+					act[r] = true;
+					const uint32_t code = start_code(a, i, true);
+					st[r] = lazy_enter(cx, code, code < cx.H ? code : car[code < lz[13] ? code : 0u]);
+				}
+				const uint32_t k = (uint32_t)__popcll(needm);
+				pnext += k < avail ? k : avail;
+			}
+		}
+		bool anyact = false;
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) anyact = anyact || act[r];
+		if (!__any(anyact)) break;
+
+		/* ---- the next NB chunks of every slot ---- */
+		u32x4 w[NB][ROWS];
+#pragma unroll
+		for (int j = 0; j < NB; j++)
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) {
+				w[j][r] = u32x4{0u, 0u, 0u, 0u};
+				if (act[r] && rem[r] > 16u * (uint32_t)j) {
+					const uint64_t ad = cur[r] + 16u * (uint32_t)j;
+					if (ad + 16u <= limit) w[j][r] = *(glb_chunk_p)ad;
+					else w[j][r] = load_chunk_edge(ad, true, limit, safe);
+				}
+			}
+
+#pragma unroll 1
+		for (uint32_t j = 0; j < (uint32_t)NB; j++) {
+			uint32_t cnt[ROWS];
+			bool some = false, full = true;
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) {
+				const uint64_t left = act[r] && rem[r] > 16u * j ? rem[r] - 16u * j : 0u;
+				cnt[r] = left < 16u ? (uint32_t)left : 16u;
+				some = some || cnt[r] != 0u;
+				full = full && cnt[r] == 16u;
+			}
+			if (!__any(some)) break;
+			uint32_t sh[ROWS][16];
+#pragma unroll
+			for (int r = 0; r < ROWS; r++)
+#pragma unroll
+				for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(w[0][r], k) * 4u);
+			uint32_t sid[ROWS], sE[ROWS], bacc[ROWS];
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) { sid[r] = st[r].id; sE[r] = st[r].E; bacc[r] = 0u; }
+			if (__all(full)) {
+#pragma unroll
+				for (int r = 0; r < ROWS; r++)
+#pragma unroll
+					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+#pragma unroll
+					for (int r = 0; r < ROWS; r++) lazy_step<ABS, false>(cx, st[r], sh[r][k], bacc[r]);
+			} else {
+#pragma unroll
+				for (int r = 0; r < ROWS; r++)
+#pragma unroll
+					for (int k = 0; k < 16; k++) bacc[r] |= (uint32_t)k < cnt[r] ? sh[r][k] : 0u;
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+#pragma unroll
+					for (int r = 0; r < ROWS; r++) lazy_step<ABS, true>(cx, st[r], sh[r][k], bacc[r], (uint32_t)k < cnt[r]);
+			}
+			uint32_t ball = 0;
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) ball |= bacc[r];
+			if (__builtin_amdgcn_ballot_w64((int32_t)ball < 0) != 0u) {
+#pragma unroll
+				for (int r = 0; r < ROWS; r++) {
+					if ((int32_t)bacc[r] < 0) {
+						uint32_t cid = sid[r], cE = sE[r];
+						lazy_careful<ABS>(cx, simg, car, cid, cE, w[0][r], cnt[r]);
+						st[r] = lazy_enter(cx, cid, cE);
+					}
+				}
+			}
+			/* the chunks rotate through w[0]: ONE copy of the step code (unrolled over j it would be four) */
+#pragma unroll
+			for (int q = 0; q + 1 < NB; q++)
+#pragma unroll
+				for (int r = 0; r < ROWS; r++) w[q][r] = w[q + 1][r];
+		}
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) {
+			const uint64_t adv = rem[r] < 16u * (uint32_t)NB ? rem[r] : 16u * (uint32_t)NB;
+			cur[r] += adv;
+			rem[r] -= adv;
+			/* an absorbing state ends the input early (fsm_exec stops pulling bytes at a missing edge, exec.c:133-138) */
+			if (ABS && (a.early & 1u) && act[r] && st[r].id >= a.abs_min) rem[r] = 0u;
+		}
 	}
 }
 
