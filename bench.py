@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged"],
                     help="c*_short / c*_ragged: the packed-lines front alone (what the default run reports as sub_results), for profiling")
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
@@ -92,6 +92,18 @@ def c5_words(nwords):
         alpha = np.frombuffer(ALPHA64, np.uint8)
         _C5[nwords] = [bytes(alpha[rng.randint(0, 64, rng.randint(8, 17))]) for _ in range(nwords)]
     return _C5[nwords]
+
+
+_C5_FLAT = {}
+
+
+def c5_flat(hip, nwords):
+    """the literal-set automaton of configs[4], built once per run (the oracle keeps one 1 GB dense table per automaton object)"""
+    if nwords not in _C5_FLAT:
+        words = c5_words(nwords)
+        # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
+        _C5_FLAT[nwords] = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
+    return _C5_FLAT[nwords]
 
 
 def c5_tail_table(words):
@@ -619,8 +631,7 @@ def main():
         words = None
         if wl == "c5":
             words = c5_words(a.c5_words)
-            # right-anchored, end-id = literal index: no absorbing accept state, every byte is walked
-            flat = hip.FlatDfa.from_strings(words, 2, list(range(len(words))))
+            flat = c5_flat(hip, a.c5_words)
         else:
             flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
         flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
@@ -825,10 +836,21 @@ def main():
         counts every byte that form moves: sum(len) + 8 B of offsets + 4 B of result per line."""
         lo, hi, n_l = (8, 64, 100_000_000) if kind == "short" else (0, 1024, 20_000_000)
         n_l = min(n_l, n)
-        flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
+        words = None
+        if wl == "c5":
+            words = c5_words(a.c5_words)
+            flat = c5_flat(hip, a.c5_words)
+        else:
+            flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
         dfa = hip.HipDfa(flat, a.layout)
+        for kv in a.knob:
+            k_, v_ = kv.split("=")
+            dfa.tune(int(k_), int(v_))
         rows = buf_all[:n_l]
-        generate(hip, wl, rows.data_ptr(), n_l, L, 0)
+        if wl == "c5":     # rows over the literals' alphabet (the literals are planted at the LINES' ends, below)
+            hip.gen_inputs_device(rows.data_ptr(), n_l, L, 0, SEED, ALPHA64)
+        else:
+            generate(hip, wl, rows.data_ptr(), n_l, L, 0)
         g = torch.Generator(device="cuda").manual_seed(SEED & 0x7FFFFFFF)
         lens = torch.randint(lo, hi + 1, (n_l,), device="cuda", dtype=torch.int32, generator=g)
         off = torch.zeros(n_l + 1, dtype=torch.int64, device="cuda")
@@ -836,6 +858,19 @@ def main():
         total = int(off[-1].item())
         packed = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
         hip.gen_pack_rows_device(rows.data_ptr(), L, lens.data_ptr(), off.data_ptr(), n_l, hi, packed.data_ptr())
+        if wl == "c5":
+            # every 8th line ends with the literal (index * 2654435761) % nwords, where it is long enough: accepted by the
+            # right-anchored automaton
+            Wt, wl_len = c5_tail_table(words)
+            Wd, ld = torch.from_numpy(Wt).cuda(), torch.from_numpy(wl_len).cuda()
+            idx = torch.arange(0, n_l, 8, device="cuda")
+            widx = (idx * 2654435761) % len(words)
+            for l in sorted(set(wl_len.tolist())):
+                m = (ld[widx] == l) & (lens[idx].to(torch.int64) >= l)
+                if bool(m.any()):
+                    pos = (off[idx[m] + 1] - l).unsqueeze(1) + torch.arange(l, device="cuda").unsqueeze(0)
+                    packed[pos.reshape(-1)] = Wd[widx[m], :l].reshape(-1)
+            del Wd, ld, idx, widx
         off32 = off.to(torch.int32) if total < (1 << 32) else None
         end = end_all[:n_l]
         end2 = torch.empty_like(end)
@@ -896,41 +931,44 @@ def main():
                     res["roofline"]["traffic_source"] = f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this sub-result (recorded, not measured in this run)"
             except Exception:
                 pass
-        # parity: a stratified sample of the lines against the oracle's walk of the same bytes
+        # parity: a stratified sample of the lines -- their bytes gathered from the PACKED buffer the kernel walked -- against
+        # the oracle's walk
         if not a.no_cpu_baseline and a.cpu_sample != 0:
-            from oracle import pyoracle
             idx = sample_indices(n_l, 100_000)
             tidx = torch.from_numpy(idx).cuda()
-            srows = rows[tidx][:, :hi].cpu().numpy() if hi <= 64 else rows[tidx].cpu().numpy()
-            slens = lens[tidx].cpu().numpy().astype(np.uint32)
+            sl = lens[tidx].to(torch.int64)
+            so = torch.zeros(len(idx) + 1, dtype=torch.int64, device="cuda")
+            torch.cumsum(sl, 0, out=so[1:])
+            stot = int(so[-1].item())
+            src = torch.repeat_interleave(off[tidx] - so[:-1], sl) + torch.arange(stot, device="cuda") if stot else torch.zeros(0, dtype=torch.int64, device="cuda")
+            sbase = packed[src].cpu().numpy() if stot else np.zeros(1, np.uint8)
             o = get_oracle(flat)
-            want = o.table_walk(srows, slens)
+            want = o.table_walk_packed_mt(sbase, so.cpu().numpy().astype(np.uint64), 1)
             got = end[tidx].cpu().numpy().view(np.uint32)
-            # ... and the packed copy holds those bytes (spot check)
-            k0 = int(idx[len(idx) // 2])
-            b0, b1 = int(off[k0].item()), int(off[k0 + 1].item())
-            same = bool(np.array_equal(packed[b0:b1].cpu().numpy(), rows[k0, :b1 - b0].cpu().numpy()))
-            res["cpu_baseline"] = {"kind": "port", "value": round(float(slens.sum()) / 1e9 / o.last_seconds, 5), "unit": "GB/s", "cores": 1,
+            del src
+            res["cpu_baseline"] = {"kind": "port", "value": round(stot / 1e9 / max(o.last_seconds, 1e-9), 5), "unit": "GB/s", "cores": 1,
                                    "sample": f"oracle dense-table walker (oracle/dfa_oracle.c), 1 thread, {len(idx)} of the lines"}
-            res["parity_vs_cpu_sample"] = "bit-exact" if np.array_equal(got, want) and same and ok_forms else "MISMATCH"
-            res["parity_sample"] = f"{len(idx)} lines: seeded stratified sample + first/last 64; the other metadata forms reproduce all {n_l} end states"
+            res["parity_vs_cpu_sample"] = "bit-exact" if np.array_equal(got, want) and ok_forms else "MISMATCH"
+            res["parity_sample"] = f"{len(idx)} lines: seeded stratified sample + first/last 64, bytes taken from the packed buffer; the other metadata forms reproduce all {n_l} end states"
             if res["parity_vs_cpu_sample"] != "bit-exact":
                 res["value"] = None
-            # ... and EVERY line: the rows stream back in 2 GiB slices and the oracle walks the first len[i] bytes of each on all
-            # granted host cores (the bytes walked are the rows' own: the packed copy was made from them on the device and is
-            # spot-checked above and byte-for-byte in tests/test_gpu_round4.py)
+            # ... and EVERY line: the packed buffer streams back in slices of whole lines (<= 2 GiB each) and the oracle walks
+            # them on all granted host cores
             if not a.no_full_parity:
                 ncores, _ = host_cores()
-                w = hi if hi <= 64 else L
-                step = max(1, (2 << 30) // w)
-                bad, t0, t_cpu = 0, time.perf_counter(), 0.0
-                for r0 in range(0, n_l, step):
-                    r1 = min(n_l, r0 + step)
-                    want_all = o.table_walk_mt(rows[r0:r1, :w].contiguous().cpu().numpy(), ncores, lens[r0:r1].cpu().numpy().astype(np.uint32))
+                offh = off.cpu().numpy().astype(np.uint64)
+                bad, t0, t_cpu, r0 = 0, time.perf_counter(), 0.0, 0
+                while r0 < n_l:
+                    r1 = int(np.searchsorted(offh, offh[r0] + np.uint64(2 << 30), side="right")) - 1
+                    r1 = min(n_l, max(r1, r0 + 1))
+                    b0, b1 = int(offh[r0]), int(offh[r1])
+                    chunk = packed[b0:b1].cpu().numpy() if b1 > b0 else np.zeros(1, np.uint8)
+                    want_all = o.table_walk_packed_mt(chunk, offh[r0:r1 + 1] - offh[r0], ncores)
                     t_cpu += o.last_seconds
                     bad += int((end[r0:r1].cpu().numpy().view(np.uint32) != want_all).sum())
+                    r0 = r1
                 res["full_parity"] = {"rows": n_l, "mismatches": bad, "cpu_threads": ncores, "seconds": round(time.perf_counter() - t0, 1),
-                                      "cpu_walk_GBps": round(total / 1e9 / max(t_cpu, 1e-9), 2), "checker": "oracle dense-table walker (oracle/dfa_oracle.c), all lines"}
+                                      "cpu_walk_GBps": round(total / 1e9 / max(t_cpu, 1e-9), 2), "checker": "oracle dense-table walker (oracle/dfa_oracle.c), all lines, from the packed buffer"}
                 if bad:
                     res["value"] = None
         dfa.close()
@@ -957,7 +995,7 @@ def main():
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
         # the short / packed front of retest and rx, at steady-state size, on the C2 and C3 tables
-        for wl in ("c2", "c3"):
+        for wl in ("c2", "c3", "c5"):
             plan.append((wl, "short", None))
             plan.append((wl, "ragged", None))
         for wl, variant, n_wl in plan:

@@ -44,6 +44,7 @@ enum {
 	                                  * (walk_lazy.h); 1 (default otherwise) the record is the walk state and a byte is three
 	                                  * straight-line record probes; 0 the chain loop over state ids (A/B measurement)   */
 	FSM_HIP_KNOB_LAZY_DYN      = 21, /* the lazy walk: 1 (default) wavefronts claim their tiles from a device counter, 0 static striding */
+	FSM_HIP_KNOB_LAZY_LINES    = 22, /* the lazy walk also serves variable-length / unaligned / resumed batches (walk_lazy_lines): 1 (default), 0 off (A/B) */
 	FSM_HIP_KNOB_DMA_BUFS      = 15, /* retired (accepted, ignored): two DMA tiles per wave measured slower than one */
 	FSM_HIP_KNOB_RAGGED_ALIGN  = 14  /* retired (accepted, ignored): the ragged kernel fetches from the inputs' own byte addresses */
 };

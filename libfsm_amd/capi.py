@@ -30,7 +30,7 @@ KNOB_INPUT_MODE, KNOB_NB, KNOB_ROWS, KNOB_WAVES, KNOB_BLOCKS_PER_CU, KNOB_EARLY_
 KNOB_NOSKIP = 13
 KNOB_RAGGED_ALIGN = 14
 KNOB_DMA_BUFS = 15
-KNOB_PICK_MEAN, KNOB_SPARSE_FAST, KNOB_LAZY_DYN = 18, 20, 21
+KNOB_PICK_MEAN, KNOB_SPARSE_FAST, KNOB_LAZY_DYN, KNOB_LAZY_LINES = 18, 20, 21, 22
 IN_DIRECT, IN_LDSDMA, IN_GENERIC, IN_RAGGED = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -24,6 +24,7 @@
 #include "launch.h"
 #include "gen_kernels.h"
 #include "walk_aux.h"
+#include "walk_lazy.h"   /* FSMHIP_LAZY_PIECE (the kernels themselves are instantiated in kern_glob.hip) */
 #include "trace_kernel.h"
 
 using namespace fsmhip;
@@ -42,6 +43,7 @@ struct fsm_hip_dfa {
 	uint32_t *d_lazy_ctr = nullptr;                  /* ... and a ring of tile counters: a launch zeroes and uses the next one (launches on
 	                                                  * several streams may be in flight; LAZY_CTRS of them never are) */
 	unsigned lazy_ctr_next = 0;
+	int knob_lazy_lines = 1;                         /* the lazy walk also serves the variable-length fronts and resumed walks (0: walk_ragged / walk_generic over the records, for A/B runs) */
 	int knob_lazy_dyn = 1;                           /* the lazy walk's wavefronts claim their tiles from a counter (0: static striding) */
 	/* device end-id delivery (built on first use) */
 	std::vector<uint32_t> fin_host;                 /* copy of the fin table uploaded to d_fin */
@@ -591,6 +593,17 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
 		return c;
 	}
+	if (layout == FSM_HIP_LAYOUT_SPARSE && !eager && d->d_lazy != nullptr && d->knob_sparse_fast == 3 && d->knob_input_mode < 0 && d->knob_lazy_lines) {
+		/* ... and on everything else such an automaton is asked (round 5): inputs of any length and metadata form, strides that
+		 * are not a multiple of 64, unaligned rows, resumed walks -- one input per lane slot with lane refill (walk_lazy_lines) */
+		c.mode = IN_LAZY_LINES;
+		c.lazy_abs = d->plan.lazy_img[11] != 0 || resumed;   /* a resumed input may start in DEAD */
+		c.nb = 4;
+		c.waves = 16;
+		c.lds = d->plan.lazy_lds_bytes;
+		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
+		return c;
+	}
 	if (c.sparse_fast == 3) c.sparse_fast = d->sparse_fast_ok ? 1 : 0;
 	c.mode = mode;
 	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? ragged_wave_lds : 0u;
@@ -698,7 +711,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : !varlen ? (uint64_t)a.n * a.stride : 0;
 	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr);
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
+	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves
+		: c.mode == IN_LAZY_LINES ? ((a.n + FSMHIP_LAZY_PIECE - 1u) / FSMHIP_LAZY_PIECE + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;
 	if (d->knob_early >= 0) a.early = (uint32_t)d->knob_early; /* bit 0 wave retire, bit 1 per-lane load skip */
@@ -715,8 +729,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	hipError_t e = hipSuccess;
 	std::string picked;
 	/* the ragged kernel sets bitmap bits one input at a time */
-	if (c.mode == IN_RAGGED && a.bitmap != nullptr) e = zero_async(a.bitmap, ntiles * sizeof(uint64_t), s);
-	if (e == hipSuccess && c.mode == IN_LAZY && d->knob_lazy_dyn && d->d_lazy_ctr != nullptr) {
+	if ((c.mode == IN_RAGGED || c.mode == IN_LAZY_LINES) && a.bitmap != nullptr) e = zero_async(a.bitmap, ntiles * sizeof(uint64_t), s);
+	if (e == hipSuccess && ((c.mode == IN_LAZY && d->knob_lazy_dyn) || c.mode == IN_LAZY_LINES) && d->d_lazy_ctr != nullptr) {
 		a.tile_ctr = d->d_lazy_ctr + (md->lazy_ctr_next++ % LAZY_CTRS);
 		e = zero_async(a.tile_ctr, sizeof(uint32_t), s);
 	}
@@ -1132,6 +1146,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
 	case FSM_HIP_KNOB_ROWS: break;   /* retired: two inputs per lane never helped the table walks (profiles/r01_sweep2*); the lazy walk always has two */
 	case FSM_HIP_KNOB_LAZY_DYN: d->knob_lazy_dyn = value != 0; break;
+	case FSM_HIP_KNOB_LAZY_LINES: d->knob_lazy_lines = value != 0; break;
 	case FSM_HIP_KNOB_MASK: break;   /* retired: exec-masking absorbing lanes cost more than it saved */
 	case FSM_HIP_KNOB_SEG: d->knob_seg = value; break;
 	case FSM_HIP_KNOB_PREFETCH: d->knob_prefetch = value; break;

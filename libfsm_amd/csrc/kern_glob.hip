@@ -13,6 +13,11 @@ hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a
 		walk_fn k = c.lazy_abs ? walk_lazy<true, 2, 4> : walk_lazy<false, 2, 4>;
 		return launch_fn(k, c, a, grid, block, s);
 	}
+	if (pol == POL_SPARSE && eager == 0 && c.mode == IN_LAZY_LINES) {
+		/* the same walk on inputs of any length / metadata form, and resumed walks: one input per lane slot, lane refill */
+		walk_fn k = c.lazy_abs ? walk_lazy_lines<true, 2, 4> : walk_lazy_lines<false, 2, 4>;
+		return launch_fn(k, c, a, grid, block, s);
+	}
 	if (pol == POL_SPARSE && eager == 0 && c.sparse_fast && c.mode == IN_DIRECT) {
 		/* fixed-stride rows, plain walk: the record is the state (SparseFastPol) */
 		walk_fn k = !c.prefetch && c.nb == 4 ? (c.sparse_fast == 2 ? walk_direct_np<SparseFastPol, 2> : walk_direct_np<SparseFastPol, 4>) : c.nb == 4 ? walk_direct<SparseFastPol, 4, 1> : walk_direct<SparseFastPol, 8, 1>;

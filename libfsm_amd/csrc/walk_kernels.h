@@ -151,7 +151,7 @@ __device__ __forceinline__ uint64_t wave_excl_prefix(uint32_t v, uint32_t lane)
 	return x - v;
 }
 
-enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_LAZY = 5 };   /* (4 was walk_packed: removed in round 4) */
+enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_LAZY = 5, IN_LAZY_LINES = 6 };   /* (4 was walk_packed: removed in round 4) */
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
 #define FSMHIP_BTAB_BYTES 256u

@@ -379,6 +379,67 @@ oracle_table_walk_lens_mt(struct oracle_dfa *d, const unsigned char *base, size_
 	return now_s() - t0;
 }
 
+/* ... and over inputs packed back to back (input i = base[off[i] .. off[i+1]): the packed-lines front's full-parity checker;
+ * off[] is relative to `base`, threads take contiguous ranges of inputs */
+struct packed_job {
+	const struct oracle_dfa *d;
+	const unsigned char *base;
+	const uint64_t *off;
+	size_t first, count;
+	uint32_t *end;
+};
+
+static void *
+packed_worker(void *opaque)
+{
+	struct packed_job *j = opaque;
+	const struct oracle_dfa *d = j->d;
+	const uint32_t S = d->statecount;
+	size_t i;
+	for (i = j->first; i < j->first + j->count; i++) {
+		const unsigned char *p = j->base + j->off[i], *e = j->base + j->off[i + 1];
+		uint32_t st = d->start;
+		for (; p < e; p++) {
+			st = d->dense[(size_t) st * 256 + *p];
+		}
+		j->end[i] = (st < S && d->states[st].end) ? st : 0xFFFFFFFFu;
+	}
+	return NULL;
+}
+
+double
+oracle_table_walk_packed_mt(struct oracle_dfa *d, const unsigned char *base, const uint64_t *off, size_t n, uint32_t *end, int nthreads)
+{
+	pthread_t th[256];
+	struct packed_job jobs[256];
+	double t0;
+	int t;
+
+	if (!d->hasstart || !build_dense(d)) {
+		return -1.0;
+	}
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 256) nthreads = 256;
+	t0 = now_s();
+	for (t = 0; t < nthreads; t++) {
+		jobs[t].d = d;
+		jobs[t].base = base;
+		jobs[t].off = off;
+		jobs[t].first = n * (size_t) t / (size_t) nthreads;
+		jobs[t].count = n * (size_t) (t + 1) / (size_t) nthreads - jobs[t].first;
+		jobs[t].end = end;
+		if (pthread_create(&th[t], NULL, packed_worker, &jobs[t]) != 0) {
+			packed_worker(&jobs[t]);
+			th[t] = (pthread_t) 0;
+		}
+	}
+	for (t = 0; t < nthreads; t++) {
+		if (th[t] != (pthread_t) 0) {
+			pthread_join(th[t], NULL);
+		}
+	}
+	return now_s() - t0;
+}
 
 size_t
 oracle_endid_count(const struct oracle_dfa *d, uint32_t state)

@@ -149,6 +149,21 @@ class Oracle:
             raise RuntimeError("oracle_table_walk_lens_mt")
         return end
 
+    def table_walk_packed_mt(self, base: np.ndarray, off: np.ndarray, nthreads: int = 1) -> np.ndarray:
+        """the dense-table walk over inputs packed back to back (input i = base[off[i]:off[i+1]]), on nthreads host threads"""
+        lib = self.lib()
+        lib.oracle_table_walk_packed_mt.restype = C.c_double
+        lib.oracle_table_walk_packed_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        base = np.ascontiguousarray(base, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        assert n >= 0 and (n == 0 or int(off[-1]) <= len(base))
+        end = np.zeros(n, np.uint32)
+        self.last_seconds = lib.oracle_table_walk_packed_mt(self._h, _p(base) if len(base) else None, _p(off), n, _p(end), int(nthreads))
+        if self.last_seconds < 0:
+            raise RuntimeError("oracle_table_walk_packed_mt")
+        return end
+
     def state_walk(self, data: np.ndarray, state_io: np.ndarray, lens=None) -> np.ndarray:
         """Streaming walk: returns the states reached (0xFFFFFFFC = dead)."""
         data = np.ascontiguousarray(data, np.uint8)

@@ -303,3 +303,137 @@ def test_node_multi_shards_by_dfa(hip):
     assert set(a.tolist()) == {0, 1}
     for nd in nodes:
         nd.close()
+
+
+# ---- the lazy walk on the variable-length fronts (walk_lazy_lines, walk_lazy.h) ------------------------------------------------
+
+def _literal_set(hip, rng, alpha_b, nwords, lo, hi, flags):
+    alpha = np.frombuffer(alpha_b, np.uint8)
+    words = sorted(set(bytes(alpha[rng.randint(0, len(alpha), rng.randint(lo, hi + 1))]) for _ in range(nwords)))
+    return words, hip.FlatDfa.from_strings(words, flags, list(range(len(words))))
+
+
+def _lines_over(rng, alpha_b, n, maxlen, words, foreign=0.0, every=3):
+    """n lines of 0..maxlen bytes over the alphabet (a few much longer), every third ending with a literal"""
+    alpha = np.frombuffer(alpha_b, np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.randint(0, maxlen + 1)) if rng.rand() > 0.02 else int(rng.randint(maxlen, 6 * maxlen + 2))
+        b = alpha[rng.randint(0, len(alpha), L)]
+        if foreign > 0 and L:
+            m = rng.rand(L) < foreign
+            b[m] = rng.randint(0, 256, int(m.sum())).astype(np.uint8)
+        if i % every == 0:
+            w = words[rng.randint(len(words))]
+            if len(w) <= L:
+                b[L - len(w):] = np.frombuffer(w, np.uint8)
+        out.append(bytes(b))
+    return out
+
+
+def _oracle_lines(orc, strs):
+    L = max(16, max([len(x) for x in strs] + [1]))
+    rows = np.zeros((len(strs), L), np.uint8)
+    for i, x in enumerate(strs):
+        rows[i, :len(x)] = np.frombuffer(x, np.uint8)
+    return orc.table_walk(rows, np.array([len(x) for x in strs], np.uint32))
+
+
+@pytest.mark.parametrize("shape", [
+    (b"abcd", 400, 3, 9, 2),
+    (b"abcdefgh", 3000, 4, 10, 2),
+    (b"abcdefghijklmnop", 4000, 5, 9, 0),                                 # unanchored, end-ids: accept states are not absorbing
+    (b"abcdefghijklmnopqrstuvwxyz0123456789", 3000, 6, 12, 2),            # most answers are sentinels: the exact path
+    (b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-", 20000, 8, 16, 2),
+], ids=["a4", "a8", "a16-unanchored", "a36", "a64"])
+def test_lazy_walk_on_every_variable_length_front(hip, shape):
+    """walk_lazy_lines against the oracle on literal sets of several shapes: packed lines through u64 offsets, u32 offsets,
+    lengths alone (host and device pointers: the device buffer is exactly the batch), fixed stride + lengths, a stride that is
+    not a multiple of 64, lines with foreign bytes, empty lines, lines of several KB, batch sizes around the 256-line piece and
+    the 128 slots of a wavefront.  KNOB_LAZY_LINES = 0 (walk_ragged / walk_generic over the records) must say the same."""
+    import torch
+    from oracle.pyoracle import Oracle
+    alpha_b, nw, lo, hi, flags = shape
+    rng = np.random.RandomState(len(alpha_b) * 13 + nw)
+    words, flat = _literal_set(hip, rng, alpha_b, nw, lo, hi, flags)
+    assert hip.Plan(flat, hip.LAYOUT_SPARSE).get("lazy").size > 0
+    orc = Oracle(flat)
+    dfa = hip.HipDfa(flat, hip.LAYOUT_SPARSE)
+    dfa.tune(hip.KNOB_SPARSE_FAST, 3)
+    for n, maxlen, foreign in ((1, 40, 0.0), (127, 64, 0.0), (129, 30, 0.0), (255, 200, 0.0), (257, 8, 0.0), (3000, 100, 0.0), (5000, 300, 0.02), (700, 50, 0.3)):
+        strs = _lines_over(rng, alpha_b, n, maxlen, words, foreign)
+        want = _oracle_lines(orc, strs)
+        base, off = _pack(strs)
+        lens = np.diff(off).astype(np.uint32)
+        for knob in (1, 0):
+            dfa.tune(hip.KNOB_LAZY_LINES, knob)
+            end, bm = dfa.exec_batch_offsets(base, off)
+            assert np.array_equal(end, want), (n, maxlen, foreign, knob, "off64", np.flatnonzero(end != want)[:5])
+            assert np.array_equal(_bits(bm, n), want != NO)
+            assert ("walk_lazy_lines" in dfa.last_kernel_name()) == (knob == 1), dfa.last_kernel_name()
+            end, bm = dfa.exec_batch_offsets32(base, off.astype(np.uint32))
+            assert np.array_equal(end, want) and np.array_equal(_bits(bm, n), want != NO), (n, maxlen, knob, "off32")
+            end, bm = dfa.exec_batch_lengths(base, lens)
+            assert np.array_equal(end, want) and np.array_equal(_bits(bm, n), want != NO), (n, maxlen, knob, "len")
+        dfa.tune(hip.KNOB_LAZY_LINES, 1)
+        # device pointers, allocations of exactly the batch's size
+        tb = torch.from_numpy(base).cuda() if len(base) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        to = torch.from_numpy(off.astype(np.int64)).cuda()
+        tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+        te = torch.full((n,), 3, dtype=torch.int32, device="cuda")
+        tm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        dfa.exec_batch_offsets_device(tb.data_ptr(), to.data_ptr(), n, te.data_ptr(), tm.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(te.cpu().numpy().view(np.uint32), want) and np.array_equal(_bits(tm.cpu().numpy(), n), want != NO)
+        te.fill_(3)
+        dfa.exec_batch_lengths_device(tb.data_ptr(), tl.data_ptr(), n, te.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(te.cpu().numpy().view(np.uint32), want), (n, maxlen, "len device")
+        # fixed stride + lengths; a stride that is no multiple of 64 (whole rows)
+        short = [x[:100] for x in strs]
+        rows = np.zeros((n, 100), np.uint8)
+        for i, x in enumerate(short):
+            rows[i, :len(x)] = np.frombuffer(x, np.uint8)
+        sl = np.array([len(x) for x in short], np.uint32)
+        end, _ = dfa.exec_batch(rows, sl)
+        assert np.array_equal(end, orc.table_walk(rows, sl)), (n, "stride + lengths")
+        assert "walk_lazy_lines" in dfa.last_kernel_name()
+        alpha = np.frombuffer(alpha_b, np.uint8)
+        rows = alpha[rng.randint(0, len(alpha), (n, 72))]
+        end, _ = dfa.exec_batch(rows)
+        assert np.array_equal(end, orc.table_walk(rows)), (n, "stride 72")
+    dfa.close()
+
+
+def test_lazy_walk_resumed_in_pieces_and_ids(hip):
+    """Resume on the lazy walk (state_io: a state beyond the LDS set re-enters with what plan.cpp's car[] says it carries): every
+    line cut at a random point, the second piece started from the states the first one reached, equals the walk of the whole
+    line; a piece started in DEAD stays dead.  Device-side end-ids (EARLIEST) ride along on the same kernel."""
+    from oracle.pyoracle import Oracle
+    alpha_b = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_-"
+    rng = np.random.RandomState(77)
+    words, flat = _literal_set(hip, rng, alpha_b, 20000, 8, 16, 2)
+    orc = Oracle(flat)
+    dfa = hip.HipDfa(flat, hip.LAYOUT_SPARSE)
+    dfa.tune(hip.KNOB_SPARSE_FAST, 3)
+    strs = _lines_over(rng, alpha_b, 4000, 120, words)
+    want = _oracle_lines(orc, strs)
+    cut = [int(rng.randint(0, len(x) + 1)) for x in strs]
+    b1, o1 = _pack([x[:c] for x, c in zip(strs, cut)])
+    b2, o2 = _pack([x[c:] for x, c in zip(strs, cut)])
+    st, _ = dfa.exec_offsets_resume(b1, o1, np.full(len(strs), hip.STATE_START, np.uint32))
+    assert "walk_lazy_lines" in dfa.last_kernel_name(), dfa.last_kernel_name()
+    st2, end = dfa.exec_offsets_resume(b2, o2, st)
+    assert np.array_equal(end, want), np.flatnonzero(end != want)[:5]
+    dead = np.full(len(strs), hip.STATE_DEAD, np.uint32)
+    st3, end3 = dfa.exec_offsets_resume(b2, o2, dead)
+    assert (end3 == NO).all()
+    # end-ids: the literal's index (EARLIEST)
+    base, off = _pack(strs)
+    ids = dfa.exec_offsets_ids(base, off, 1)
+    assert "walk_lazy_lines" in dfa.last_kernel_name()
+    z = flat
+    eo, ei = np.asarray(z.endid_off), np.asarray(z.endids)
+    first = np.array([ei[eo[q]] if eo[q + 1] > eo[q] else NO for q in range(flat.nstates)] + [NO], np.uint32)
+    assert np.array_equal(ids, first[np.where(want != NO, want, flat.nstates)])
+    dfa.close()

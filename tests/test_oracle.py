@@ -180,3 +180,17 @@ def test_oracle_on_reference_fsm_corpus():
         total += len(ret)
         acc += int((ret == 1).sum())
     assert total > 8000 and acc > 2500
+
+
+def test_packed_table_walker_equals_the_goldens(built):
+    """oracle_table_walk_packed_mt (the full-parity checker of bench.py's packed-lines legs) on every golden vector: the
+    reference's own answers, on 1 and on 3 threads"""
+    from common import Golden, all_golden_paths
+    from oracle.pyoracle import Oracle
+    for p in all_golden_paths():
+        g = Golden(p)
+        base, off = g.packed()
+        want = np.where(g.ret == 1, g.end, 0xFFFFFFFF).astype(np.uint32)
+        o = Oracle(g.flat)
+        for nt in (1, 3):
+            assert np.array_equal(o.table_walk_packed_mt(base, off, nt), want), g.name
