@@ -131,6 +131,12 @@ void fsm_hip_dfa_free(struct fsm_hip_dfa *dfa);
 
 int fsm_hip_dfa_info(const struct fsm_hip_dfa *dfa, struct fsm_hip_dfa_info *out);
 
+/* Everything a later call on batches of up to n inputs would allocate, now: the tile-base block of the lengths-only front (and
+ * the layout's tables, for a dfa created with FSM_HIP_DEFER_UPLOAD).  After it the device-pointer fronts make no allocation
+ * for such batches: they can be captured into a HIP graph from the first launch (an allocation that would be needed during a
+ * stream capture fails with ENOMEM instead of breaking the capture). */
+int fsm_hip_reserve(struct fsm_hip_dfa *dfa, size_t n);
+
 /* ------------------------------------------------------------------ */
 /* batched execution (the hot path)                                   */
 /* ------------------------------------------------------------------ */
@@ -330,6 +336,14 @@ int fsm_hip_exec_batch_resume_offsets(const struct fsm_hip_dfa *dfa,
 	uint32_t *state_io, uint32_t *end_out);
 int fsm_hip_exec_batch_resume_offsets_device(const struct fsm_hip_dfa *dfa,
 	const void *d_base, const uint64_t *d_off, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
+/* ... and over the compact forms (meta_form = FSM_HIP_META_OFF64 / _OFF32 / _LENGTHS, as fsm_hip_exec_batch_packed_all): the carry
+ * of fsm_vm_match_file (src/libfsm/vm.c:188-216) for batches whose metadata is u32 offsets or lengths alone (round 5) */
+int fsm_hip_exec_batch_resume_packed(const struct fsm_hip_dfa *dfa,
+	const unsigned char *base, int meta_form, const void *meta, size_t n,
+	uint32_t *state_io, uint32_t *end_out);
+int fsm_hip_exec_batch_resume_packed_device(const struct fsm_hip_dfa *dfa,
+	const void *d_base, int meta_form, const void *d_meta, size_t n,
 	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream);
 
 /* ------------------------------------------------------------------ */

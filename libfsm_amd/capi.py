@@ -625,6 +625,31 @@ class HipDfa:
             raise _oserr("fsm_hip_exec_batch_resume_offsets")
         return st, end
 
+    def exec_packed_resume(self, base: np.ndarray, meta_form: int, meta: np.ndarray, n: int, state_io: np.ndarray):
+        """fsm_hip_exec_batch_resume_packed: resume over u64 offsets / u32 offsets / lengths alone; returns (state_out, end)."""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        meta = np.ascontiguousarray(meta)
+        st = np.ascontiguousarray(state_io, dtype=np.uint32).copy()
+        end = np.empty(n, dtype=np.uint32)
+        C.set_errno(0)
+        if self._lib.fsm_hip_exec_batch_resume_packed(C.c_void_p(self._h), C.c_void_p(base.ctypes.data if len(base) else None), C.c_int(meta_form),
+                                                      C.c_void_p(meta.ctypes.data if len(meta) else None), C.c_size_t(n), _ptr(st), _ptr(end)) != 0:
+            raise _oserr("fsm_hip_exec_batch_resume_packed")
+        return st, end
+
+    def exec_packed_resume_device(self, d_base: int, meta_form: int, d_meta: int, n: int, d_state_io: int, d_end: int = 0, d_bitmap: int = 0, stream: int = 0):
+        C.set_errno(0)
+        vp = C.c_void_p
+        if self._lib.fsm_hip_exec_batch_resume_packed_device(vp(self._h), vp(d_base or None), C.c_int(meta_form), vp(d_meta or None), C.c_size_t(n), vp(d_state_io),
+                                                             vp(d_end or None), vp(d_bitmap or None), vp(stream or None)) != 0:
+            raise _oserr("fsm_hip_exec_batch_resume_packed_device")
+
+    def reserve(self, n: int):
+        """fsm_hip_reserve: allocate now what batches of up to n inputs would allocate later (graph capture from the first launch)."""
+        C.set_errno(0)
+        if self._lib.fsm_hip_reserve(C.c_void_p(self._h), C.c_size_t(n)) != 0:
+            raise _oserr("fsm_hip_reserve")
+
     def exec_offsets_eager(self, base: np.ndarray, off: np.ndarray):
         base = np.ascontiguousarray(base, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)

@@ -533,7 +533,7 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* per_lane: take walk_generic unless a knob says otherwise -- the inputs average < 96 bytes (walk_ragged works in
  * 128-byte segments: 0.7-1.2 vs 1.5-2.1 TB/s at 8-64 bytes, profiles/r03t_*); huge: the batch may hold an input the
  * ragged kernel's 32-bit piece count cannot (>= 2^36 bytes) */
-static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false, bool resumed = false)
+static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, int eager, bool per_lane = false, bool huge = false, bool resumed = false, bool many = false)
 {
 	LaunchCfg c = LaunchCfg();    /* kfn = nullptr until a launch sets it */
 	const uint32_t layout = d->plan.layout;
@@ -709,7 +709,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const int eager = a.eager_out == nullptr ? 0 : a.eager_words > 1 ? 2 : 1;
 	const bool varlen = a.off != nullptr || a.off32 != nullptr || a.len != nullptr;
 	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : !varlen ? (uint64_t)a.n * a.stride : 0;
-	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr);
+	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr, a.n >= ((uint64_t)1 << 32));
 	const uint64_t ntiles = (a.n + 63u) / 64u;
 	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves
 		: c.mode == IN_LAZY_LINES ? ((a.n + FSMHIP_LAZY_PIECE - 1u) / FSMHIP_LAZY_PIECE + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
@@ -771,22 +771,57 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 /* The lengths-only front: byte offset of every 64th input of a batch packed back to back (walk_aux.h tile_bases_*), into the
  * dfa's grow-only block; the walk that follows on the same stream reads it.  The block's previous user (any stream) is
  * waited for first; `tbase` = the array the walk kernels take (T + 1 entries, the last one the batch's size). */
+static size_t tb_bytes_for(size_t n)
+{
+	const uint64_t T1 = (n + 63u) / 64u + 1u, nb = (T1 + 1023u) / 1024u;
+	return (size_t)(T1 + nb) * sizeof(uint64_t);
+}
+
+/* (grows by doubling: a handful of blocking hipMalloc calls over a dfa's life; launches in flight may still use the old block) */
+static hipError_t tb_grow(fsm_hip_dfa *d, size_t want)
+{
+	if (want <= d->tb_scratch_bytes) return hipSuccess;
+	if (d->tb_scratch) d->tb_scratch_old.push_back(d->tb_scratch);
+	d->tb_scratch = nullptr;
+	d->tb_scratch_bytes = 0;
+	size_t cap = (size_t)1 << 16;
+	while (cap < want) cap *= 2;
+	const hipError_t e = hipMalloc((void **)&d->tb_scratch, cap);
+	if (e == hipSuccess) d->tb_scratch_bytes = cap;
+	return e;
+}
+
+/* Everything a later call on batches of up to n inputs would allocate, now: the tile-base block of the lengths-only front
+ * (the layout's tables too, for a dfa created with FSM_HIP_DEFER_UPLOAD).  After it the device-pointer fronts make no
+ * allocation for such batches and can be captured into a HIP graph from the first launch. */
+extern "C" int fsm_hip_reserve(struct fsm_hip_dfa *d, size_t n)
+{
+	if (d == nullptr) { errno = EINVAL; return -1; }
+	if (ensure_uploaded(d) != 0) return -1;
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	DfaLock lk(d->mu);
+	const hipError_t e = tb_grow(d, tb_bytes_for(n));
+	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	return 0;
+}
+
 static int tile_bases(fsm_hip_dfa *d, const uint32_t *d_len, size_t n, hipStream_t s, const uint64_t **tbase)
 {
 	DfaLock lk(d->mu);
 	const uint64_t T1 = (n + 63u) / 64u + 1u, nb = (T1 + 1023u) / 1024u;
-	const size_t want = (size_t)(T1 + nb) * sizeof(uint64_t);
+	const size_t want = tb_bytes_for(n);
 	hipError_t e = hipSuccess;
 	if (d->tb_scratch_busy) e = hipStreamWaitEvent(s, d->tb_scratch_ev, 0);
 	if (e == hipSuccess && want > d->tb_scratch_bytes) {
-		/* (grows by doubling: a handful of blocking hipMalloc calls over a dfa's life; launches in flight may still use the old block) */
-		if (d->tb_scratch) d->tb_scratch_old.push_back(d->tb_scratch);
-		d->tb_scratch = nullptr;
-		d->tb_scratch_bytes = 0;
-		size_t cap = (size_t)1 << 16;
-		while (cap < want) cap *= 2;
-		e = hipMalloc((void **)&d->tb_scratch, cap);
-		if (e == hipSuccess) d->tb_scratch_bytes = cap;
+		/* a blocking hipMalloc: illegal while the stream is being captured into a graph -- fsm_hip_reserve() sizes the block ahead */
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+			if (getenv("FSM_HIP_DEBUG")) fprintf(stderr, "fsm_hip: the lengths front needs %zu bytes of scratch during a stream capture: call fsm_hip_reserve() first\n", want);
+			errno = ENOMEM;
+			return -1;
+		}
+		e = tb_grow(d, want);
 	}
 	if (e == hipSuccess) {
 		uint64_t *tb = reinterpret_cast<uint64_t *>(d->tb_scratch), *bt = tb + T1;
@@ -1757,18 +1792,24 @@ extern "C" int fsm_hip_state_is_absorbing(const struct fsm_hip_dfa *d, uint32_t 
 }
 
 static int resume_device(fsm_hip_dfa *d, const void *d_base, size_t stride, const uint32_t *d_len, const uint64_t *d_off, size_t n,
-	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint,
+	const uint32_t *d_off32 = nullptr, bool lens_only = false)
 {
-	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_off == nullptr && d_off32 == nullptr && !lens_only && d_base == nullptr && stride != 0) ||
+	    (lens_only && n != 0 && d_len == nullptr)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
 	if (ensure_resume(d) != 0) return -1;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	if (ensure_uploaded(d) != 0) return -1;
 	WalkArgs a = d->proto;
+	const bool packed = d_off != nullptr || d_off32 != nullptr || lens_only;
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
 	a.base = static_cast<const uint8_t *>(d_base);
-	a.stride = d_off ? 0 : stride;
-	a.len = d_off ? nullptr : d_len;
+	a.stride = packed ? 0 : stride;
+	a.len = d_off != nullptr || d_off32 != nullptr ? nullptr : d_len;
 	a.off = d_off;
+	a.off32 = d_off == nullptr ? d_off32 : nullptr;
 	a.n = n;
 	a.end_out = d_end_out;
 	a.bitmap = d_accept_bitmap;
@@ -1776,9 +1817,77 @@ static int resume_device(fsm_hip_dfa *d, const void *d_base, size_t stride, cons
 	a.enc_of = d->d_enc_of;
 	a.orig_of = d->d_orig_of;
 	a.nstates = d->plan.nstates;
-	const bool fast = d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
+	const bool lo = lens_only && d_off == nullptr && d_off32 == nullptr;
+	DfaLock lk(d->mu);   /* pre-pass, walk and the block's event in one critical section (see exec_packed_device) */
+	if (lo && tile_bases(d, d_len, n, s, &a.tbase) != 0) return -1;
+	const bool fast = !packed && d_len == nullptr && stride != 0 && stride % 16u == 0 &&
 		(reinterpret_cast<uintptr_t>(d_base) % 16u) == 0 && d->knob_input_mode != IN_GENERIC;
-	return launch_walk(d, a, fast, static_cast<hipStream_t>(hip_stream), hint);
+	const int r = launch_walk(d, a, fast, s, hint);
+	if (lo) tile_bases_done(d, s);
+	return r;
+}
+
+/* resume over packed inputs whose metadata is u64 offsets, u32 offsets or lengths alone: the carry of fsm_vm_match_file
+ * (src/libfsm/vm.c:188-216: the state survives from one buffer to the next) for batches in the compact forms */
+extern "C" int fsm_hip_exec_batch_resume_packed_device(const struct fsm_hip_dfa *dc,
+	const void *d_base, int meta_form, const void *d_meta, size_t n,
+	uint32_t *d_state_io, uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream)
+{
+	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(dc);
+	if (n != 0 && d_meta == nullptr) { errno = EINVAL; return -1; }
+	switch (meta_form) {
+	case FSM_HIP_META_OFF64:
+		return resume_device(d, d_base, 0, nullptr, static_cast<const uint64_t *>(d_meta), n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, BatchHint());
+	case FSM_HIP_META_OFF32:
+		return resume_device(d, d_base, 0, nullptr, nullptr, n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, BatchHint(), static_cast<const uint32_t *>(d_meta), false);
+	case FSM_HIP_META_LENGTHS:
+		return resume_device(d, d_base, 0, static_cast<const uint32_t *>(d_meta), nullptr, n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, BatchHint(), nullptr, true);
+	default:
+		errno = EINVAL;
+		return -1;
+	}
+}
+
+extern "C" int fsm_hip_exec_batch_resume_packed(const struct fsm_hip_dfa *d,
+	const unsigned char *base, int meta_form, const void *meta, size_t n,
+	uint32_t *state_io, uint32_t *end_out)
+{
+	if (d == nullptr || state_io == nullptr || (n != 0 && meta == nullptr) ||
+	    (meta_form != FSM_HIP_META_OFF64 && meta_form != FSM_HIP_META_OFF32 && meta_form != FSM_HIP_META_LENGTHS)) { errno = EINVAL; return -1; }
+	if (n == 0) return 0;
+	size_t in_bytes = 0, meta_bytes = 0;
+	if (meta_form == FSM_HIP_META_OFF64) {
+		const uint64_t *o = static_cast<const uint64_t *>(meta);
+		for (size_t i = 0; i < n; i++) if (o[i + 1] < o[i]) { errno = EINVAL; return -1; }
+		in_bytes = (size_t)o[n]; meta_bytes = (n + 1) * sizeof(uint64_t);
+	} else if (meta_form == FSM_HIP_META_OFF32) {
+		const uint32_t *o = static_cast<const uint32_t *>(meta);
+		for (size_t i = 0; i < n; i++) if (o[i + 1] < o[i]) { errno = EINVAL; return -1; }
+		in_bytes = o[n]; meta_bytes = (n + 1) * sizeof(uint32_t);
+	} else {
+		const uint32_t *l = static_cast<const uint32_t *>(meta);
+		uint64_t sum = 0;
+		for (size_t i = 0; i < n; i++) sum += l[i];
+		in_bytes = (size_t)sum; meta_bytes = n * sizeof(uint32_t);
+	}
+	if (in_bytes != 0 && base == nullptr) { errno = EINVAL; return -1; }
+	DevGuard dg(d->device);
+	if (!dg.ok()) { errno = ENODEV; return -1; }
+	HostCall hc(d);
+	const int p_in = hc.add(HostCall::IN, base, nullptr, in_bytes, 32);
+	const int p_meta = hc.add(HostCall::IN, meta, nullptr, meta_bytes);
+	const int p_st = hc.add(HostCall::INOUT, state_io, state_io, n * sizeof(uint32_t));
+	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
+	if (hc.begin() != 0) return -1;
+	BatchHint hint;
+	hint.bytes = in_bytes;
+	hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
+	const void *dm = hc.dev<unsigned char>(p_meta);
+	if (resume_device(hc.d, hc.dev<unsigned char>(p_in), 0, meta_form == FSM_HIP_META_LENGTHS ? static_cast<const uint32_t *>(dm) : nullptr,
+	                  meta_form == FSM_HIP_META_OFF64 ? static_cast<const uint64_t *>(dm) : nullptr, n,
+	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, hint,
+	                  meta_form == FSM_HIP_META_OFF32 ? static_cast<const uint32_t *>(dm) : nullptr, meta_form == FSM_HIP_META_LENGTHS) != 0) return -1;
+	return hc.end();
 }
 
 extern "C" int fsm_hip_exec_batch_resume_device(const struct fsm_hip_dfa *dc,

@@ -110,6 +110,23 @@ static void worker_main(fsm_hip_node *nd, size_t k)
 	}
 }
 
+/* clearing by a KERNEL, not hipMemsetAsync: as the first node of a replayed graph a memset node was seen to run before the work
+ * that precedes the graph launch on the same stream had finished (walk_aux.h zero_async, round 4) */
+__global__ void __launch_bounds__(256) node_zero_kernel(uint32_t *p, uint64_t n32)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+static hipError_t node_zero_async(void *p, uint64_t bytes, hipStream_t s)
+{
+	const uint64_t n32 = bytes / 4u;
+	if (n32 == 0) return hipSuccess;
+	uint64_t blocks = (n32 + 255u) / 256u;
+	if (blocks > 4096u) blocks = 4096u;
+	hipLaunchKernelGGL(node_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t *>(p), n32);
+	return hipGetLastError();
+}
+
 /* accepted inputs of a bitmap slice: one atomic per wavefront */
 __global__ void __launch_bounds__(256)
 count_bits_kernel(const uint64_t *words, uint64_t nwords, unsigned long long *out)
@@ -433,7 +450,7 @@ extern "C" int fsm_hip_node_exec_device(struct fsm_hip_node *nd, const struct fs
 		if (hipStreamWaitEvent(s, nd->gathered[2 * (size_t)k + (size_t)slot], 0) != hipSuccess) { errno = EIO; return -1; }
 		uint64_t *slice = b->d_bitmap_all ? b->d_bitmap_all[k] + (size_t)k * wpd : nullptr;
 		if (slice != nullptr && cnt < wpd * 64 &&
-		    hipMemsetAsync(slice, 0, wpd * sizeof(uint64_t), s) != hipSuccess) { errno = EIO; return -1; }
+		    node_zero_async(slice, wpd * sizeof(uint64_t), s) != hipSuccess) { errno = EIO; return -1; }
 		fsm_hip_dfa *d = nd->dfa[(size_t)k];
 		uint32_t *e_out = b->d_end_out ? b->d_end_out[k] : nullptr;
 		if (cnt != 0) {
@@ -444,7 +461,7 @@ extern "C" int fsm_hip_node_exec_device(struct fsm_hip_node *nd, const struct fs
 			if (r != 0) return -1;
 		}
 		if (count) {
-			if (hipMemsetAsync(nd->d_count[(size_t)k] + slot, 0, sizeof(unsigned long long), s) != hipSuccess) { errno = EIO; return -1; }
+			if (node_zero_async(nd->d_count[(size_t)k] + slot, sizeof(unsigned long long), s) != hipSuccess) { errno = EIO; return -1; }
 			hipLaunchKernelGGL(count_bits_kernel, dim3(256), dim3(256), 0, s, slice, (uint64_t)wpd, nd->d_count[(size_t)k] + slot);
 			if (hipGetLastError() != hipSuccess) { errno = EIO; return -1; }
 		}
