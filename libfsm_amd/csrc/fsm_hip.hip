@@ -771,6 +771,9 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 /* The lengths-only front: byte offset of every 64th input of a batch packed back to back (walk_aux.h tile_bases_*), into the
  * dfa's grow-only block; the walk that follows on the same stream reads it.  The block's previous user (any stream) is
  * waited for first; `tbase` = the array the walk kernels take (T + 1 entries, the last one the batch's size). */
+static int ensure_ids(fsm_hip_dfa *d);
+static int ensure_resume(fsm_hip_dfa *d);
+
 static size_t tb_bytes_for(size_t n)
 {
 	const uint64_t T1 = (n + 63u) / 64u + 1u, nb = (T1 + 1023u) / 1024u;
@@ -803,6 +806,10 @@ extern "C" int fsm_hip_reserve(struct fsm_hip_dfa *d, size_t n)
 	DfaLock lk(d->mu);
 	const hipError_t e = tb_grow(d, tb_bytes_for(n));
 	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
+	/* ... and the tables the end-id and resume fronts build at their first call */
+	(void)ensure_ids(d);
+	(void)ensure_resume(d);
+	errno = 0;
 	return 0;
 }
 

@@ -437,3 +437,135 @@ def test_lazy_walk_resumed_in_pieces_and_ids(hip):
     first = np.array([ei[eo[q]] if eo[q + 1] > eo[q] else NO for q in range(flat.nstates)] + [NO], np.uint32)
     assert np.array_equal(ids, first[np.where(want != NO, want, flat.nstates)])
     dfa.close()
+
+
+# ---- capturable from the first launch; resume over the compact forms -----------------------------------------------------------
+
+def test_lengths_front_captures_from_the_first_launch_after_reserve(hip):
+    """fsm_hip_reserve(dfa, n) sizes the lengths-only front's tile-base block ahead: a COLD dfa (never launched) captures the
+    lengths front and fsm_hip_exec_batch_packed_all_device into a HIP graph at a size (600 000 lines) that would have grown
+    the default block, replayed on changed inputs against the oracle.  Without the reserve the same capture is refused with
+    ENOMEM (an allocation during a stream capture would break it) and the stream stays usable."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g_ = Golden(os.path.join(GOLDEN, "c3.npz"))
+    o = Oracle(g_.flat)
+    rng = np.random.RandomState(8)
+    n = 600_000
+    alpha = np.frombuffer(b"abcdwxyz0123456789", np.uint8)
+    src = g_.strings()
+
+    def batch():
+        lens = rng.randint(0, 25, n).astype(np.uint32)
+        rows = alpha[rng.randint(0, len(alpha), (n, 24))]
+        pre = np.frombuffer(src[int(rng.randint(len(src)))][:6].ljust(6, b"0"), np.uint8)
+        rows[::3, :6] = pre                                   # a pattern's prefix: some lines stay alive
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        mask = np.arange(24)[None, :] < lens[:, None]
+        return rows, lens, off, rows[mask]
+
+    rows, lens, off, packed = batch()
+    cap = n * 24 + 16
+    d_packed = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_end = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    d_ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def put(lens, packed):
+        d_len.copy_(torch.from_numpy(lens.view(np.int32)))
+        d_packed[:len(packed)] = torch.from_numpy(packed).cuda()
+
+    put(lens, packed)
+    # 1. no reserve: refused, not broken
+    cold = hip.HipDfa(g_.flat)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gr0 = torch.cuda.CUDAGraph()
+        refused = False
+        try:
+            with torch.cuda.graph(gr0, stream=st):
+                try:
+                    cold.exec_batch_lengths_device(d_packed.data_ptr(), d_len.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr(), stream=st.cuda_stream)
+                except OSError as e:
+                    refused = True
+                    import errno as _e
+                    assert e.errno == _e.ENOMEM, e
+        except RuntimeError:
+            pass                                                  # (an empty capture may or may not instantiate)
+    assert refused
+    torch.cuda.synchronize()
+    cold.close()
+    # 2. reserve, then capture at the first launch
+    dfa = hip.HipDfa(g_.flat)
+    dfa.reserve(n)
+    graphs = {}
+    with torch.cuda.stream(st):
+        for name in ("lengths", "packed_all"):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                if name == "lengths":
+                    dfa.exec_batch_lengths_device(d_packed.data_ptr(), d_len.data_ptr(), n, d_end.data_ptr(), d_bm.data_ptr(), stream=st.cuda_stream)
+                else:
+                    dfa.exec_packed_all_device(d_packed.data_ptr(), hip.META_LENGTHS, d_len.data_ptr(), n, d_end=d_end.data_ptr(), d_bitmap=d_bm.data_ptr(),
+                                               ids_mode=1, d_ids=d_ids.data_ptr(), stream=st.cuda_stream)
+            graphs[name] = gr
+    eo, ei = np.asarray(g_.flat.endid_off), np.asarray(g_.flat.endids)
+    first = np.array([ei[eo[q]] if eo[q + 1] > eo[q] else NO for q in range(g_.flat.nstates)] + [NO], np.uint32)
+    for rep in range(2):
+        rows, lens, off, packed = batch()
+        put(lens, packed)
+        want = o.table_walk(rows, lens)
+        for name, gr in graphs.items():
+            d_end.fill_(7)
+            d_bm.fill_(-1)
+            d_ids.fill_(9)
+            torch.cuda.synchronize()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want), (name, rep)
+            assert np.array_equal(_bits(d_bm.cpu().numpy(), n), want != NO), (name, rep)
+            if name == "packed_all":
+                assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), first[np.where(want != NO, want, g_.flat.nstates)]), rep
+    dfa.close()
+
+
+@pytest.mark.parametrize("table", ["c1.npz", "c3.npz", "re_strings_2.npz"])
+def test_resume_over_the_compact_forms(hip, table):
+    """fsm_hip_exec_batch_resume_packed{,_device}: the carry of fsm_vm_match_file (src/libfsm/vm.c:188-216 -- the state survives
+    from one buffer to the next) for batches whose metadata is u32 offsets or lengths alone: every line cut in three pieces,
+    each piece batch in another form, equals the walk of the whole line; a line's state is the reference's state id."""
+    import torch
+    from oracle.pyoracle import Oracle
+    g_ = Golden(os.path.join(GOLDEN, table))
+    o = Oracle(g_.flat)
+    rng = np.random.RandomState(21)
+    src = g_.strings()
+    strs = [src[i % len(src)][:rng.randint(0, 200)] for i in range(3000)]
+    want = _oracle_lines(o, strs)
+    c1 = [int(rng.randint(0, len(x) + 1)) for x in strs]
+    c2 = [int(rng.randint(c, len(x) + 1)) for x, c in zip(strs, c1)]
+    pieces = [[x[:a] for x, a in zip(strs, c1)], [x[a:b] for x, a, b in zip(strs, c1, c2)], [x[b:] for x, b in zip(strs, c2)]]
+    dfa = hip.HipDfa(g_.flat)
+    n = len(strs)
+    st = np.full(n, hip.STATE_START, np.uint32)
+    forms = [hip.META_OFF32, hip.META_LENGTHS, hip.META_OFF64]
+    for p, form in zip(pieces, forms):
+        base, off = _pack(p)
+        meta = off.astype(np.uint32) if form == hip.META_OFF32 else np.diff(off).astype(np.uint32) if form == hip.META_LENGTHS else off
+        st, end = dfa.exec_packed_resume(base, form, meta, n, st)
+    assert np.array_equal(end, want), np.flatnonzero(end != want)[:5]
+    # device pointers, lengths only, with the accept bitmap
+    st = torch.full((n,), int(hip.STATE_START), dtype=torch.int64).to(torch.int32).cuda() if False else torch.from_numpy(np.full(n, hip.STATE_START, np.uint32).view(np.int32)).cuda()
+    d_end = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    for p in pieces:
+        base, off = _pack(p)
+        tb = torch.from_numpy(base).cuda() if len(base) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        tl = torch.from_numpy(np.diff(off).astype(np.int32)).cuda()
+        dfa.exec_packed_resume_device(tb.data_ptr(), hip.META_LENGTHS, tl.data_ptr(), n, st.data_ptr(), d_end.data_ptr(), d_bm.data_ptr())
+        torch.cuda.synchronize()
+    assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(_bits(d_bm.cpu().numpy(), n), want != NO)
+    dfa.close()
