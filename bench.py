@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged", "c3_eager40"],
                     help="c*_short / c*_ragged: the packed-lines front alone (what the default run reports as sub_results), for profiling")
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
@@ -928,7 +928,12 @@ def main():
                 t = json.load(open(pj))
                 if int(t.get("n", 0)) == n_l and t.get("kernels_sha16") == kernels_sha16():
                     res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                    res["roofline"]["traffic_source"] = f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this sub-result (recorded, not measured in this run)"
+                    res["roofline"]["traffic_source"] = (f"profiles/{t.get('source')}: rocprofv3 --pmc passes over this sub-result -- reads from TCC_EA0_RDREQ_32B / _64B / _128B "
+                                                         "(32 a + 64 b + 128 c bytes), writes from WRITE_SIZE (recorded, not measured in this run)")
+                    # a kernel that stops reading lines which can no longer change state moves fewer bytes than the caller handed it:
+                    # its rate on the bytes it MOVED beside the one on the bytes it matched
+                    if res["roofline"]["traffic"]:
+                        res["roofline"]["frac_on_bytes_moved"] = round(res["roofline"]["traffic"] / f0["kernel_ms_avg"] / 1e6 / HBM_PEAK_GBS, 4)
             except Exception:
                 pass
         # parity: a stratified sample of the lines -- their bytes gathered from the PACKED buffer the kernel walked -- against
@@ -975,9 +980,144 @@ def main():
         del packed, off, lens, end2, bm
         return res
 
+    def run_eager40():
+        """SURVEY.md 8(f)2 / exec.c:126-144: the eager-output walk on the kind of DFA it exists for -- the reference's
+        fsm_union_repeated_pattern_group over 40 unanchored literals, one eager id each (tests/golden/bench/eager40.npz, frozen
+        from the real reference by tests/golden/make_eager40.py); 1e7 x 1 KiB rows of lowercase text, a pattern planted in
+        every 4th.  Per input: L bytes read + 4 B end state + 8 B id set written."""
+        z = np.load(os.path.join(ROOT, "tests", "golden", "bench", "eager40.npz"))
+        flat = hip.FlatDfa.load(z)
+        words = bytes(z["patterns"]).split(b"\n")
+        n_e = min(10_000_000, n)
+        buf, end = buf_all[:n_e], end_all[:n_e]
+        alpha = b"abcdefghijklmnopqrstuvwxyz"
+        hip.gen_inputs_device(buf.data_ptr(), n_e, L, 0, 7, alpha, words[0], 4)
+        dfa = hip.HipDfa(flat, a.layout)
+        W = dfa.eager_words()
+        sets = torch.zeros((n_e, W), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        res = {"workload": "c3_eager40"}
+        for name, fn in (("plain", lambda: dfa.exec_batch_device(buf.data_ptr(), L, n_e, end.data_ptr(), 0, stream=stream)),
+                         ("eager", lambda: dfa.exec_batch_eager_device(buf.data_ptr(), L, n_e, end.data_ptr(), sets.data_ptr(), stream=stream))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ms = []
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                fn()
+                ms.append(dfa.last_kernel_ms())
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / a.steps * 1e3
+            res[name] = {"ms_per_step": round(wall, 4), "kernel_ms_avg": round(float(np.mean(ms)), 4), "GBps": round(n_e * L / wall / 1e6, 2), "kernel": dfa.last_kernel_name()}
+        k_ms = res["eager"]["kernel_ms_avg"]
+        alg = float(n_e) * (L + 4 + 8 * W)
+        info = dfa.info()
+        res.update(value=res["eager"]["GBps"], ms_per_step=res["eager"]["ms_per_step"],
+                   config={"workload": f"eager outputs: fsm_union_repeated_pattern_group over 40 unanchored literals ({flat.nstates} states, {dfa.eager_id_count()} eager ids), "
+                                       f"{n_e} x {L} B lowercase rows, a pattern planted in every 4th; end state + id set per input",
+                           "inputs_per_gpu": n_e, "input_len": L, "dfa_states": flat.nstates, "table_layout": info["layout_name"], "eager_ids": dfa.eager_id_count(),
+                           "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"], "waves_per_block": info["waves_per_block"]},
+                   roofline={"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4),
+                             "kernel": res["eager"]["kernel"], "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg,
+                             "algorithmic_bytes": "L bytes + 4 B end state + 8 B id set per input", "traffic": None, "traffic_source": None,
+                             "plain_walk_same_dfa_GBps": res["plain"]["GBps"]})
+        pj = os.path.join(ROOT, "profiles", "pmc_c3_eager40.json")
+        if os.path.exists(pj):
+            try:
+                t = json.load(open(pj))
+                if int(t.get("n", 0)) == n_e and t.get("kernels_sha16") == kernels_sha16():
+                    res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = f"profiles/{t.get('source')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this sub-result (recorded, not measured in this run)"
+            except Exception:
+                pass
+        if not a.no_cpu_baseline and a.cpu_sample != 0:
+            # the oracle's eager walk (exec.c:126-144 restated) on a stratified sample: end state AND id set per input
+            o = get_oracle(flat)
+            idx = sample_indices(n_e, 20_000)
+            tidx = torch.from_numpy(idx).cuda()
+            rows = buf[tidx].cpu().numpy()
+            t0 = time.perf_counter()
+            _, wend, wsets = o.exec_eager(rows, None, cap=dfa.eager_id_count() + 8)
+            t_cpu = time.perf_counter() - t0
+            ids = np.array([dfa.eager_id(b) for b in range(dfa.eager_id_count())], np.uint32)
+            got_end = end[tidx].cpu().numpy().view(np.uint32)
+            bits = np.unpackbits(sets[tidx].cpu().numpy().view(np.uint8).reshape(len(idx), W * 8), axis=1, bitorder="little")[:, :len(ids)].astype(bool)
+            ok = bool(np.array_equal(got_end, wend)) and all(np.array_equal(ids[bits[i]], np.sort(np.asarray(wsets[i], np.uint32))) for i in range(len(idx)))
+            res["cpu_baseline"] = {"kind": "port", "value": round(rows.size / 1e9 / t_cpu, 5), "unit": "GB/s", "cores": 1,
+                                   "sample": f"oracle eager walk (oracle/dfa_oracle.c, exec.c:126-144 restated), 1 thread, {len(idx)} inputs"}
+            res["parity_vs_cpu_sample"] = "bit-exact" if ok else "MISMATCH"
+            res["parity_sample"] = f"{len(idx)} inputs (stratified): end state and eager id set; {int((sets != 0).any(dim=1).sum().item())} of {n_e} inputs fired an id"
+            if not ok:
+                res["value"] = None
+        dfa.close()
+        return res
+
+    def lds_chain_ceiling(sub):
+        """roofline.lds_chain_ceiling for a lookup-layout sub-result: the same dependent chain (random ds_read_b32 per byte, extract,
+        add, compare, select) with the inputs in registers, at the sub-result's table size and wavefront shape."""
+        try:
+            cfg = sub["config"]
+            tb = int(max(2048, min(160 * 1024 - 1024, cfg.get("table_bytes") or cfg["lds_bytes_per_block"])))
+            waves = int(cfg["waves_per_block"])
+            bpc = max(1, min((160 * 1024) // max(tb, 1), 32 // max(waves, 1)))
+            scratch = torch.zeros(4, dtype=torch.int32, device="cuda")
+            g = hip.lds_chain_probe_gbps(tb, waves, bpc, 1 << 16, scratch.data_ptr(), stream)
+            sub["roofline"]["lds_chain_ceiling"] = {
+                "probe": f"fsm_hip_lds_chain_probe_gbps: {waves} wavefronts x {bpc} workgroup(s) per CU beside a {tb} B random table, 65 536 dependent "
+                         "byte-steps per lane (ds_read_b32 -> bfe -> add -> compare -> select), input bytes made in registers",
+                "implied_GBps": round(g, 1), "achieved_over_ceiling": round(sub["roofline"]["achieved"] / g, 4) if g > 0 and sub["roofline"].get("achieved") else None}
+        except Exception as e:  # noqa: BLE001
+            sub["roofline"]["lds_chain_ceiling"] = {"error": repr(e)[:200]}
+
+    def run_multi_dfa():
+        """north_star's many-DFA batches on the reference's own retest corpus (37 automata / 115 lines, tests/golden/retest): per
+        pass over the 37 records, table builds included, one by one (fsm_hip_dfa_create + fsm_hip_exec_batch_offsets each) against
+        ONE fsm_hip_exec_multi over dfas created with FSM_HIP_DEFER_UPLOAD; every end state against the frozen fsm_exec answers."""
+        import glob
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from common import Golden
+        gs = [Golden(p) for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retest", "*.npz")))]
+        jobs = [g.strings() for g in gs]
+        want = [np.where(g.ret == 1, g.end, 0xFFFFFFFF).astype(np.uint32) for g in gs]
+
+        def one_by_one():
+            outs = []
+            for g, j in zip(gs, jobs):
+                d = hip.HipDfa(g.flat)
+                outs.append(d.exec_strings(j)[0])
+                d.close()
+            return outs
+
+        def multi():
+            ds = [hip.HipDfa(g.flat, hip.DEFER_UPLOAD) for g in gs]
+            outs = [e for e, _ in hip.exec_multi(ds, jobs)]
+            for d in ds:
+                d.close()
+            return outs
+
+        ok = all(np.array_equal(e, w) for e, w in zip(multi(), want)) and all(np.array_equal(e, w) for e, w in zip(one_by_one(), want))
+        launches = hip.multi_last_launches()
+        t = {}
+        for name, fn in (("one_by_one", one_by_one), ("multi", multi)):
+            fn()
+            ts = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            t[name] = float(np.median(ts))
+        return {"dfas": len(gs), "lines": sum(len(j) for j in jobs), "launches": launches, "ms_per_call_multi": round(t["multi"], 3),
+                "ms_per_call_one_by_one": round(t["one_by_one"], 3), "speedup": round(t["one_by_one"] / t["multi"], 1),
+                "parity": "bit-exact" if ok else "MISMATCH",
+                "note": "wall time of a pass over all records, fsm_hip_dfa_create included (retest builds a DFA per record, src/retest/main.c:1056-1058); "
+                        "end states against the reference's frozen fsm_exec answers"}
+
     if "_" in a.workload:       # the packed-lines front alone
         wl, kind = a.workload.split("_")
-        r = run_lines(wl, kind)
+        r = run_eager40() if kind == "eager40" else run_lines(wl, kind)
+        r["config"].setdefault("lines", r["config"].get("inputs_per_gpu"))
+        r["config"].setdefault("mean_len", r["config"].get("input_len"))
         r.update(metric="input GB/s matched (whole node)", n_gpus=world, steps=a.steps, warmup=a.warmup, higher_is_better=True, scaling=a.scaling,
                  vs_baseline=None, dtype="u8", data="synthetic")
         r["config"]["inputs_per_gpu"] = r["config"]["lines"]
@@ -1011,7 +1151,18 @@ def main():
                 if not same:
                     r["value"] = None
             r["workload"] = wl + ("_" + variant if variant else "")
+            if r["config"].get("table_layout") in ("comb256", "lds", "lds2", "comb"):
+                lds_chain_ceiling(r)        # the lookup layouts' own denominator beside the HBM one
             subs.append(r)
+        try:
+            subs.append(run_eager40())
+            lds_chain_ceiling(subs[-1]) if subs[-1]["config"].get("table_layout") in ("comb256", "lds", "lds2", "comb") else None
+        except Exception as e:  # noqa: BLE001
+            subs.append({"workload": "c3_eager40", "value": None, "error": repr(e)[:300]})
+        try:
+            main_res["multi_dfa"] = run_multi_dfa()
+        except Exception as e:  # noqa: BLE001
+            main_res["multi_dfa"] = {"error": repr(e)[:300]}
         # leave the main workload's inputs in the buffer for the stream probe below
     if rank != 0:
         if world > 1:
@@ -1035,7 +1186,7 @@ def main():
                          measured_read_stream_GBps=None if stream_gbps is None else round(stream_gbps, 1),
                          frac_of_measured_stream=None if not stream_gbps else round(main_res["roofline"]["achieved"] / stream_gbps, 4)),
     }
-    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity", "multi_gpu"):
+    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity", "multi_gpu", "multi_dfa"):
         if k in main_res:
             res[k] = main_res[k]
     # N = 1 on a box that shows several GPUs: the C multi-device front on all of them, in a subprocess of its own

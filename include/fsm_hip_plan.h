@@ -102,6 +102,12 @@ double fsm_hip_stream_read_probe_ms(const void *d_base, size_t bytes, void *d_sc
  * FETCH_SIZE tallies per gather. */
 double fsm_hip_gather_probe_ms(const void *d_base, size_t bytes, size_t ngathers, int vec_bytes, void *d_scratch4, void *hip_stream);
 
+/* The LDS-chain ceiling of the lookup layouts (comb256 / lds / lds2: one random LDS read per input byte on the dependent
+ * chain): the same chain -- ds_read_b32, bit-field extract, add, compare, select -- on `waves` wavefronts per workgroup,
+ * `blocks_per_cu` workgroups per CU, beside a random table of table_bytes, the input bytes made in registers.  Returns GB/s
+ * of "bytes" walked by the whole device (every lane walks `steps`), -1 on error.  d_scratch4: 4 writable device bytes. */
+double fsm_hip_lds_chain_probe_gbps(size_t table_bytes, int waves, int blocks_per_cu, size_t steps, void *d_scratch4, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1026,6 +1026,17 @@ def gather_probe_ms(d_base: int, nbytes: int, ngathers: int, vec_bytes: int, d_s
     return float(ms)
 
 
+def lds_chain_probe_gbps(table_bytes: int, waves: int, blocks_per_cu: int, steps: int, d_scratch4: int, stream: int = 0) -> float:
+    """fsm_hip_lds_chain_probe_gbps: what a dependent chain of random LDS reads sustains (the lookup layouts' ceiling)."""
+    lib = load_library()
+    lib.fsm_hip_lds_chain_probe_gbps.restype = C.c_double
+    C.set_errno(0)
+    r = lib.fsm_hip_lds_chain_probe_gbps(C.c_size_t(table_bytes), C.c_int(waves), C.c_int(blocks_per_cu), C.c_size_t(steps), C.c_void_p(d_scratch4), C.c_void_p(stream or None))
+    if r < 0:
+        raise _oserr("fsm_hip_lds_chain_probe_gbps")
+    return float(r)
+
+
 def pack_affixes(items: Sequence[bytes]) -> np.ndarray:
     """[len<=7, b0..b6] entries for the affix generator."""
     t = np.zeros((len(items), 8), dtype=np.uint8)

@@ -1147,6 +1147,35 @@ extern "C" int fsm_hip_exec_batch_lengths(const struct fsm_hip_dfa *d,
 	return exec_host(d, base, total, 0, len, nullptr, n, end_out, accept_bitmap, nullptr, true);
 }
 
+extern "C" double fsm_hip_lds_chain_probe_gbps(size_t table_bytes, int waves, int blocks_per_cu, size_t steps, void *d_scratch4, void *hip_stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	float ms = -1.f;
+	double gbps = -1.0;
+	if (d_scratch4 == nullptr || table_bytes < 2048 || table_bytes > 160u * 1024u || waves < 1 || waves > 16 || blocks_per_cu < 1 || steps < 16) { errno = EINVAL; return -1.0; }
+	int dev = 0, ncu = 256;
+	(void)hipGetDevice(&dev);
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	const uint32_t words = (uint32_t)(table_bytes / 4u);
+	const unsigned grid = (unsigned)(ncu * blocks_per_cu);
+	HIP_TRY(hipFuncSetAttribute((const void *)lds_chain_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes));
+	for (int rep = 0; rep < 2; rep++) {   /* the second launch is the timed one */
+		if (e0 == nullptr) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
+		HIP_TRY(hipEventRecord(e0, s));
+		hipLaunchKernelGGL(lds_chain_probe_kernel, dim3(grid), dim3((unsigned)waves * 64u), table_bytes, s, words, (uint32_t)(steps / 16u * 16u), static_cast<uint32_t *>(d_scratch4));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e1, s));
+		HIP_TRY(hipEventSynchronize(e1));
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	}
+	gbps = (double)grid * waves * 64.0 * (double)(steps / 16u * 16u) / ((double)ms * 1e-3) / 1e9;
+fail:
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return gbps;
+}
+
 /* ------------------------------------------------------------------ */
 /* info / tuning / end-ids                                            */
 /* ------------------------------------------------------------------ */

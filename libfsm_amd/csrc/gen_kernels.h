@@ -222,6 +222,40 @@ gather_probe_kernel(const unsigned char *base, uint64_t nvec, uint64_t ngathers,
 	if (acc == 0x9E3779B9u) out[0] = acc;
 }
 
+/* The LDS-chain ceiling of the lookup layouts (Comb256Pol, LdsPol, Lds2Pol: one random LDS read per input byte on the
+ * dependent chain): the same chain -- ds_read_b32 at (state + byte), bit-field extract, add, compare, select -- on `waves`
+ * wavefronts per workgroup beside a table of `table_bytes`, with the "input bytes" made in registers (no global load at
+ * all).  Every lane walks `steps` bytes; table entries are uniformly random offsets into the table, so the reads conflict
+ * in the LDS banks as a real table's do.  bytes walked / time = what the LDS array and its latency allow these kernels. */
+__global__ void __launch_bounds__(1024)
+lds_chain_probe_kernel(uint32_t table_words, uint32_t steps, uint32_t *out)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	uint32_t *T = reinterpret_cast<uint32_t *>(lds);
+	const uint32_t span = table_words > 257u ? table_words - 257u : 1u;   /* states are < span: state + byte (+ 1) stays inside the table */
+	for (uint32_t i = threadIdx.x; i < table_words; i += blockDim.x) {
+		const uint32_t nx = (uint32_t)(mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + blockIdx.x) % span);
+		T[i] = (nx << 16) | ((i & 0xff00u));                    /* next << 16 | an "owner" tag in bits 15:8 */
+	}
+	__syncthreads();
+	uint32_t s = (threadIdx.x * 2654435761u) % span;
+	uint64_t x = mix64(((uint64_t)blockIdx.x << 32) | threadIdx.x);
+	for (uint32_t t = 0; t < steps; t += 16u) {
+		x = x * 6364136223846793005ull + 1442695040888963407ull;   /* 16 "input bytes" in registers: one multiply-add per chunk */
+		uint64_t bytes = x;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t b = (uint32_t)(bytes >> ((k & 7) * 8)) & 0xffu;
+			const uint32_t e = T[s + b];                               /* the dependent random LDS read */
+			const uint32_t owner = __builtin_amdgcn_ubfe(e, 8u, 8u);
+			const uint32_t nx = e >> 16;
+			s = owner == ((s + b) >> 8 & 0xffu) ? nx : nx + 1u;    /* compare + select, as the comb lookup's "is this entry mine" */
+			if (k == 7) bytes = x >> 3 | x << 61;
+		}
+	}
+	if (s == steps) out[0] = s;    /* (a run-time value: the compiler cannot prove the walk dead) */
+}
+
 } // namespace fsmhip
 
 #endif

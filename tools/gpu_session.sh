@@ -49,7 +49,7 @@ for step in "$@"; do
 	            tail -2 gpurun_out/${TAG}_prof_$wl.log
 	            rm -rf gpurun_out/${TAG}_prof_$wl/*/*.db gpurun_out/${TAG}_prof_$wl/*/*/*.db 2>/dev/null
 	        done ;;
-	profn)  for wl in ${PROF_WLS:-c3 c3t c2 c5 c3_short c2_short}; do
+	profn)  for wl in ${PROF_WLS:-c3 c3t c2 c5 c3_short c2_short c3_ragged c2_ragged c5_short c5_ragged c3_eager40}; do
 	            L2=""; [ $wl = c5 ] && L2="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"
 	            FSM_BENCH_LINES_FORMS=off64 L2_PMC="$L2" timeout 600 bash tools/profile.sh $wl $PWD/gpurun_out/${TAG}_prof_$wl > gpurun_out/${TAG}_prof_$wl.log 2>&1
 	            python tools/rocpd_summary.py gpurun_out/${TAG}_prof_$wl $wl gpurun_out/${TAG}_$wl >> gpurun_out/${TAG}_prof_$wl.log 2>&1

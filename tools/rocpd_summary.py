@@ -23,7 +23,7 @@ def rows(db, sql, params=()):
     return [dict(zip(cols, r)) for r in cur.fetchall()]
 
 
-def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib):
+def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib, req=None):
     """The packed-lines front (bench.py --workload c3_short ...): algorithmic bytes = sum(len) + 8 B offsets + 4 B result per line.
     The lines are read by per-lane 16-byte buffer loads at 36-byte (short) or 512-byte (ragged) mean pitch, not by the
     16-byte-per-lane coalesced stream the x2 correction of FETCH_SIZE was calibrated on: the raw counter is taken at face value
@@ -46,15 +46,20 @@ def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib):
         calib = {"c2": 1.067, "c3": 1.135}.get(w_)
         if calib is not None:
             read = raw * calib
+    fetch_derived = read + write_kib * 1024
+    if req is not None:
+        # round 5: the read side from the request-size counters of the same launches -- derived without assuming that the kernel
+        # fetches exactly its algorithmic bytes (the round-4 calibration factor did: it is kept for comparison only)
+        read = req["read_bytes_by_request_size"]
     hbm = read + write_kib * 1024
     summary = {
-        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline (FSM_BENCH_LINES_FORMS=off64; then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
+        "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline (FSM_BENCH_LINES_FORMS=off64; then --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_EA0_RDREQ_{{32B,64B,128B}} in separate passes)",
         "bench_line_under_trace": bench,
         "kernel_stats_top": [{"name": t["name"][:120], "calls": t["total_calls"], "avg_us": round(t["average"], 1), "pct": round(t["percentage"], 2)} for t in top[:5]],
         "walk_kernel": {"name": walk["name"], "calls": walk["total_calls"], "avg_ms": round(walk["average"] / 1e3, 4),
                         "algorithmic_GBps": round(alg / (walk["average"] * 1e-6) / 1e9, 1)},
         "pmc": {"FETCH_SIZE_KiB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": pmc["WRITE_SIZE"], "fetch_bytes_raw": raw, "fetch_bytes_doubled": 2 * raw,
-                "read_bytes_taken": read, "fetch_calibration_factor": calib, "bytes_that_must_be_read": must_read, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+                "read_bytes_taken": read, "read_requests_by_size": req, "hbm_bytes_from_FETCH_SIZE_with_round4_factor": fetch_derived, "fetch_calibration_factor": calib, "bytes_that_must_be_read": must_read, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
                 "traffic_over_algorithmic": round(hbm / alg, 4)},
     }
     json.dump(summary, open(out + "_rocprof_summary.json", "w"), indent=1)
@@ -67,7 +72,9 @@ def lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib):
 
 def main():
     prof, wl, out = sys.argv[1:4]
-    bench = json.loads(open(os.path.join(prof, "bench_trace.json")).read().strip().splitlines()[-1])
+    # the full record of the traced run (bench.py prints a compact line on stdout and writes the whole thing next to it)
+    detail = os.path.join(prof, "bench_detail_trace.json")
+    bench = json.load(open(detail)) if os.path.exists(detail) else json.loads(open(os.path.join(prof, "bench_trace.json")).read().strip().splitlines()[-1])
     top = rows(glob.glob(os.path.join(prof, "trace", "*.db"))[0], "select name, total_calls, total_duration, average, percentage from top_kernels")
     walk = sorted([t for t in top if "walk_" in t["name"]], key=lambda t: -t["total_duration"])[0]   # (the device-side choice launches two: the one that ran)
     pmc = {}
@@ -77,11 +84,32 @@ def main():
         if not r:
             r = rows(db, f"select name, counter_name, counter_value, duration from pmc_events where counter_name = '{ctr}' and name like '%walk_%'")
         pmc[ctr] = [x["counter_value"] for x in r]
+    # the fabric read requests by size (profile.sh pass 4): bytes = 32 a + 64 b + 128 c -- no assumption about the access pattern
+    req = None
+    rdb = glob.glob(os.path.join(prof, "req", "*.db"))
+    if rdb:
+        r = rows(rdb[0], "select counter_name, counter_value from pmc_events where name = ?", (walk["name"],))
+        if not r:
+            r = rows(rdb[0], "select counter_name, counter_value from pmc_events where name like '%walk_%'")
+        acc = {}
+        for x in r:
+            acc.setdefault(x["counter_name"].replace("_sum", ""), []).append(x["counter_value"])
+        if acc:
+            m = {k: sum(v) / len(v) for k, v in acc.items()}
+            a32, a64, a128, tot = m.get("TCC_EA0_RDREQ_32B", 0.0), m.get("TCC_EA0_RDREQ_64B", 0.0), m.get("TCC_EA0_RDREQ_128B", 0.0), m.get("TCC_EA0_RDREQ", 0.0)
+            req = {"RDREQ_32B": a32, "RDREQ_64B": a64, "RDREQ_128B": a128, "RDREQ": tot,
+                   "read_bytes_by_request_size": 32.0 * a32 + 64.0 * a64 + 128.0 * a128,
+                   "note": "TCC_EA0_RDREQ_{32B,64B,128B}: the L2's fabric read requests by size, per walk launch; bytes = 32 a + 64 b + 128 c "
+                           "(if the three do not add up to RDREQ, the remainder is counted as 64-byte requests)"}
+            rest = tot - (a32 + a64 + a128)
+            if rest > 0.005 * max(tot, 1.0):
+                req["read_bytes_by_request_size"] += 64.0 * rest
+                req["unclassified_requests"] = rest
     n, L = bench["config"]["inputs_per_gpu"], bench["config"]["input_len"]
     fetch_kib = sum(pmc["FETCH_SIZE"]) / len(pmc["FETCH_SIZE"])
     write_kib = sum(pmc["WRITE_SIZE"]) / len(pmc["WRITE_SIZE"])
-    if "lines" in bench["config"]:
-        return lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib)
+    if "lines" in bench["config"] and "_" in wl and not wl.endswith("eager40"):
+        return lines_summary(prof, wl, out, bench, top, walk, pmc, fetch_kib, write_kib, req)
     # Read side.  gfx950 tallies a 128-byte request of a 16-byte-per-lane coalesced stream as 64 bytes
     # (MI355X_MICROARCH.md section HBM): the streamed input, n * L bytes, shows up as n * L / 2.  A gather that
     # misses is ONE 64-byte request tallied as 64 bytes (tools/fetch_calib.py, profiles/r02e_fetch_calib.json:
@@ -90,7 +118,10 @@ def main():
     raw = fetch_kib * 1024
     stream_raw = min(raw, n * L / 2)
     hbm = stream_raw * 2 + (raw - stream_raw) + write_kib * 1024
-    alg = n * (L + 4)
+    alg = bench["roofline"].get("algorithmic_bytes_per_launch") or n * (L + 4)
+    fetch_derived = hbm
+    if req is not None:
+        hbm = req["read_bytes_by_request_size"] + write_kib * 1024
     summary = {
         "command": f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 5 --warmup 2 --no-cpu-baseline --subs none  (then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes)",
         "bench_line_under_trace": bench,
@@ -99,6 +130,7 @@ def main():
                         "algorithmic_GBps": round(alg / (walk["average"] * 1e-6) / 1e9, 1)},
         "pmc": {"FETCH_SIZE_KiB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": pmc["WRITE_SIZE"],
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
+                "read_requests_by_size": req, "hbm_bytes_from_FETCH_SIZE_x2_rule": fetch_derived,
                 "note": "read side = 2 x the input stream's share of FETCH_SIZE (gfx950 tallies 128-B requests of 16-B/lane streams as 64 B) + the rest of FETCH_SIZE at face value (gather misses are 64-B requests tallied as 64 B: profiles/r02e_fetch_calib.json); write side as reported"},
     }
     l2db = glob.glob(os.path.join(prof, "l2", "*.db"))
