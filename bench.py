@@ -441,6 +441,7 @@ def _short_kernel(name, width=72):
     if not name:
         return name
     name = str(name).replace("fsmhip::", "").replace(" (mean length < 96 B, decided on the device)", "")
+    name = name.replace(" (mean length below the pick threshold, decided on the device)", " (picked on device)").replace(" (decided on the device)", " (picked on device)")
     return name if len(name) <= width else name[:width - 1] + "~"
 
 

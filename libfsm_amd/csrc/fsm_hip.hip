@@ -85,7 +85,9 @@ struct fsm_hip_dfa {
 	uint32_t table_lds = 0;      /* LDS bytes of the policy's tables */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
-	std::string last_kernel;     /* demangled name(s) of the walk kernel(s) of the last launch */
+	std::string last_kernel;     /* demangled name of the walk kernel of the last launch */
+	std::string last_kernel_short, last_kernel_long;   /* a device-side pick launched both: which one RAN is read from the flag on demand */
+	const uint32_t *last_pick_flag = nullptr;
 	/* tuning knobs (fsm_hip_dfa_tune) */
 	int knob_input_mode = -1;    /* -1 auto */
 	int knob_nb = 0;             /* 0 auto */
@@ -747,7 +749,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 			ag.skip_flag = a.pick_flag;
 			ag.skip_when = 0u;
 			e = launch_layout(d, eager, g, ag, dim3((unsigned)(gb0 < gcap ? gb0 : gcap)), dim3((unsigned)g.waves * 64u), s);
-			if (e == hipSuccess) picked = kernel_name(g.kfn, s) + " (mean length < " + std::to_string(d->knob_pick_mean) + " B, decided on the device) | ";
+			if (e == hipSuccess) picked = kernel_name(g.kfn, s);
 			a.skip_flag = a.pick_flag;
 			a.skip_when = 1u;   /* long: walk_ragged, below */
 		}
@@ -755,7 +757,16 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (e == hipSuccess) {
 		c.kfn = nullptr;
 		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
-		if (e == hipSuccess) md->last_kernel = picked + kernel_name(c.kfn, s);
+		if (e == hipSuccess) {
+			md->last_kernel = kernel_name(c.kfn, s);
+			md->last_pick_flag = nullptr;
+			if (pick) {   /* both were launched, one returned at once: fsm_hip_last_kernel_name() asks the flag which */
+				md->last_kernel_short = picked;
+				md->last_kernel_long = md->last_kernel;
+				md->last_pick_flag = a.pick_flag;
+				md->last_kernel = picked + " | " + md->last_kernel;
+			}
+		}
 		debug_stage(s, "walk");
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
@@ -946,7 +957,20 @@ extern "C" int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *d,
 extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return "";
-	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
+	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
+	DfaLock lk(md->mu);
+	if (md->last_pick_flag != nullptr) {
+		/* a device-pointer variable-length call: the choice between the two kernels was made on the device (offsets_pick): read it
+		 * back (a 4-byte copy; waits for the launch) and name the kernel that walked the batch, as rocprofv3 would show it busy */
+		uint32_t flag = 2;
+		DevGuard dg(d->device);
+		if (dg.ok() && md->timed && hipEventSynchronize(md->ev1) == hipSuccess &&
+		    hipMemcpy(&flag, md->last_pick_flag, sizeof flag, hipMemcpyDeviceToHost) == hipSuccess && flag <= 1u) {
+			md->last_kernel = flag == 1u ? md->last_kernel_short : md->last_kernel_long;
+			md->last_kernel += flag == 1u ? " (mean length below the pick threshold, decided on the device)" : " (decided on the device)";
+		}
+		md->last_pick_flag = nullptr;
+	}
 	return d->last_kernel.c_str();
 }
 

@@ -569,3 +569,22 @@ def test_resume_over_the_compact_forms(hip, table):
     assert np.array_equal(d_end.cpu().numpy().view(np.uint32), want)
     assert np.array_equal(_bits(d_bm.cpu().numpy(), n), want != NO)
     dfa.close()
+
+
+def test_last_kernel_name_after_a_device_side_pick(hip):
+    """A device-pointer variable-length call cannot know its mean line length: both walk_generic and walk_ragged are launched and
+    a small kernel decides on the device which one returns at once.  fsm_hip_last_kernel_name() reads that decision back and
+    names the ONE kernel that walked the batch (round 4 answered with both names)."""
+    import torch
+    g_ = Golden(os.path.join(GOLDEN, "c1.npz"))
+    dfa = hip.HipDfa(g_.flat)
+    rng = np.random.RandomState(4)
+    for lo, hi, expect in ((4, 40, "walk_generic"), (300, 900, "walk_ragged")):
+        strs = [bytes(rng.randint(97, 123, rng.randint(lo, hi)).astype(np.uint8)) for _ in range(5000)]
+        base, off = _pack(strs)
+        tb, to = torch.from_numpy(base).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        te = torch.zeros(len(strs), dtype=torch.int32, device="cuda")
+        dfa.exec_batch_offsets_device(tb.data_ptr(), to.data_ptr(), len(strs), te.data_ptr(), 0)
+        name = dfa.last_kernel_name()
+        assert expect in name and " | " not in name and "on the device" in name, name
+    dfa.close()

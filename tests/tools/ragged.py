@@ -42,7 +42,7 @@ def main():
             for r0 in range(0, n, 1 << 20):                                     # masked selects of <= 1 GiB at a time
                 r1 = min(n, r0 + (1 << 20))
                 packed[int(off[r0]):int(off[r1])] = buf[r0:r1][ar < lens[r0:r1, None]]
-            dfa = hip.HipDfa(flat)
+            dfa = hip.HipDfa(flat, int(os.environ.get("RAGGED_LAYOUT", "0")))
             idx = np.random.RandomState(0).randint(0, n, 1024)
             rows = buf[torch.from_numpy(idx).cuda()].cpu().numpy()
             want = Oracle(flat).table_walk(rows, lens.cpu().numpy().astype(np.uint32)[idx])
