@@ -104,6 +104,10 @@ struct fsm_hip_dfa {
 	bool sparse_fast_ok = true;  /* the record array sits inside one 4 GiB window (SparseFastPol::enter) */
 	int knob_pick_mean = 96;     /* variable-length batches whose mean input length is below this many bytes go to walk_generic */
 	unsigned flags = 0;
+	/* The pair table (lds2) wins on fixed-stride rows but leaves no LDS for the ragged kernel's tiles: a dfa planned that way keeps a
+	 * SECOND automaton image (lds / combself / ...) for its variable-length, unaligned and resumed batches */
+	fsm_hip_dfa *alt = nullptr;
+	const fsm_hip_dfa *last_used = nullptr;   /* which of the two the last launch went to (timing / kernel name) */
 	bool uploaded = false;       /* the layout's tables are on the device (FSM_HIP_DEFER_UPLOAD: not before the first single-dfa call) */
 };
 
@@ -155,6 +159,14 @@ struct DevGuard {
 };
 
 typedef std::lock_guard<std::recursive_mutex> DfaLock;
+
+/* the automaton image a batch goes to: the second one (fsm_hip_dfa::alt) for everything the fixed-stride kernels do not take */
+static const fsm_hip_dfa *route(const fsm_hip_dfa *d, bool fixed_stride_fast)
+{
+	const fsm_hip_dfa *t = d->alt != nullptr && !fixed_stride_fast ? d->alt : d;
+	const_cast<fsm_hip_dfa *>(d)->last_used = t;
+	return t;
+}
 
 extern "C" int fsm_hip_version(void) { return 210; }
 
@@ -489,6 +501,14 @@ extern "C" struct fsm_hip_dfa *fsm_hip_dfa_create(const struct fsm_hip_dfa_desc 
 		if (r != 0) { errno = r; goto fail; }
 	}
 	if (!(flags & FSM_HIP_DEFER_UPLOAD) && dfa_upload(d) != 0) goto fail;
+	if (d->plan.layout == FSM_HIP_LAYOUT_LDS2 && (flags & FSM_HIP_LAYOUT_MASK) == FSM_HIP_LAYOUT_AUTO && !(flags & FSM_HIP_PLAN_NO_LDS2)) {
+		/* fewer than eight ragged wavefronts fit beside the pair table: the variable-length fronts get a table of their own */
+		const uint32_t pair_lds = Lds2Pol::lds_bytes((uint32_t)(d->plan.lds_tab.size() * 2));
+		if (pair_lds + 8u * FSMHIP_RAGGED_WAVE_LDS > d->lds_limit) {
+			d->alt = fsm_hip_dfa_create(desc, flags | FSM_HIP_PLAN_NO_LDS2);
+			if (d->alt == nullptr) goto fail;
+		}
+	}
 	return d;
 fail:
 	{
@@ -502,6 +522,7 @@ fail:
 extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return;
+	if (d->alt) fsm_hip_dfa_free(d->alt);
 	if (d->d_tab) (void)hipFree(d->d_tab);
 	if (d->d_fin) (void)hipFree(d->d_fin);
 	if (d->d_btab) (void)hipFree(d->d_btab);
@@ -814,6 +835,7 @@ extern "C" int fsm_hip_reserve(struct fsm_hip_dfa *d, size_t n)
 	if (ensure_uploaded(d) != 0) return -1;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
+	if (d->alt != nullptr && fsm_hip_reserve(d->alt, n) != 0) return -1;   /* the variable-length fronts run on the second image */
 	DfaLock lk(d->mu);
 	const hipError_t e = tb_grow(d, tb_bytes_for(n));
 	if (e != hipSuccess) { errno = hip_errno(e); return -1; }
@@ -867,6 +889,10 @@ static int exec_stride_device(const struct fsm_hip_dfa *d,
 	uint32_t *d_end_out, uint64_t *d_accept_bitmap, void *hip_stream, const BatchHint &hint)
 {
 	if (d == nullptr || (n != 0 && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	{
+		const fsm_hip_dfa *t = route(d, d_len == nullptr && stride != 0 && stride % 16u == 0 && (reinterpret_cast<uintptr_t>(d_base) % 16u) == 0);
+		if (t != d) return exec_stride_device(t, d_base, stride, d_len, n, d_end_out, d_accept_bitmap, hip_stream, hint);
+	}
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	if (ensure_uploaded(d) != 0) return -1;
@@ -897,6 +923,10 @@ static int exec_packed_device(const struct fsm_hip_dfa *d,
 {
 	if (d == nullptr || (n != 0 && d_off == nullptr && d_off32 == nullptr && d_len == nullptr)) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
+	{
+		const fsm_hip_dfa *t = route(d, false);
+		if (t != d) return exec_packed_device(t, d_base, d_off, d_off32, d_len, n, d_end_out, d_accept_bitmap, hip_stream, hint);
+	}
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -957,6 +987,7 @@ extern "C" int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *d,
 extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return "";
+	if (d->last_used != nullptr && d->last_used != d) return fsm_hip_last_kernel_name(d->last_used);   /* the launch went to the second image */
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);
 	if (md->last_pick_flag != nullptr) {
@@ -977,6 +1008,7 @@ extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return -1.0;
+	if (d->last_used != nullptr && d->last_used != d) return fsm_hip_last_kernel_ms(d->last_used);
 	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
 	if (!d->timed) return -1.0;
 	float ms = 0.f;
@@ -1236,6 +1268,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 {
 	if (d == nullptr) { errno = EINVAL; return -1; }
 	if (ensure_uploaded(d) != 0) return -1;
+	if (d->alt != nullptr) (void)fsm_hip_dfa_tune(d->alt, knob, value);   /* the knobs of the variable-length kernels live there */
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
@@ -1682,6 +1715,10 @@ static int ids_device(fsm_hip_dfa *d, const void *d_base, size_t stride, const u
 {
 	if (d == nullptr || d_id_out == nullptr || (mode != FSM_HIP_IDS_EARLIEST && mode != FSM_HIP_IDS_RET && mode != FSM_HIP_IDS_ERROR) ||
 	    (n != 0 && d_off == nullptr && d_base == nullptr && stride != 0)) { errno = EINVAL; return -1; }
+	{
+		const fsm_hip_dfa *t = route(d, d_off == nullptr && d_len == nullptr && stride != 0 && stride % 16u == 0 && (reinterpret_cast<uintptr_t>(d_base) % 16u) == 0);
+		if (t != d) return ids_device(const_cast<fsm_hip_dfa *>(t), d_base, stride, d_len, d_off, n, mode, d_id_out, hip_stream, hint);
+	}
 	if (ensure_ids(d) != 0) return -1;
 	if (mode == FSM_HIP_IDS_ERROR) {
 		/* AMBIG_ERROR: an end state with more than one id is refused (print/c.c:67-72 fails the
@@ -1858,6 +1895,10 @@ static int resume_device(fsm_hip_dfa *d, const void *d_base, size_t stride, cons
 	if (d == nullptr || d_state_io == nullptr || (n != 0 && d_off == nullptr && d_off32 == nullptr && !lens_only && d_base == nullptr && stride != 0) ||
 	    (lens_only && n != 0 && d_len == nullptr)) { errno = EINVAL; return -1; }
 	if (n == 0) return 0;
+	{
+		const fsm_hip_dfa *t = route(d, false);     /* (a resumed walk never takes the fixed-stride kernels of the pair table) */
+		if (t != d) return resume_device(const_cast<fsm_hip_dfa *>(t), d_base, stride, d_len, d_off, n, d_state_io, d_end_out, d_accept_bitmap, hip_stream, hint, d_off32, lens_only);
+	}
 	if (ensure_resume(d) != 0) return -1;
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
@@ -2078,6 +2119,10 @@ static int all_device(const struct fsm_hip_dfa *dc,
 	const bool packed = d_off != nullptr || d_off32 != nullptr || lens_only;
 	if (d == nullptr || (n != 0 && !packed && d_base == nullptr && stride != 0) || (d_off != nullptr && d_len != nullptr) ||
 	    (lens_only && n != 0 && d_len == nullptr)) { errno = EINVAL; return -1; }
+	{
+		const fsm_hip_dfa *t = route(d, !packed && d_len == nullptr && stride != 0 && stride % 16u == 0 && (reinterpret_cast<uintptr_t>(d_base) % 16u) == 0);
+		if (t != d) return all_device(t, d_base, stride, d_len, d_off, d_off32, lens_only, n, d_end_out, d_accept_bitmap, ids_mode, d_id_out, d_eager_out, hip_stream, hint);
+	}
 	if (d_id_out != nullptr) {
 		if (ids_mode != FSM_HIP_IDS_EARLIEST && ids_mode != FSM_HIP_IDS_RET && ids_mode != FSM_HIP_IDS_ERROR) { errno = EINVAL; return -1; }
 		if (ensure_ids(d) != 0) return -1;

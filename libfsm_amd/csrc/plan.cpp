@@ -396,7 +396,7 @@ try {
 		/* one lookup per two bytes where the pair table fits: ahead of every one-lookup-per-byte layout, the self-loop
 		 * ones included -- those walk self-loop runs at 6 TB/s but a transition-dense input at 1.2 (profiles/
 		 * r06f_lds2_probe.txt: 107 states, 21 classes), the pair table 4.6-4.75 whatever the input */
-		if (emit_lds2() == 0) return 0;
+		if (!(flags & FSM_HIP_PLAN_NO_LDS2) && emit_lds2() == 0) return 0;
 		/* many states sit in self-loops ([0-9]+, .*): bytes that do not change the state then
 		 * cost one conflict-free lookup (CombSelfPol) */
 		if (p.selfloop_fraction >= 0.15 && emit_combself() == 0) return 0;

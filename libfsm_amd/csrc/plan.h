@@ -100,6 +100,9 @@ struct Plan {
 
 /* Returns 0 or an errno value (EINVAL, ENOMEM, ENOTSUP for a forced layout
  * that cannot hold this DFA).  lds_limit = usable LDS bytes per workgroup. */
+/* internal flag (above the public ones of fsm_hip.h): AUTO skips the pair table -- the second plan a dfa keeps for its variable-length fronts */
+#define FSM_HIP_PLAN_NO_LDS2 0x4000u
+
 int build_plan(const fsm_hip_dfa_desc *desc, unsigned flags, uint32_t lds_limit, Plan &out);
 
 /* LDS bytes needed by each layout's kernel for `waves` wavefronts per block

@@ -588,3 +588,66 @@ def test_last_kernel_name_after_a_device_side_pick(hip):
         name = dfa.last_kernel_name()
         assert expect in name and " | " not in name and "on the device" in name, name
     dfa.close()
+
+
+def test_pair_table_dfa_keeps_a_second_image_for_variable_length_batches(hip):
+    """AUTO plans a mid-size dense DFA as the pair table (lds2: one LDS lookup per two bytes, the fastest fixed-stride walk) --
+    which leaves no LDS for the ragged kernel's tiles.  Such a dfa now keeps a SECOND image (lds / combself ...) for its
+    variable-length, unaligned and resumed batches: fixed-stride rows still run Lds2Pol, packed lines run walk_ragged on the
+    other table, ids and resume agree with the oracle on both.  (Round 4's review: every packed batch fell to walk_generic.)"""
+    import time
+    import torch
+    from oracle.pyoracle import Oracle
+    alpha_b = b"abcdefghijkl"
+    rng = np.random.RandomState(len(alpha_b) * 131 + 70)
+    al = np.frombuffer(alpha_b, np.uint8)
+    words = sorted(set(bytes(al[rng.randint(0, len(al), rng.randint(3, 8))]) for _ in range(70)))
+    flat = hip.FlatDfa.from_strings(words, 0, list(range(len(words))))
+    orc = Oracle(flat)
+    dfa = hip.HipDfa(flat)
+    assert dfa.info()["layout_name"] == "lds2", dfa.info()
+    n, L = 200_000, 256
+    rows = al[rng.randint(0, len(al), (n, L))]
+    for i in range(0, n, 4):
+        w = words[rng.randint(len(words))]
+        rows[i, L - len(w):] = np.frombuffer(w, np.uint8)
+    want_rows = orc.table_walk(rows)
+    end, _ = dfa.exec_batch(rows)
+    assert np.array_equal(end, want_rows) and "Lds2Pol" in dfa.last_kernel_name(), dfa.last_kernel_name()
+    lens = rng.randint(0, L + 1, n).astype(np.uint32)
+    want = orc.table_walk(rows, lens)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    packed = rows[np.arange(L)[None, :] < lens[:, None]]
+    end, bm = dfa.exec_batch_offsets(packed, off)
+    assert np.array_equal(end, want) and np.array_equal(_bits(bm, n), want != NO)
+    name = dfa.last_kernel_name()
+    assert "walk_ragged" in name and "Lds2Pol" not in name, name
+    end, _ = dfa.exec_batch(rows, lens)                                  # stride + lengths: the same
+    assert np.array_equal(end, want) and "Lds2Pol" not in dfa.last_kernel_name()
+    ids = dfa.exec_offsets_ids(packed, off, 1)
+    eo, ei = np.asarray(flat.endid_off), np.asarray(flat.endids)
+    first = np.array([ei[eo[q]] if eo[q + 1] > eo[q] else NO for q in range(flat.nstates)] + [NO], np.uint32)
+    assert np.array_equal(ids, first[np.where(want != NO, want, flat.nstates)])
+    cut = (lens // 2).astype(np.uint32)
+    o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum(cut)
+    o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum(lens - cut)
+    p1 = rows[np.arange(L)[None, :] < cut[:, None]]
+    p2 = rows[(np.arange(L)[None, :] >= cut[:, None]) & (np.arange(L)[None, :] < lens[:, None])]
+    st, _ = dfa.exec_offsets_resume(p1, o1, np.full(n, hip.STATE_START, np.uint32))
+    st, end = dfa.exec_offsets_resume(p2, o2, st)
+    assert np.array_equal(end, want)
+    # what the second image buys, on the device-resident packed lines (printed, not asserted)
+    tb, to = torch.from_numpy(packed).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    te = torch.zeros(n, dtype=torch.int32, device="cuda")
+    forced = hip.HipDfa(flat, hip.LAYOUT_LDS2)                            # the pair table alone: no second image
+    for d, label in ((dfa, "auto (second image)"), (forced, "pair table only")):
+        ms = []
+        for _ in range(5):
+            d.exec_batch_offsets_device(tb.data_ptr(), to.data_ptr(), n, te.data_ptr(), 0)
+            ms.append(d.last_kernel_ms())
+        torch.cuda.synchronize()
+        assert np.array_equal(te.cpu().numpy().view(np.uint32), want)
+        print(f"packed 0-256 B lines, {label}: {min(ms[1:]):.3f} ms  {len(packed) / min(ms[1:]) / 1e6:.0f} GB/s  {d.last_kernel_name()}")
+    forced.close()
+    dfa.close()
