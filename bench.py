@@ -555,6 +555,16 @@ WORKLOAD_TEXT = {
 }
 
 
+T_START = time.perf_counter()
+
+
+def over_budget():
+    """The full-N checks of the SUB-results are the long part of a default run (host-side: every byte streamed back and walked by the
+    CPU checker).  On a slow or throttled host they stop once the run is FSM_BENCH_TIME_BUDGET seconds old (default 420): the sample
+    parity of every sub-result still runs, the main workload's full check always does, and the record says what was skipped."""
+    return time.perf_counter() - T_START > float(os.environ.get("FSM_BENCH_TIME_BUDGET", "420"))
+
+
 def main():
     a = parse()
     if a.node_front:
@@ -801,7 +811,10 @@ def main():
         # the full-N compare, for the main workload of a default run -- and for c5 wherever it runs (round 4: its
         # table is 1 GB as the oracle keeps it and the cpu_baseline leg has built it already; 1e7 rows take the walker's threads
         # about a minute)
-        if world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5"):
+        if world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5") \
+                and wl != a.workload and over_budget():
+            res["full_parity_skipped"] = "time budget (FSM_BENCH_TIME_BUDGET) reached: sample parity only"
+        elif world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5"):
             res["full_parity"] = full_parity(torch, flat, buf, end, n_, L)
             if res["full_parity"]["mismatches"]:
                 res["value"] = None
@@ -960,7 +973,9 @@ def main():
                 res["value"] = None
             # ... and EVERY line: the packed buffer streams back in slices of whole lines (<= 2 GiB each) and the oracle walks
             # them on all granted host cores
-            if not a.no_full_parity:
+            if not a.no_full_parity and over_budget():
+                res["full_parity_skipped"] = "time budget (FSM_BENCH_TIME_BUDGET) reached: sample parity only"
+            elif not a.no_full_parity:
                 ncores, _ = host_cores()
                 offh = off.cpu().numpy().astype(np.uint64)
                 bad, t0, t_cpu, r0 = 0, time.perf_counter(), 0.0, 0
