@@ -143,6 +143,89 @@ main(void)
 		assert(fsm_hip_exec_batch_packed_all(dfa, buf, 7, len, NI, ea, NULL, 0, NULL, NULL) == -1 && errno == EINVAL);
 	}
 
+	/* round 5: retest's shape -- a DFA per record and a few lines through each (src/retest/main.c:1056-1058, :1114) -- as ONE
+	 * submission: every pattern its own automaton (no table upload of its own: FSM_HIP_DEFER_UPLOAD), every automaton all the
+	 * lines, one fsm_hip_exec_multi; each answer against fsm_exec on that pattern's own fsm.  Then the same split over a node's
+	 * devices by DFA, resume over the compact metadata forms, and the allocation-free promise of fsm_hip_reserve. */
+	{
+		struct fsm *pf[NP];
+		struct fsm_hip_dfa *pd[NP];
+		const struct fsm_hip_dfa *cpd[NP];
+		struct fsm_hip_node *pn[NP];
+		struct fsm_hip_multi_batch mb[NP];
+		static uint32_t mend[NP][NI];
+		static uint64_t mbm[NP][(NI + 63) / 64];
+		static const int devs2[2] = { 0, 0 };
+		uint64_t cost[4] = { 10, 1000, 10, 500 };
+		int dev_of[4];
+		size_t q;
+
+		for (q = 0; q < NP; q++) {
+			pf[q] = compile(patterns[q], (fsm_end_id_t) q);
+			pd[q] = fsm_hip_compile(pf[q], FSM_HIP_DEFER_UPLOAD);
+			assert(pd[q] != NULL);
+			cpd[q] = pd[q];
+			mb[q].base = buf;
+			mb[q].off = off;
+			mb[q].n = NI;
+			mb[q].end_out = mend[q];
+			mb[q].accept_bitmap = mbm[q];
+		}
+		assert(fsm_hip_exec_multi(cpd, mb, NP) == 0);
+		assert(fsm_hip_multi_last_launches() == 1 && fsm_hip_multi_last_fused_jobs() == NP);
+		for (q = 0; q < NP; q++) {
+			for (i = 0; i < NI; i++) {
+				const char *sq = inputs[i];
+				fsm_state_t e = 0;
+				int r = fsm_exec(pf[q], fsm_sgetc, &sq, &e, NULL);
+				assert((mend[q][i] != FSM_HIP_NO_MATCH) == (r == 1));
+				assert(r != 1 || mend[q][i] == e);
+				assert(((mbm[q][i / 64] >> (i % 64)) & 1) == (uint64_t) (r == 1));
+			}
+		}
+		/* sharded by DFA over two replicas per automaton */
+		for (q = 0; q < NP; q++) {
+			pn[q] = fsm_hip_node_compile(pf[q], FSM_HIP_DEFER_UPLOAD, devs2, 2);
+			assert(pn[q] != NULL);
+			memset(mend[q], 0x55, sizeof mend[q]);
+		}
+		{
+			uint32_t keep[NP][NI];
+			assert(fsm_hip_exec_multi(cpd, mb, NP) == 0);
+			memcpy(keep, mend, sizeof keep);
+			for (q = 0; q < NP; q++) memset(mend[q], 0x55, sizeof mend[q]);
+			assert(fsm_hip_node_exec_multi(pn, mb, NP) == 0);
+			assert(memcmp(keep, mend, sizeof keep) == 0);
+		}
+		assert(fsm_hip_multi_assign(cost, 4, 2, dev_of) == 0);
+		assert(dev_of[1] == 0 && dev_of[3] == 1 && dev_of[0] == 1 && dev_of[2] == 1);   /* largest first, least loaded device, ties low */
+		/* resume over the compact forms: every line in two pieces (its first byte, the rest), u32 offsets then lengths alone */
+		{
+			uint32_t o32[NI + 1], l2[NI], st[NI], e2[NI];
+			unsigned char b1[NI + 1], b2[1024];
+			size_t t2 = 0;
+			o32[0] = 0;
+			for (i = 0; i < NI; i++) {
+				const size_t len = strlen(inputs[i]);
+				b1[o32[i]] = len ? (unsigned char) inputs[i][0] : 0;
+				o32[i + 1] = o32[i] + (len ? 1 : 0);
+				l2[i] = len ? (uint32_t) (len - 1) : 0;
+				memcpy(b2 + t2, inputs[i] + (len ? 1 : 0), l2[i]);
+				t2 += l2[i];
+				st[i] = FSM_HIP_STATE_START;
+			}
+			assert(fsm_hip_reserve(dfa, NI) == 0);
+			assert(fsm_hip_exec_batch_resume_packed(dfa, b1, FSM_HIP_META_OFF32, o32, NI, st, NULL) == 0);
+			assert(fsm_hip_exec_batch_resume_packed(dfa, b2, FSM_HIP_META_LENGTHS, l2, NI, st, e2) == 0);
+			assert(memcmp(end, e2, sizeof end) == 0);
+		}
+		for (q = 0; q < NP; q++) {
+			fsm_hip_node_free(pn[q]);
+			fsm_hip_dfa_free(pd[q]);
+			fsm_free(pf[q]);
+		}
+	}
+
 	/* the node front: one replica per listed device (this rig lists its one GPU twice), the batch sharded
 	 * over them, results in the caller's arrays: identical to the single-dfa batch */
 	{
