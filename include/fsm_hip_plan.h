@@ -26,7 +26,12 @@ enum {
 	FSM_HIP_KNOB_ROWS          = 3,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
-	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* 0/1 override of FSM_HIP_NO_EARLY_RETIRE                       */
+	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* -1: from the dfa's flags; else a bit set -- 1: retire a wavefront whose lanes are all absorbing
+	                                  * (0 = FSM_HIP_NO_EARLY_RETIRE), 2: absorbing lanes stop loading, 4: no chunk skips, 8: no
+	                                  * absorbing-lane masking, 16: walk_generic always asks for four chunks; measurement / test aids
+	                                  * of the lines kernels: 32: never walk_lines32 (walk_generic's own body, what batches of 4 GiB
+	                                  * and more run), 64: walk_lines32 keeps the first chunk's skip tests, 128: round 4's resource
+	                                  * bound (total - 8: loses bytes; for the test that pins the range rule) */
 	FSM_HIP_KNOB_MASK          = 7,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_HOT_BYTES     = 8,  /* global layout: bytes of the table head mirrored in LDS        */
 	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */

@@ -86,7 +86,7 @@ struct fsm_hip_dfa {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
 	std::string last_kernel;     /* demangled name of the walk kernel of the last launch */
-	std::string last_kernel_short, last_kernel_long;   /* a device-side pick launched both: which one RAN is read from the flag on demand */
+	std::string last_kernel_pick[3];   /* a device-side pick launched several (indexed by PICK_*): which one RAN is read from the flag on demand */
 	const uint32_t *last_pick_flag = nullptr;
 	/* tuning knobs (fsm_hip_dfa_tune) */
 	int knob_input_mode = -1;    /* -1 auto */
@@ -742,15 +742,20 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (d->knob_noskip > 0) a.early |= 4u;
 
 	/* Variable-length inputs (the retest / rx front).  Short ones (mean < 96 bytes) walk fastest one per lane with per-lane
-	 * loads (walk_generic), long ones in 128-byte segments with lane refill (walk_ragged).  A host-pointer front knows the
-	 * mean; a device-pointer front cannot know it without a synchronising copy, so BOTH kernels are launched and a small
-	 * kernel decides on the device which of them returns at once (offsets_pick, walk_aux.h). */
-	const bool pick = varlen && known_bytes == 0 && !hint.short_mean && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
+	 * loads (walk_generic; a plain walk of a packed batch below 4 GiB: its 32-bit form walk_lines32), long ones in 128-byte
+	 * segments with lane refill (walk_ragged).  A host-pointer front knows the mean and the size; a device-pointer front cannot
+	 * know them without a synchronising copy, so the candidates are ALL launched and a small kernel decides on the device
+	 * which of them runs (offsets_pick, walk_aux.h); the others return at once. */
+	const bool pick_len = varlen && known_bytes == 0 && !hint.short_mean && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
+	/* the 32-bit lines kernel: plain outputs, a packed front, < 2^29 inputs; the batch's size: known (1 / 0) or not (-1) */
+	const bool lines_cand = !eager && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr) &&
+		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len);
+	const int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
+	const bool pick = pick_len || fits32 < 0;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events, the flag ring and the tile-base block are per dfa */
 	hipError_t e = hipSuccess;
-	std::string picked;
 	/* the ragged kernel sets bitmap bits one input at a time */
 	if ((c.mode == IN_RAGGED || c.mode == IN_LAZY_LINES) && a.bitmap != nullptr) e = zero_async(a.bitmap, ntiles * sizeof(uint64_t), s);
 	if (e == hipSuccess && ((c.mode == IN_LAZY && d->knob_lazy_dyn) || c.mode == IN_LAZY_LINES) && d->d_lazy_ctr != nullptr) {
@@ -758,37 +763,50 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		e = zero_async(a.tile_ctr, sizeof(uint32_t), s);
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev0, s);
+	md->last_pick_flag = nullptr;
+	for (auto &nm : md->last_kernel_pick) nm.clear();
 	if (e == hipSuccess && pick) {
 		a.pick_flag = md->d_pick + (md->pick_next++ % PICK_FLAGS);
-		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)d->knob_pick_mean);
+		a.skip_flag = a.pick_flag;
+		/* bit 0: walk_ragged is a candidate (else every batch counts as short); bit 1: so is walk_lines32 */
+		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)d->knob_pick_mean, (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u));
 		e = hipGetLastError();
-		if (e == hipSuccess) {
-			/* short: walk_generic, which returns at once unless the flag says short (1) */
-			const LaunchCfg g = pick_cfg(d, false, a.stride, eager, true, false);
-			const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
-			WalkArgs ag = a;
-			ag.skip_flag = a.pick_flag;
-			ag.skip_when = 0u;
-			e = launch_layout(d, eager, g, ag, dim3((unsigned)(gb0 < gcap ? gb0 : gcap)), dim3((unsigned)g.waves * 64u), s);
-			if (e == hipSuccess) picked = kernel_name(g.kfn, s);
-			a.skip_flag = a.pick_flag;
-			a.skip_when = 1u;   /* long: walk_ragged, below */
-		}
 	}
-	if (e == hipSuccess) {
+	/* the per-lane kernels (short inputs): walk_generic unless the batch is known to fit 32 bits, walk_lines32 unless known not to */
+	const bool per_lane = c.mode == IN_GENERIC || pick_len;
+	if (e == hipSuccess && per_lane) {
+		LaunchCfg g = c.mode == IN_GENERIC ? c : pick_cfg(d, false, a.stride, eager, true, false);
+		const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
+		const dim3 ggrid((unsigned)(gb0 < gcap ? gb0 : gcap)), gblock((unsigned)g.waves * 64u);
+		for (int w32 = 0; w32 < 2 && e == hipSuccess; w32++) {
+			if (w32 ? fits32 == 0 : fits32 == 1) continue;
+			WalkArgs ag = a;
+			ag.run_when = w32 ? PICK_LINES32 : PICK_GENERIC;
+			g.lines32 = w32;
+			g.kfn = nullptr;
+			e = launch_layout(d, eager, g, ag, ggrid, gblock, s);
+			if (e == hipSuccess) {
+				md->last_kernel = kernel_name(g.kfn, s);
+				md->last_kernel_pick[ag.run_when] = md->last_kernel;
+			}
+		}
+		debug_stage(s, "walk (per-lane)");
+	}
+	if (e == hipSuccess && c.mode != IN_GENERIC) {
+		a.run_when = PICK_RAGGED;
 		c.kfn = nullptr;
 		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
 		if (e == hipSuccess) {
 			md->last_kernel = kernel_name(c.kfn, s);
-			md->last_pick_flag = nullptr;
-			if (pick) {   /* both were launched, one returned at once: fsm_hip_last_kernel_name() asks the flag which */
-				md->last_kernel_short = picked;
-				md->last_kernel_long = md->last_kernel;
-				md->last_pick_flag = a.pick_flag;
-				md->last_kernel = picked + " | " + md->last_kernel;
-			}
+			md->last_kernel_pick[PICK_RAGGED] = md->last_kernel;
 		}
 		debug_stage(s, "walk");
+	}
+	if (e == hipSuccess && pick) {   /* several were launched, one ran: fsm_hip_last_kernel_name() asks the flag which */
+		md->last_pick_flag = a.pick_flag;
+		std::string all;
+		for (const auto &nm : md->last_kernel_pick) if (!nm.empty()) all += (all.empty() ? "" : " | ") + nm;
+		md->last_kernel = all;
 	}
 	if (e == hipSuccess) e = hipEventRecord(md->ev1, s);
 	if (e != hipSuccess) {
@@ -993,12 +1011,13 @@ extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 	if (md->last_pick_flag != nullptr) {
 		/* a device-pointer variable-length call: the choice between the two kernels was made on the device (offsets_pick): read it
 		 * back (a 4-byte copy; waits for the launch) and name the kernel that walked the batch, as rocprofv3 would show it busy */
-		uint32_t flag = 2;
+		uint32_t flag = 3;
 		DevGuard dg(d->device);
 		if (dg.ok() && md->timed && hipEventSynchronize(md->ev1) == hipSuccess &&
-		    hipMemcpy(&flag, md->last_pick_flag, sizeof flag, hipMemcpyDeviceToHost) == hipSuccess && flag <= 1u) {
-			md->last_kernel = flag == 1u ? md->last_kernel_short : md->last_kernel_long;
-			md->last_kernel += flag == 1u ? " (mean length below the pick threshold, decided on the device)" : " (decided on the device)";
+		    hipMemcpy(&flag, md->last_pick_flag, sizeof flag, hipMemcpyDeviceToHost) == hipSuccess && flag <= 2u && !md->last_kernel_pick[flag].empty()) {
+			md->last_kernel = md->last_kernel_pick[flag];
+			md->last_kernel += flag == PICK_RAGGED ? " (decided on the device)" : flag == PICK_LINES32 ? " (picked on the device: short lines, a batch below 4 GiB)"
+			                                                                   : " (mean length below the pick threshold, decided on the device)";
 		}
 		md->last_pick_flag = nullptr;
 	}

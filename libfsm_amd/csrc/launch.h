@@ -22,6 +22,7 @@ struct LaunchCfg {
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
+	int lines32;         /* IN_GENERIC, plain walk of a packed batch below 4 GiB / 2^29 inputs: the 32-bit kernel (walk_lines32) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 	mutable const void *kfn;   /* out: the kernel launch_fn launched (its name goes into fsm_hip_last_kernel_name) */
 };
@@ -71,7 +72,9 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 		/* the plain walk (no second output table, no resume) has an instantiation per metadata form: with the form decided at
 		 * run time every pointer of every form stays live across the loop -- 40-56 scalar registers spilled to vector lanes
 		 * against 7-19 (tools/kernel_resources.py) */
-		if (a.out2 == nullptr && a.state_io == nullptr) {
+		if (c.lines32 && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr)) {
+			k = a.off != nullptr ? walk_lines32<Pol, FR_OFF64> : a.off32 != nullptr ? walk_lines32<Pol, FR_OFF32> : walk_lines32<Pol, FR_LENS>;
+		} else if (a.out2 == nullptr && a.state_io == nullptr) {
 			k = a.off != nullptr ? walk_generic<Pol, 1024, true, FR_OFF64> : a.off32 != nullptr ? walk_generic<Pol, 1024, true, FR_OFF32>
 			  : a.tbase != nullptr ? walk_generic<Pol, 1024, true, FR_LENS> : walk_generic<Pol, 1024, true, FR_STRIDE>;
 		} else k = walk_generic<Pol>;

@@ -1,7 +1,8 @@
 /*
  * walk_aux.h -- the small kernels around the walk (included by fsm_hip.hip only):
- *   offsets_pick   which walk kernel takes a batch of variable-length inputs: walk_generic (mean length below a
- *                  threshold) or walk_ragged; decided on the device, a device-pointer front cannot know the lengths;
+ *   offsets_pick   which walk kernel takes a batch of variable-length inputs: walk_generic / walk_lines32 (mean length below a
+ *                  threshold; the batch below 4 GiB) or walk_ragged; decided on the device, a device-pointer front cannot know
+ *                  the lengths;
  *   tile_bases_*   the lengths-only front (inputs packed back to back, u32 len[n] and nothing else -- what a caller
  *                  holding (b, e) pairs has, src/libfsm/print/c.c:569-619): byte offset of every 64th input.  The walk
  *                  kernels add a wavefront prefix sum of the 64 lengths they load anyway, so the n-entry offsets array
@@ -14,14 +15,16 @@
 
 namespace fsmhip {
 
+/* cand bit 0: walk_ragged is a candidate (else every batch goes to a per-lane kernel); bit 1: walk_lines32 is one -- taken for a
+ * short-lines batch that ends below 4 GiB (its last offset, not its size: the kernel's offsets are relative to the base) */
 __global__ void __launch_bounds__(256)
-offsets_pick(const WalkArgs a, uint32_t threshold)
+offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t cand)
 {
 	__shared__ uint64_t part[256];
-	uint64_t bytes = 0, cnt = a.n;
-	if (a.off != nullptr) bytes = a.off[a.n] - a.off[0];
-	else if (a.off32 != nullptr) bytes = a.off32[a.n] - a.off32[0];
-	else if (a.tbase != nullptr) bytes = a.tbase[(a.n + 63u) / 64u];
+	uint64_t bytes = 0, cnt = a.n, last = ~(uint64_t)0;
+	if (a.off != nullptr) { last = a.off[a.n]; bytes = last - a.off[0]; }
+	else if (a.off32 != nullptr) { last = a.off32[a.n]; bytes = last - a.off32[0]; }
+	else if (a.tbase != nullptr) bytes = last = a.tbase[(a.n + 63u) / 64u];
 	else if (a.len != nullptr) {
 		/* fixed stride + lengths: a strided sample of (at most) 4096 of them */
 		const uint64_t ns = a.n < 4096u ? a.n : 4096u, step = a.n / ns;
@@ -36,7 +39,10 @@ offsets_pick(const WalkArgs a, uint32_t threshold)
 		bytes = part[0];
 		cnt = ns;
 	} else bytes = a.n * a.stride;
-	if (threadIdx.x == 0) *a.pick_flag = bytes / (cnt ? cnt : 1u) < threshold ? 1u : 0u;
+	if (threadIdx.x == 0) {
+		const bool shrt = !(cand & 1u) || bytes / (cnt ? cnt : 1u) < threshold;
+		*a.pick_flag = !shrt ? (uint32_t)PICK_RAGGED : (cand & 2u) && last < ((uint64_t)1 << 32) ? (uint32_t)PICK_LINES32 : (uint32_t)PICK_GENERIC;
+	}
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)

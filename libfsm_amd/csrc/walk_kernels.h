@@ -78,7 +78,12 @@ struct WalkArgs {
 	                           * (what the bytes beyond an input's end are given: step16_part); else >= 32 */
 	uint32_t        early;    /* bit 0: retire a wavefront once every lane is absorbing;
 	                           * bit 1: absorbing lanes stop loading their input;
-	                           * bit 2: never skip a chunk (skip16 off: measurement aid) */
+	                           * bit 2: never skip a chunk (skip16 off: measurement aid);
+	                           * bit 3: no absorbing-lane masking; bit 4: walk_generic always asks for four chunks;
+	                           * bit 5 (32): never the 32-bit lines kernel (walk_lines32): walk_generic's own body, as batches
+	                           *   of 4 GiB and more take it; bit 6 (64): walk_lines32 keeps the skip tests on an input's
+	                           *   first chunk; bit 7 (128): the per-lane loads' resource ends at total - 8 (round 4's bound:
+	                           *   loses bytes, kept for the test that pins the hardware's range rule) */
 	uint32_t        dflt;     /* Comb256Pol: encoded default state                    */
 	const uint32_t *fin2;     /* optional second per-state table (end-id / ret index) */
 	uint32_t       *out2;     /* n entries, written from fin2, or NULL                */
@@ -99,10 +104,10 @@ struct WalkArgs {
 	const uint32_t *ew_off;
 	const uint32_t *ew_word;
 	const uint64_t *ew_mask;
-	/* two kernels launched for one batch, the choice made on the device: return at once if *skip_flag == skip_when */
+	/* several kernels launched for one batch, the choice made on the device: return at once unless *skip_flag == run_when */
 	const uint32_t *skip_flag;
-	uint32_t        skip_when;
-	uint32_t       *pick_flag;   /* offsets_pick writes 1 (short inputs: walk_generic) or 0 (walk_ragged) here */
+	uint32_t        run_when;
+	uint32_t       *pick_flag;   /* offsets_pick writes PICK_RAGGED, PICK_GENERIC or PICK_LINES32 here */
 	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy; a zeroed tile counter, or NULL */
 	const void     *lazy;
 	uint32_t       *tile_ctr;
@@ -151,6 +156,7 @@ __device__ __forceinline__ uint64_t wave_excl_prefix(uint32_t v, uint32_t lane)
 	return x - v;
 }
 
+enum { PICK_RAGGED = 0, PICK_GENERIC = 1, PICK_LINES32 = 2 };
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_LAZY = 5, IN_LAZY_LINES = 6 };   /* (4 was walk_packed: removed in round 4) */
 
 #define FSMHIP_NO_MATCH 0xFFFFFFFFu
@@ -383,6 +389,7 @@ struct LdsSelfPol {
 	const unsigned char *tab;
 	uint32_t smoff;   /* offset of the mask inside a row */
 	uint32_t ident;   /* WalkArgs::ident_class */
+	uint32_t start_sm; /* the start state's mask */
 	bool skip_on;
 
 	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
@@ -394,8 +401,10 @@ struct LdsSelfPol {
 		smoff = a.fin_div - 4u;   /* fin_div = row bytes */
 		ident = a.ident_class;
 		skip_on = !(a.early & 4u);
+		start_sm = *reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.start + smoff);
 	}
 	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
+	__device__ __forceinline__ bool first_noskip() const { return ident < 32u && (start_sm & 0x7FFFFFFFu) == 0u; }
 	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, mask_of(code) }; return s; }
 	__device__ __forceinline__ static uint32_t code(const S &s) { return s.st; }
@@ -524,6 +533,8 @@ struct CombSelfPol {
 		skip_on = !(a.early & 4u);
 	}
 	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
+	/* no byte is a self-loop of the start state (anchored patterns): a chunk-level skip test on an input's FIRST chunk cannot pass */
+	__device__ __forceinline__ bool first_noskip() const { return ident < 32u && (start_sm & 0x7FFFFFFFu) == 0u; }
 	/* every input starts from the start state unless it is resumed: its mask is fetched once per
 	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
 	__device__ __forceinline__ S init(uint32_t code) const
@@ -1481,6 +1492,28 @@ __device__ __forceinline__ void step16_part(const Pol &pol, typename Pol::S &st,
 	}
 }
 
+/* An input's FIRST chunk when the policy says no byte is a self-loop of the start state (first_noskip(): anchored patterns --
+ * C3): the chunk-level skip tests (fill + raw-range test + class-mask vote: ~80 vector instructions on the self-loop-mask
+ * layouts) cannot pass, so the chunk goes straight to its lookups and the walk.  Plain walks only: every lane is in the start state. */
+template <class Pol>
+__device__ __forceinline__ auto first_noskip(const Pol &pol, int) -> decltype(pol.first_noskip()) { return pol.first_noskip(); }
+template <class Pol>
+__device__ __forceinline__ bool first_noskip(const Pol &, long) { return false; }
+
+template <class Pol>
+__device__ __forceinline__ auto step16_noskip(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t cnt, int) -> decltype(pol.ident, void())
+{
+	typename Pol::P pre[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const typename Pol::P c = pre_of(pol, w, k, 0);
+		pre[k] = (uint32_t)k < cnt ? c : (typename Pol::P)pol.ident;
+	}
+	walk_chunk(pol, st, pre, 0);
+}
+template <class Pol>
+__device__ __forceinline__ void step16_noskip(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t cnt, long) { step16_part(pol, st, w, 0u, cnt); }
+
 /* does the policy give the bytes beyond an input's end a class of their own (step16_part_ident)?  Then a partial chunk is
  * as cheap as a whole one */
 template <class Pol>
@@ -1539,11 +1572,197 @@ __device__ __forceinline__ void write_result_plain(const WalkArgs &a, uint64_t w
  * every form then stays live across the loop) */
 enum { FR_ANY = 0, FR_OFF64 = 1, FR_OFF32 = 2, FR_LENS = 3, FR_STRIDE = 4 };
 
+/*
+ * Round 5 (second half): the same walk with everything in 32 bits -- the form walk_generic<.., PLAIN, a packed front> takes,
+ * decided on the device, whenever the batch is below 4 GiB and 2^29 inputs (every batch retest / rx ever make).  The ISA
+ * accounting of the kernel above put ~170 instructions of per-tile prologue and ~60 of loop
+ * control around a walk of 32-70: 64-bit offsets, a window re-based per tile with its readfirstlanes, a three-way slow
+ * test, clamped metadata indices, a run-time resume test.  Here:
+ *  - ONE buffer resource over the whole batch (bounded 8 bytes short of its last byte, as the window was), one over the
+ *    metadata array: a chunk's address is the input's 32-bit byte offset + an immediate, an index beyond n reads zeros;
+ *  - u64 offsets are read as their low halves by one 12-byte load (off[i].lo, off[i].hi, off[i+1].lo);
+ *  - the slow test is one compare: does an input of this tile end within the batch's last 8 bytes;
+ *  - no resume / second-table / eager arguments are looked at (PLAIN).
+ */
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ void write_result_plain32(const WalkArgs &a, uint32_t tile, uint32_t st, uint32_t n)
+{
+	const uint32_t lane = threadIdx.x & 63u, i = tile * 64u + lane;
+	const bool valid = i < n;
+	uint32_t end = FSMHIP_NO_MATCH;
+	const uint32_t idx = fin_index(a, st);
+	if (valid) end = a.fin[idx];
+	if (valid && a.end_out != nullptr) a.end_out[i] = end;
+	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
+	if (a.bitmap != nullptr && lane == 0) a.bitmap[tile] = m;
+}
+
+template <class Pol, int FRONT>
+__device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol, const uint32_t total_v)
+{
+	constexpr uint32_t NC = 4;
+	/* (a value loaded from global memory sits in a vector register even when every lane loaded the same word, and a buffer
+	 * resource built from it makes every load through it a waterfall loop) */
+	const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total_v);
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+	const uint32_t n = (uint32_t)a.n, ntiles = (n + 63u) >> 6, tstride = gridDim.x * nw;
+	/* (the saturating subtraction is a vector instruction: back to a scalar register, or the resource is a vector one) */
+	const uint32_t lim8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total >= 8u ? total - 8u : 0u));
+	/* The resource ends 4 bytes short of the batch, the edge test is at 8: gfx950 returns a dword of a buffer load only when the
+	 * WHOLE dword lies inside the resource (offset + 4 <= num_records; tests/test_gpu_round5.py pins it: with the resource
+	 * ending at total - 8, as round 4 had it, an input that ended at total - 8 .. total - 11 lost its last bytes), and a dword
+	 * that starts at any byte alignment inside [.., total - 4) never reaches past the batch's last byte.
+	 * (a.early & 128: round 4's bound, for that test) */
+	const uint32_t nrec = (a.early & 128u) ? lim8 : (uint32_t)__builtin_amdgcn_readfirstlane((int)(total >= 4u ? total - 4u : 0u));
+	const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.base), 0, (int)nrec, 0x00020000);
+	const void *mp = FRONT == FR_OFF64 ? static_cast<const void *>(a.off) : FRONT == FR_OFF32 ? static_cast<const void *>(a.off32) : static_cast<const void *>(a.len);
+	const uint32_t mbytes = FRONT == FR_OFF64 ? (n + 1u) * 8u : FRONT == FR_OFF32 ? (n + 1u) * 4u : n * 4u;
+	const __amdgpu_buffer_rsrc_t meta = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(mp), 0, (int)mbytes, 0x00020000);
+
+	const bool noskip0 = first_noskip(pol, 0) && !(a.early & 64u);    /* (a.early & 64: off, for A/B runs) */
+	uint32_t nb = 0, ne = 0, ntb = 0;
+	auto fetch = [&](uint32_t tile) {
+		const uint32_t i = tile * 64u + lane;            /* beyond n: zeros come back (lengths 0; offsets: masked below) */
+		if (FRONT == FR_OFF64) {
+			const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(meta, (int)(i * 8u), 0, 0);
+			nb = v.x; ne = v.z;
+		} else if (FRONT == FR_OFF32) {
+			const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(meta, (int)(i * 4u), 0, 0);
+			nb = v.x; ne = v.y;
+		} else {
+			ne = __builtin_amdgcn_raw_buffer_load_b32(meta, (int)(i * 4u), 0, 0);
+			ntb = (uint32_t)a.tbase[tile < ntiles ? tile : ntiles];
+		}
+	};
+
+	uint32_t tile = blockIdx.x * nw + wave;
+	if (tile >= ntiles) return;
+	fetch(tile);
+	bool pend = false;
+	uint32_t ptile = 0, pcode = 0;
+	for (; tile < ntiles; tile += tstride) {
+		const uint32_t i = tile * 64u + lane;
+		const bool valid = i < n;
+		uint32_t beg, len;
+		if (FRONT == FR_LENS) { len = ne; beg = ntb + (uint32_t)wave_excl_prefix(len, lane); }
+		else { beg = nb; len = valid ? ne - nb : 0u; }
+		fetch(tile + tstride);
+		/* an input that ends within 8 bytes of the batch's end (at most eight inputs of a batch): its whole chunks that lie inside
+		 * the resource are walked with everybody's, its last <= 23 bytes afterwards, fetched one byte at a time through a resource
+		 * that ends where the batch does */
+		const bool edge = len != 0u && beg + len > lim8;
+		const bool any_edge = __any(edge);
+		uint32_t lenw = len;
+		if (any_edge && edge) lenw = beg < lim8 ? (lim8 - beg) & ~15u : 0u;
+		const uint32_t nfull = lenw >> 4, tail = lenw & 15u, nchunks = (lenw + 15u) >> 4;
+		typename Pol::S st[1] = { init_state(pol, a.start, a, (uint64_t)i, valid, 0) };
+		auto load_chunk = [&](uint32_t c) -> u32x4 {
+			return __builtin_amdgcn_raw_buffer_load_b128(win, (int)(beg + 16u * c), 0, 0);
+		};
+		u32x4 wq[NC];
+#pragma unroll
+		for (uint32_t j = 0; j < NC; j++) {
+			wq[j] = u32x4{0u, 0u, 0u, 0u};
+			if (j == 0 || __any(j < nchunks)) wq[j] = load_chunk(j);
+		}
+		if (pend) write_result_plain32(a, ptile, pcode, n);
+		if (tail_in_step<Pol>(0)) {
+#pragma unroll 1
+			for (uint32_t c = 0; c < NC; c++) {
+				if (!__any(c < nchunks)) break;
+				if (c < nchunks) {
+					if (c == 0u && noskip0) {
+						step16_noskip(pol, st[0], wq[0], nfull != 0u ? 16u : tail, 0);
+					} else if (__all(c < nfull)) {
+						const u32x4 w1[1] = { wq[0] };
+						step16<Pol, 1>(pol, st, w1);
+					} else {
+						step16_part(pol, st[0], wq[0], 0u, c < nfull ? 16u : tail);
+					}
+				}
+				wq[0] = wq[1]; wq[1] = wq[2]; wq[2] = wq[3];
+			}
+			if (__any(nchunks > NC)) {
+				u32x4 w[1] = { load_chunk(NC) };
+				for (uint32_t c = NC; __any(c < nchunks); c++) {
+					if (c < nchunks) {
+						const u32x4 wn = load_chunk(c + 1u);
+						if (__all(c < nfull)) step16<Pol, 1>(pol, st, w);
+						else step16_part(pol, st[0], w[0], 0u, c < nfull ? 16u : tail);
+						w[0] = wn;
+					}
+					if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1u >= nchunks)) break;
+				}
+			}
+		} else {
+			u32x4 tw = wq[0];
+#pragma unroll
+			for (uint32_t c = 0; c < NC; c++) {
+				if (!__any(c < nfull)) break;
+				if (c < nfull) {
+					const u32x4 w1[1] = { wq[c] };
+					step16<Pol, 1>(pol, st, w1);
+				}
+				if (c + 1u < NC && nfull == c + 1u) tw = wq[c + 1u];
+			}
+			if (__any(nchunks > NC)) {
+				u32x4 w[1] = { load_chunk(NC) };
+				for (uint32_t c = NC; __any(c < nchunks); c++) {
+					if (c < nchunks) {
+						const u32x4 wn = load_chunk(c + 1u);
+						if (c < nfull) step16<Pol, 1>(pol, st, w);
+						else tw = w[0];
+						w[0] = wn;
+					}
+					if ((a.early & 1u) && __all(Pol::code(st[0]) >= a.abs_min || c + 1u >= nchunks)) break;
+				}
+			}
+			if (__any(tail != 0u)) {
+				if (tail != 0u) step16_part(pol, st[0], tw, 0u, tail);
+			}
+		}
+		if (any_edge) {
+			const __amdgpu_buffer_rsrc_t wint = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.base), 0, (int)total, 0x00020000);
+			const uint32_t rem = edge ? len - lenw : 0u;
+			uint32_t d[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+			for (uint32_t k = 0; k < 24u; k++) {
+				const uint32_t o = k < rem ? beg + lenw + k : 0xFFFFFFFFu;     /* out of range: zero, no memory request */
+				d[k >> 2] |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(wint, (int)o, 0, 0) << ((k & 3u) * 8u);
+			}
+			if (rem != 0u) step16_part(pol, st[0], u32x4{d[0], d[1], d[2], d[3]}, 0u, rem < 16u ? rem : 16u);
+			if (rem > 16u) step16_part(pol, st[0], u32x4{d[4], d[5], 0u, 0u}, 0u, rem - 16u);
+		}
+		finish_state(pol, a, (uint64_t)i, valid, st[0], 0);
+		pend = true;
+		ptile = tile;
+		pcode = Pol::code(st[0]);
+	}
+	if (pend) write_result_plain32(a, ptile, pcode, n);
+}
+
+/* the kernel around it: a packed front (FR_OFF64 / FR_OFF32 / FR_LENS), plain outputs, a batch below 4 GiB and 2^29 inputs --
+ * the host front knows that, a device front launches this kernel AND walk_generic and offsets_pick says which one runs */
+template <class Pol, int FRONT>
+__global__ void __launch_bounds__(1024)
+walk_lines32(const WalkArgs a)
+{
+	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* another kernel took the batch */
+	extern __shared__ __align__(16) unsigned char lds[];
+	Pol pol;
+	pol.setup(lds, a);
+	__syncthreads();
+	const uint32_t total = FRONT == FR_OFF64 ? (uint32_t)a.off[a.n] : FRONT == FR_OFF32 ? a.off32[a.n] : (uint32_t)a.tbase[(a.n + 63u) / 64u];
+	generic_body32<Pol, FRONT>(a, pol, total);
+}
+
 template <class Pol, int MAXT = 1024, bool PLAIN = false, int FRONT = FR_ANY>
 __global__ void __launch_bounds__(MAXT)
 walk_generic(const WalkArgs a)
 {
-	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
+	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* another kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	Pol pol;
 	pol.setup(lds, a);
@@ -1601,7 +1820,10 @@ walk_generic(const WalkArgs a)
 		/* slow: an input of this step ends within 8 bytes of the batch's end, or the step's inputs reach 4 GiB beyond its first byte
 		 * (then 32-bit offsets do not do), or lie out of order */
 		const bool slow = __any(nchunks != 0 && (beg + len + 8u > total || rel64 + 16u * nchunks >= 0xFFFFFF00ull || beg < tb));
-		const uint64_t wbytes = total - tb >= 8u ? total - tb - 8u : 0u;
+		/* (4 bytes short of the batch, the slow test above at 8: a dword comes back only when all of it lies inside the resource --
+		 * see generic_body32; a.early & 128: round 4's bound of 8) */
+		const uint64_t wcut = (a.early & 128u) ? 8u : 4u;
+		const uint64_t wbytes = total - tb >= wcut ? total - tb - wcut : 0u;
 		const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base + tb), 0, (int)(wbytes < 0xFFFFFFF0ull ? (uint32_t)wbytes : 0xFFFFFFF0u), 0x00020000);
 		const uint32_t rel = (uint32_t)rel64;
 		const uint64_t p0 = base + beg;
@@ -1754,7 +1976,7 @@ walk_ragged(const WalkArgs a)
 	const bool f_off32 = FRONT == FR_ANY ? a.off == nullptr && a.off32 != nullptr : FRONT == FR_OFF32;
 	const bool f_lens = FRONT == FR_ANY ? a.off == nullptr && a.off32 == nullptr && a.tbase != nullptr : FRONT == FR_LENS;
 	constexpr uint32_t RING = FSMHIP_RAGGED_RING, TOP = RING / 2u;   /* top-up granularity */
-	if (a.skip_flag != nullptr && *a.skip_flag == a.skip_when) return;   /* the other kernel took the batch */
+	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* another kernel took the batch */
 	extern __shared__ __align__(16) unsigned char lds[];
 	constexpr bool HOLES = ragged_aux_in_holes<Pol>::value;
 	Pol pol;

@@ -107,15 +107,22 @@ def test_packed_kernel_length_distributions(hip, name):
         base, off = _packed(strings)
         for L, dfa in dfas:
             lens = np.diff(off.astype(np.int64)).astype(np.uint32)
-            for mode, waves in ((hip.IN_GENERIC, 0), (hip.IN_GENERIC, 1), (hip.IN_RAGGED, 5), (hip.IN_RAGGED, 0), (-1, 0)):
+            # (round 5: a plain walk of a packed batch below 4 GiB takes walk_lines32, the 32-bit form of walk_generic; early = 33
+            # -- bit 5 of the knob -- keeps it on walk_generic's own body, which batches of 4 GiB and more still run)
+            for mode, waves, early in ((hip.IN_GENERIC, 0, -1), (hip.IN_GENERIC, 0, 33), (hip.IN_GENERIC, 1, -1), (hip.IN_RAGGED, 5, -1), (hip.IN_RAGGED, 0, -1), (-1, 0, -1)):
                 if L != hip.LAYOUT_AUTO and waves not in (0, 1):
                     continue
-                print(name, cname, L, mode, waves, flush=True)
+                print(name, cname, L, mode, waves, early, flush=True)
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves)
+                dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                 end, bm = dfa.exec_batch_offsets(base, off)
                 bad = np.nonzero(end != want)[0]
-                assert len(bad) == 0, (name, cname, L, mode, waves, len(bad), bad[:8], [len(strings[i]) for i in bad[:8]])
+                assert len(bad) == 0, (name, cname, L, mode, waves, early, len(bad), bad[:8], [len(strings[i]) for i in bad[:8]])
+                if mode == hip.IN_GENERIC and len(strings):
+                    kn = dfa.last_kernel_name()
+                    lazy = "walk_lazy" in kn
+                    assert lazy or ("walk_lines32" in kn) == (early < 0), (kn, early)
                 assert np.array_equal(bits(bm, len(strings)), ret == 1), (name, cname, L, mode, waves)
                 end, bm = dfa.exec_batch_offsets(base, off, want_bitmap=False)      # end states only
                 assert np.array_equal(end, want)

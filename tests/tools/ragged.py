@@ -57,44 +57,48 @@ def main():
                     continue
                 dfa.tune(hip.KNOB_INPUT_MODE, mode)
                 dfa.tune(hip.KNOB_WAVES, waves or int(os.environ.get("PK_WAVES", 0)))
-                for kn, ev in ((hip.KNOB_PICK_MEAN, "PICK_MEAN"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP"), (hip.KNOB_EARLY_RETIRE, "RAGGED_EARLY")):
+                for kn, ev in ((hip.KNOB_PICK_MEAN, "PICK_MEAN"), (hip.KNOB_NOSKIP, "RAGGED_NOSKIP")):
                     if os.environ.get(ev):
                         dfa.tune(kn, int(os.environ[ev]))
-                ms = []
-                for r in range(4):
-                    if front == "packed":
-                        dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n, end.data_ptr(), 0)
-                    elif front == "off32":
-                        if off32 is None:
-                            break
-                        dfa.exec_batch_offsets32_device(packed.data_ptr(), off32.data_ptr(), n, end.data_ptr(), 0)
-                    elif front == "lengths":
-                        dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, end.data_ptr(), 0)
-                    elif front == "len-bitmap":       # the 1-bit-per-input answer alone (the end states of the previous front stay in `end`)
-                        dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, 0, bm.data_ptr())
-                    elif front == "rows":       # whole 1024-byte rows: what the same kernel (3) / the LDS-DMA kernel (-1) does without raggedness
-                        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)
-                    else:
-                        dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0, d_len=lens.data_ptr())
-                    t = dfa.last_kernel_ms()
-                    if r:
-                        ms.append(t)
-                torch.cuda.synchronize()
-                if not ms:
-                    continue
-                if front == "rows":
-                    print(f"{wl} {dfa.info()['layout_name']:8s} lens=1024           front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
-                          f"GB/s(walked)={n * L / min(ms) / 1e6:8.1f}", flush=True)
-                    continue
-                ok = np.array_equal(end.cpu().numpy().view(np.uint32)[idx], want)
-                if ref is None:
-                    ref = end.clone()
-                ok = ok and bool(torch.equal(ref, end))
-                if front == "len-bitmap":
-                    got = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
-                    ok = ok and np.array_equal(got, ref.cpu().numpy() != -1)
-                print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
-                      f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}", flush=True)
+                # RAGGED_EARLY: one value of the early knob or a comma list of them, timed one after the other on the same batch
+                # (33 = walk_generic's own body instead of walk_lines32, 65 = walk_lines32 with the first-chunk skip tests left in)
+                for early in [int(x) for x in os.environ.get("RAGGED_EARLY", "-1").split(",")]:
+                    dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                    ms = []
+                    for r in range(4):
+                        if front == "packed":
+                            dfa.exec_batch_offsets_device(packed.data_ptr(), off.data_ptr(), n, end.data_ptr(), 0)
+                        elif front == "off32":
+                            if off32 is None:
+                                break
+                            dfa.exec_batch_offsets32_device(packed.data_ptr(), off32.data_ptr(), n, end.data_ptr(), 0)
+                        elif front == "lengths":
+                            dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, end.data_ptr(), 0)
+                        elif front == "len-bitmap":       # the 1-bit-per-input answer alone (the end states of the previous front stay in `end`)
+                            dfa.exec_batch_lengths_device(packed.data_ptr(), lens.data_ptr(), n, 0, bm.data_ptr())
+                        elif front == "rows":       # whole 1024-byte rows: what the same kernel (3) / the LDS-DMA kernel (-1) does without raggedness
+                            dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0)
+                        else:
+                            dfa.exec_batch_device(buf.data_ptr(), L, n, end.data_ptr(), 0, d_len=lens.data_ptr())
+                        t = dfa.last_kernel_ms()
+                        if r:
+                            ms.append(t)
+                    torch.cuda.synchronize()
+                    if not ms:
+                        continue
+                    if front == "rows":
+                        print(f"{wl} {dfa.info()['layout_name']:8s} lens=1024           front={front:10s} mode={mode:2d} waves={waves:2d} ms={min(ms):8.3f} "
+                              f"GB/s(walked)={n * L / min(ms) / 1e6:8.1f}", flush=True)
+                        continue
+                    ok = np.array_equal(end.cpu().numpy().view(np.uint32)[idx], want)
+                    if ref is None:
+                        ref = end.clone()
+                    ok = ok and bool(torch.equal(ref, end))
+                    if front == "len-bitmap":
+                        got = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+                        ok = ok and np.array_equal(got, ref.cpu().numpy() != -1)
+                    print(f"{wl} {dfa.info()['layout_name']:8s} lens={dist:14s} front={front:10s} mode={mode:2d} waves={waves:2d} early={early:3d} ms={min(ms):8.3f} "
+                          f"GB/s(walked)={total / min(ms) / 1e6:8.1f} {'ok' if ok else 'MISMATCH'}  {dfa.last_kernel_name()[:60]}", flush=True)
             dfa.close()
 
 
