@@ -715,6 +715,46 @@ static std::string kernel_name(const void *kfn, hipStream_t s)
 	return r;
 }
 
+/* vector registers of a kernel (cached per kernel: the query is a driver call) */
+static int kernel_vgprs(const void *kfn)
+{
+	if (kfn == nullptr) return 0;
+	static std::mutex cache_mu;
+	static std::vector<std::pair<const void *, int>> cache;
+	{
+		std::lock_guard<std::mutex> lk(cache_mu);
+		for (const auto &e : cache) if (e.first == kfn) return e.second;
+	}
+	hipFuncAttributes at;
+	const int r = hipFuncGetAttributes(&at, kfn) == hipSuccess ? at.numRegs : 0;
+	std::lock_guard<std::mutex> lk(cache_mu);
+	cache.emplace_back(kfn, r);
+	return r;
+}
+
+/* The per-lane kernels on an LDS table are bound by latency (a tile's chunks are asked for and waited for at once): what
+ * counts is how many wavefronts a CU holds.  The table's LDS allows `by_lds` workgroups per CU; a SIMD holds 512 / registers
+ * wavefronts (8 at most), a workgroup of W wavefronts puts ceil(W / 4) on each.  walk_lines32<CombSelfPol> (76 registers: 6 per
+ * SIMD): one 16-wavefront workgroup fits (4 per SIMD), or TWO of 12 (6 per SIMD) -- 24000000 lines of 8-64 bytes on the C3 table:
+ * 0.485 -> 0.418 ms, 8-16 bytes 0.294 -> 0.234 (profiles/r08d_lines32_waves.txt).  Returns the workgroup size (wavefronts)
+ * that keeps most wavefronts resident, the larger one on a tie. */
+static int waves_by_occupancy(int vgprs, int by_lds, int wmax)
+{
+	if (vgprs <= 0) return wmax;
+	const int alloc = (vgprs + 7) / 8 * 8;
+	int per_simd = 512 / alloc;
+	if (per_simd > 8) per_simd = 8;
+	int best = wmax, best_res = 0;
+	for (int w = wmax; w >= 8; w -= 4) {
+		const int each = (w + 3) / 4;
+		int blocks = per_simd / each;
+		if (blocks > by_lds) blocks = by_lds;
+		if (blocks * w > 32) blocks = 32 / w;
+		if (blocks * w > best_res) { best_res = blocks * w; best = w; }
+	}
+	return best;
+}
+
 static void debug_stage(hipStream_t s, const char *what)
 {
 	static const int lvl = getenv("FSM_HIP_DEBUG") ? atoi(getenv("FSM_HIP_DEBUG")) : 0;
@@ -775,14 +815,29 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	/* the per-lane kernels (short inputs): walk_generic unless the batch is known to fit 32 bits, walk_lines32 unless known not to */
 	const bool per_lane = c.mode == IN_GENERIC || pick_len;
 	if (e == hipSuccess && per_lane) {
-		LaunchCfg g = c.mode == IN_GENERIC ? c : pick_cfg(d, false, a.stride, eager, true, false);
-		const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
-		const dim3 ggrid((unsigned)(gb0 < gcap ? gb0 : gcap)), gblock((unsigned)g.waves * 64u);
+		const LaunchCfg g0 = c.mode == IN_GENERIC ? c : pick_cfg(d, false, a.stride, eager, true, false);
 		for (int w32 = 0; w32 < 2 && e == hipSuccess; w32++) {
 			if (w32 ? fits32 == 0 : fits32 == 1) continue;
 			WalkArgs ag = a;
 			ag.run_when = w32 ? PICK_LINES32 : PICK_GENERIC;
+			LaunchCfg g = g0;
 			g.lines32 = w32;
+			/* the workgroup size that keeps most wavefronts on a CU, from the kernel's own register count (LDS tables, plain walks,
+			 * no knob) */
+			if (!eager && d->knob_waves <= 0 && d->knob_blocks_per_cu <= 0 && d->table_lds != 0 && d->plan.layout != FSM_HIP_LAYOUT_TINY) {
+				g.probe = 1;
+				g.kfn = nullptr;
+				if (launch_layout(d, eager, g, ag, dim3(1), dim3(64), s) == hipSuccess && g.kfn != nullptr) {
+					const int by_lds = (int)(d->lds_limit / d->table_lds);
+					g.waves = waves_by_occupancy(kernel_vgprs(g.kfn), by_lds < 1 ? 1 : by_lds, g0.waves);
+					int bpc = by_lds < 1 ? 1 : by_lds;
+					if (bpc * g.waves > 32) bpc = 32 / g.waves;
+					g.blocks_per_cu = bpc < 1 ? 1 : bpc;
+				}
+				g.probe = 0;
+			}
+			const uint64_t gb0 = (ntiles + g.waves - 1) / g.waves, gcap = (uint64_t)d->ncu * g.blocks_per_cu;
+			const dim3 ggrid((unsigned)(gb0 < gcap ? gb0 : gcap)), gblock((unsigned)g.waves * 64u);
 			g.kfn = nullptr;
 			e = launch_layout(d, eager, g, ag, ggrid, gblock, s);
 			if (e == hipSuccess) {

@@ -24,6 +24,7 @@ struct LaunchCfg {
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
 	int lines32;         /* IN_GENERIC, plain walk of a packed batch below 4 GiB / 2^29 inputs: the 32-bit kernel (walk_lines32) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
+	int probe;           /* 1: do not launch, only say (kfn) which kernel it would be (fsm_hip.hip sizes a workgroup by the kernel's registers) */
 	mutable const void *kfn;   /* out: the kernel launch_fn launched (its name goes into fsm_hip_last_kernel_name) */
 };
 
@@ -44,6 +45,10 @@ typedef void (*walk_fn)(const WalkArgs);
 
 static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s)
 {
+	if (c.probe) {
+		c.kfn = (const void *)k;
+		return hipSuccess;
+	}
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);

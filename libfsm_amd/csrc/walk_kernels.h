@@ -156,6 +156,23 @@ __device__ __forceinline__ uint64_t wave_excl_prefix(uint32_t v, uint32_t lane)
 	return x - v;
 }
 
+/* the same in 32 bits by data-parallel primitives: seven adds whose second operand comes from another lane of the row / the
+ * row before (row_shr 1, 2, 3; 4 and 8 on the banks that have such a lane; the last lane of row 0 / 2 broadcast into row 1 / 3;
+ * lane 31 into rows 2 and 3) -- the shuffle form above is six LDS-path permutes of 64 bits each.  (walk_lines32's lengths front:
+ * a batch below 4 GiB.) */
+__device__ __forceinline__ uint32_t wave_excl_prefix32(uint32_t v)
+{
+	uint32_t s = v;
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   /* row_shr:2 */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);   /* row_shr:3 */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, false);   /* row_shr:4, lanes 4..15 of a row */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, false);   /* row_shr:8, lanes 8..15 */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false);   /* row_bcast:15 into rows 1 and 3 */
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);   /* row_bcast:31 into rows 2 and 3 */
+	return s - v;
+}
+
 enum { PICK_RAGGED = 0, PICK_GENERIC = 1, PICK_LINES32 = 2 };
 enum { IN_DIRECT = 0, IN_LDSDMA = 1, IN_GENERIC = 2, IN_RAGGED = 3, IN_LAZY = 5, IN_LAZY_LINES = 6 };   /* (4 was walk_packed: removed in round 4) */
 
@@ -404,7 +421,7 @@ struct LdsSelfPol {
 		start_sm = *reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(a.tab) + a.start + smoff);
 	}
 	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
-	__device__ __forceinline__ bool first_noskip() const { return ident < 32u && (start_sm & 0x7FFFFFFFu) == 0u; }
+	__device__ __forceinline__ bool first_noskip() const { return ident == 31u && (start_sm & 0x7FFFFFFFu) == 0u; }
 	__device__ __forceinline__ uint32_t mask_of(uint32_t st) const { return *reinterpret_cast<const uint32_t *>(tab + st + smoff); }
 	__device__ __forceinline__ S init(uint32_t code) const { S s = { code, mask_of(code) }; return s; }
 	__device__ __forceinline__ static uint32_t code(const S &s) { return s.st; }
@@ -534,7 +551,7 @@ struct CombSelfPol {
 	}
 	__device__ __forceinline__ bool ident_ok() const { return ident < 32u; }
 	/* no byte is a self-loop of the start state (anchored patterns): a chunk-level skip test on an input's FIRST chunk cannot pass */
-	__device__ __forceinline__ bool first_noskip() const { return ident < 32u && (start_sm & 0x7FFFFFFFu) == 0u; }
+	__device__ __forceinline__ bool first_noskip() const { return ident == 31u && (start_sm & 0x7FFFFFFFu) == 0u; }
 	/* every input starts from the start state unless it is resumed: its mask is fetched once per
 	 * workgroup, not once per input (the ragged kernel seeds a lane every time an input ends) */
 	__device__ __forceinline__ S init(uint32_t code) const
@@ -1503,11 +1520,17 @@ __device__ __forceinline__ bool first_noskip(const Pol &, long) { return false; 
 template <class Pol>
 __device__ __forceinline__ auto step16_noskip(const Pol &pol, typename Pol::S &st, const u32x4 &w, uint32_t cnt, int) -> decltype(pol.ident, void())
 {
+	/* the bytes beyond the input's end get the spare class: one compare + one select per byte.  The byte count passes through an
+	 * empty asm per byte: without it the compiler hoists the sixteen compares to the head of the tile (they depend on the
+	 * input's length alone) and keeps their 32 scalar registers live across the walk -- registers this kernel does not have:
+	 * they went to vector lanes and back, 2 + 2 more instructions per byte. */
 	typename Pol::P pre[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
+		uint32_t ck = cnt;
+		asm volatile("" : "+v"(ck));
 		const typename Pol::P c = pre_of(pol, w, k, 0);
-		pre[k] = (uint32_t)k < cnt ? c : (typename Pol::P)pol.ident;
+		pre[k] = (uint32_t)k < ck ? c : (typename Pol::P)pol.ident;
 	}
 	walk_chunk(pol, st, pre, 0);
 }
@@ -1646,7 +1669,7 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 		const uint32_t i = tile * 64u + lane;
 		const bool valid = i < n;
 		uint32_t beg, len;
-		if (FRONT == FR_LENS) { len = ne; beg = ntb + (uint32_t)wave_excl_prefix(len, lane); }
+		if (FRONT == FR_LENS) { len = ne; beg = ntb + wave_excl_prefix32(len); }
 		else { beg = nb; len = valid ? ne - nb : 0u; }
 		fetch(tile + tstride);
 		/* an input that ends within 8 bytes of the batch's end (at most eight inputs of a batch): its whole chunks that lie inside
@@ -1724,16 +1747,22 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 			}
 		}
 		if (any_edge) {
+			/* (four bytes a turn, the turns not unrolled: this runs once per launch, and the registers of an unrolled form -- 24
+			 * offsets + 24 bytes -- would set the whole kernel's count) */
 			const __amdgpu_buffer_rsrc_t wint = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.base), 0, (int)total, 0x00020000);
-			const uint32_t rem = edge ? len - lenw : 0u;
-			uint32_t d[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+			const uint32_t rem = edge ? len - lenw : 0u, from = beg + lenw;
+#pragma unroll 1
+			for (uint32_t k0 = 0; __any(k0 < rem); k0 += 4u) {
+				uint32_t b[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 24u; k++) {
-				const uint32_t o = k < rem ? beg + lenw + k : 0xFFFFFFFFu;     /* out of range: zero, no memory request */
-				d[k >> 2] |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(wint, (int)o, 0, 0) << ((k & 3u) * 8u);
+				for (uint32_t k = 0; k < 4u; k++)     /* out of range (0xFFFFFFFF): zero, no memory request */
+					b[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(wint, (int)(k0 + k < rem ? from + k0 + k : 0xFFFFFFFFu), 0, 0);
+#pragma unroll
+				for (uint32_t k = 0; k < 4u; k++) {
+					const typename Pol::S nx = pol.next(st[0], pol.pre(b[k] & 0xffu));
+					st[0] = pick(k0 + k < rem, nx, st[0]);
+				}
 			}
-			if (rem != 0u) step16_part(pol, st[0], u32x4{d[0], d[1], d[2], d[3]}, 0u, rem < 16u ? rem : 16u);
-			if (rem > 16u) step16_part(pol, st[0], u32x4{d[4], d[5], 0u, 0u}, 0u, rem - 16u);
 		}
 		finish_state(pol, a, (uint64_t)i, valid, st[0], 0);
 		pend = true;
@@ -1745,8 +1774,10 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 
 /* the kernel around it: a packed front (FR_OFF64 / FR_OFF32 / FR_LENS), plain outputs, a batch below 4 GiB and 2^29 inputs --
  * the host front knows that, a device front launches this kernel AND walk_generic and offsets_pick says which one runs */
+/* (six wavefronts per SIMD = two 12-wavefront workgroups per CU beside a table of up to 80 KB: <= 80 vector registers.  The
+ * self-loop-mask layouts sit at 75-82 on their own; every other layout is far below) */
 template <class Pol, int FRONT>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, 6)
 walk_lines32(const WalkArgs a)
 {
 	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* another kernel took the batch */
