@@ -789,7 +789,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const bool pick_len = varlen && known_bytes == 0 && !hint.short_mean && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
 	/* the 32-bit lines kernel: plain outputs, a packed front, < 2^29 inputs; the batch's size: known (1 / 0) or not (-1) */
 	const bool lines_cand = !eager && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr) &&
-		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len);
+		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len) && d->plan.layout != FSM_HIP_LAYOUT_SPARSE;   /* (launch.h lines32_ok) */
 	const int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
 	const bool pick = pick_len || fits32 < 0;
 

@@ -77,8 +77,9 @@ static hipError_t launch_pol(const LaunchCfg &c, const WalkArgs &a, dim3 grid, d
 		/* the plain walk (no second output table, no resume) has an instantiation per metadata form: with the form decided at
 		 * run time every pointer of every form stays live across the loop -- 40-56 scalar registers spilled to vector lanes
 		 * against 7-19 (tools/kernel_resources.py) */
-		if (c.lines32 && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr)) {
-			k = a.off != nullptr ? walk_lines32<Pol, FR_OFF64> : a.off32 != nullptr ? walk_lines32<Pol, FR_OFF32> : walk_lines32<Pol, FR_LENS>;
+		if (lines32_ok<Pol>::value && c.lines32 && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr)) {
+			if constexpr (lines32_ok<Pol>::value)
+				k = a.off != nullptr ? walk_lines32<Pol, FR_OFF64> : a.off32 != nullptr ? walk_lines32<Pol, FR_OFF32> : walk_lines32<Pol, FR_LENS>;
 		} else if (a.out2 == nullptr && a.state_io == nullptr) {
 			k = a.off != nullptr ? walk_generic<Pol, 1024, true, FR_OFF64> : a.off32 != nullptr ? walk_generic<Pol, 1024, true, FR_OFF32>
 			  : a.tbase != nullptr ? walk_generic<Pol, 1024, true, FR_LENS> : walk_generic<Pol, 1024, true, FR_STRIDE>;

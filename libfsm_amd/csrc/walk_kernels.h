@@ -1610,19 +1610,26 @@ enum { FR_ANY = 0, FR_OFF64 = 1, FR_OFF32 = 2, FR_LENS = 3, FR_STRIDE = 4 };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
-__device__ __forceinline__ void write_result_plain32(const WalkArgs &a, uint32_t tile, uint32_t st, uint32_t n)
+/* a tile's results in two halves: the fin[] lookup, and -- once it is back -- the stores */
+struct ResPend32 { uint32_t end; bool valid; };
+__device__ __forceinline__ ResPend32 result_load32(const WalkArgs &a, uint32_t tile, uint32_t st, uint32_t n)
+{
+	ResPend32 r;
+	r.valid = tile * 64u + (threadIdx.x & 63u) < n;
+	r.end = FSMHIP_NO_MATCH;
+	const uint32_t idx = fin_index(a, st);
+	if (r.valid) r.end = a.fin[idx];
+	return r;
+}
+__device__ __forceinline__ void result_store32(const WalkArgs &a, uint32_t tile, const ResPend32 &r)
 {
 	const uint32_t lane = threadIdx.x & 63u, i = tile * 64u + lane;
-	const bool valid = i < n;
-	uint32_t end = FSMHIP_NO_MATCH;
-	const uint32_t idx = fin_index(a, st);
-	if (valid) end = a.fin[idx];
-	if (valid && a.end_out != nullptr) a.end_out[i] = end;
-	const uint64_t m = __ballot(valid && end != FSMHIP_NO_MATCH);
+	if (r.valid && a.end_out != nullptr) a.end_out[i] = r.end;
+	const uint64_t m = __ballot(r.valid && r.end != FSMHIP_NO_MATCH);
 	if (a.bitmap != nullptr && lane == 0) a.bitmap[tile] = m;
 }
 
-template <class Pol, int FRONT>
+template <class Pol, int FRONT, bool PF>
 __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol, const uint32_t total_v)
 {
 	constexpr uint32_t NC = 4;
@@ -1645,12 +1652,15 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 	const __amdgpu_buffer_rsrc_t meta = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(mp), 0, (int)mbytes, 0x00020000);
 
 	const bool noskip0 = first_noskip(pol, 0) && !(a.early & 64u);    /* (a.early & 64: off, for A/B runs) */
-	uint32_t nb = 0, ne = 0, ntb = 0;
+	uint32_t nb = 0, ne = 0, ntb = 0, nhi = 0;
 	auto fetch = [&](uint32_t tile) {
 		const uint32_t i = tile * 64u + lane;            /* beyond n: zeros come back (lengths 0; offsets: masked below) */
 		if (FRONT == FR_OFF64) {
+			/* (the offset's high half is looked at -- it is 0 in a batch below 4 GiB; an input whose is not counts as empty -- so that
+			 * its register stays the load's until the load is back: the compiler took a dead middle register of a load in flight
+			 * for a temporary, and the write-after-write wait that costs took a prefetched chunk with it) */
 			const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(meta, (int)(i * 8u), 0, 0);
-			nb = v.x; ne = v.z;
+			nb = v.x; nhi = v.y; ne = v.z;
 		} else if (FRONT == FR_OFF32) {
 			const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(meta, (int)(i * 4u), 0, 0);
 			nb = v.x; ne = v.y;
@@ -1659,38 +1669,71 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 			ntb = (uint32_t)a.tbase[tile < ntiles ? tile : ntiles];
 		}
 	};
+	/* where the inputs of the tile whose metadata was fetched last lie.  lenw = the bytes that are walked in chunks: all of them,
+	 * except for an input that ends within 8 bytes of the batch's end (at most eight inputs of a batch): its whole chunks that lie
+	 * inside the resource are walked with everybody's, its last <= 23 bytes afterwards, fetched a byte at a time through a
+	 * resource that ends where the batch does */
+	struct Where { uint32_t beg, len, lenw; };
+	auto prepare = [&](uint32_t tile) -> Where {
+		const uint32_t i = tile * 64u + lane;
+		Where t;
+		if (FRONT == FR_LENS) { t.len = ne; t.beg = ntb + wave_excl_prefix32(t.len); }
+		else { t.beg = nb; t.len = i < n && (FRONT != FR_OFF64 || nhi == 0u) ? ne - nb : 0u; }
+		const bool edge = t.len != 0u && t.beg + t.len > lim8;
+		t.lenw = edge ? (t.beg < lim8 ? (lim8 - t.beg) & ~15u : 0u) : t.len;
+		return t;
+	};
+	/* an input's first NC chunks, asked for together.  A chunk NO input of the tile has is skipped by a wave-uniform branch (8-16
+	 * byte lines: one load, not four); in a chunk that some have, an input that does not asks at an offset beyond the resource:
+	 * zeros, no memory request (a.early & 4096: every lane asks at its own offset, as the first version did -- A/B runs) */
+	auto issue = [&](const Where &t, u32x4 (&w)[NC]) {
+		const uint32_t nch = (t.lenw + 15u) >> 4;
+		const bool all_ask = (a.early & 4096u) != 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < NC; j++) {
+			w[j] = u32x4{0u, 0u, 0u, 0u};
+			if (j == 0 || __any(j < nch))
+				w[j] = __builtin_amdgcn_raw_buffer_load_b128(win, (int)(j < nch || all_ask ? t.beg + 16u * j : 0xFFFFFFF0u), 0, 0);
+		}
+	};
 
 	uint32_t tile = blockIdx.x * nw + wave;
 	if (tile >= ntiles) return;
 	fetch(tile);
+	Where cur = {0u, 0u, 0u}, nxt = {0u, 0u, 0u};
+	u32x4 wq[NC], wn[NC];
+	if (PF) {
+		/* two tiles in flight: the chunks of tile t + 1 are asked for before tile t is walked (light policies: the registers are there) */
+		cur = prepare(tile);
+		fetch(tile + tstride);
+		issue(cur, wq);
+	}
 	bool pend = false;
 	uint32_t ptile = 0, pcode = 0;
 	for (; tile < ntiles; tile += tstride) {
 		const uint32_t i = tile * 64u + lane;
 		const bool valid = i < n;
-		uint32_t beg, len;
-		if (FRONT == FR_LENS) { len = ne; beg = ntb + wave_excl_prefix32(len); }
-		else { beg = nb; len = valid ? ne - nb : 0u; }
-		fetch(tile + tstride);
-		/* an input that ends within 8 bytes of the batch's end (at most eight inputs of a batch): its whole chunks that lie inside
-		 * the resource are walked with everybody's, its last <= 23 bytes afterwards, fetched one byte at a time through a resource
-		 * that ends where the batch does */
-		const bool edge = len != 0u && beg + len > lim8;
+		/* the previous tile's results: the fin[] lookup is asked for FIRST (loads come back in order: what is waited for must not
+		 * sit behind the next tile's chunks) */
+		ResPend32 rp = {FSMHIP_NO_MATCH, false};
+		if (pend) rp = result_load32(a, ptile, pcode, n);
+		if (PF) {
+			nxt = prepare(tile + tstride);
+			fetch(tile + 2u * tstride);
+			issue(nxt, wn);
+		} else {
+			cur = prepare(tile);
+			fetch(tile + tstride);
+			issue(cur, wq);
+		}
+		const uint32_t beg = cur.beg, len = cur.len, lenw = cur.lenw;
+		const bool edge = lenw != len;
 		const bool any_edge = __any(edge);
-		uint32_t lenw = len;
-		if (any_edge && edge) lenw = beg < lim8 ? (lim8 - beg) & ~15u : 0u;
 		const uint32_t nfull = lenw >> 4, tail = lenw & 15u, nchunks = (lenw + 15u) >> 4;
 		typename Pol::S st[1] = { init_state(pol, a.start, a, (uint64_t)i, valid, 0) };
 		auto load_chunk = [&](uint32_t c) -> u32x4 {
 			return __builtin_amdgcn_raw_buffer_load_b128(win, (int)(beg + 16u * c), 0, 0);
 		};
-		u32x4 wq[NC];
-#pragma unroll
-		for (uint32_t j = 0; j < NC; j++) {
-			wq[j] = u32x4{0u, 0u, 0u, 0u};
-			if (j == 0 || __any(j < nchunks)) wq[j] = load_chunk(j);
-		}
-		if (pend) write_result_plain32(a, ptile, pcode, n);
 		if (tail_in_step<Pol>(0)) {
 #pragma unroll 1
 			for (uint32_t c = 0; c < NC; c++) {
@@ -1765,12 +1808,40 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 			}
 		}
 		finish_state(pol, a, (uint64_t)i, valid, st[0], 0);
+		/* ... and their stores come after the walk: the oldest operations still counted when the NEXT walk waits for its chunks are
+		 * then these stores, a whole walk old (a store asked for before the walk would sit between the chunks and the prefetch in
+		 * the in-order count, and the wait for the chunks would take it, or a prefetched chunk, along) */
+		if (pend) result_store32(a, ptile, rp);
 		pend = true;
 		ptile = tile;
 		pcode = Pol::code(st[0]);
+		if (PF) {
+			cur = nxt;
+#pragma unroll
+			for (uint32_t j = 0; j < NC; j++) wq[j] = wn[j];
+		}
 	}
-	if (pend) write_result_plain32(a, ptile, pcode, n);
+	if (pend) {
+		const ResPend32 rp = result_load32(a, ptile, pcode, n);
+		result_store32(a, ptile, rp);
+	}
 }
+
+/* the policies whose walk leaves the registers for a second tile in flight (the self-loop-mask layouts and the record walk sit at
+ * 70-80 registers without it) */
+template <class Pol> struct lines_prefetch { static constexpr bool value = true; };
+template <> struct lines_prefetch<CombSelfPol> { static constexpr bool value = false; };
+template <> struct lines_prefetch<LdsSelfPol> { static constexpr bool value = false; };
+template <> struct lines_prefetch<SparsePol> { static constexpr bool value = false; };
+
+/* The record walk (SparsePol) stays on walk_generic: one build of walk_lines32<SparsePol> lost the state of a lane between an
+ * input's first and second chunk in ~45 % of its launches (8+ wavefronts per workgroup; inputs whose match straddles byte 16),
+ * the builds before and after it -- same walk source, a different order of the loads around it -- in none of 300
+ * (profiles/r08i_*).  Its per-byte loop mixes flat loads that land in LDS or in memory with global loads under complementary
+ * exec masks; which instruction order trips, and whether it is the compiler's wait-count merge or the hardware, was not
+ * found.  Automata of that layout are served by walk_lazy_lines (walk_lazy.h) on these fronts anyway. */
+template <class Pol> struct lines32_ok { static constexpr bool value = true; };
+template <> struct lines32_ok<SparsePol> { static constexpr bool value = false; };
 
 /* the kernel around it: a packed front (FR_OFF64 / FR_OFF32 / FR_LENS), plain outputs, a batch below 4 GiB and 2^29 inputs --
  * the host front knows that, a device front launches this kernel AND walk_generic and offsets_pick says which one runs */
@@ -1786,7 +1857,8 @@ walk_lines32(const WalkArgs a)
 	pol.setup(lds, a);
 	__syncthreads();
 	const uint32_t total = FRONT == FR_OFF64 ? (uint32_t)a.off[a.n] : FRONT == FR_OFF32 ? a.off32[a.n] : (uint32_t)a.tbase[(a.n + 63u) / 64u];
-	generic_body32<Pol, FRONT>(a, pol, total);
+	if (lines_prefetch<Pol>::value && !(a.early & 256u)) generic_body32<Pol, FRONT, true>(a, pol, total);   /* (a.early & 256: off, for A/B runs) */
+	else generic_body32<Pol, FRONT, false>(a, pol, total);
 }
 
 template <class Pol, int MAXT = 1024, bool PLAIN = false, int FRONT = FR_ANY>
