@@ -42,7 +42,8 @@
  *   walk_direct_np  the same without the register double-buffer (<= 64 VGPRs, occupancy instead).
  * Any length / alignment / packed offsets:
  *   walk_ragged  the LDS-DMA input path with per-lane source addresses + lane refill per segment;
- *   walk_generic per-lane 16-byte loads (fallback, and the better one for very short inputs).
+ *   walk_generic per-lane 16-byte loads (fallback, and the better one for very short inputs);
+ *   walk_lines32 the same walk in 32 bits for plain walks of packed batches below 4 GiB (round 5: the short-lines kernel).
  * Where an input lies: fixed stride (+ lengths), u64 or u32 offsets, or lengths alone (packed back to back: per-tile
  * bases from a small pre-pass + a wavefront prefix sum).
  */
@@ -1578,8 +1579,8 @@ __device__ __forceinline__ void write_result_plain(const WalkArgs &a, uint64_t w
  * rx feed (a few dozen bytes each) and the fallback for everything else.  A step has ONE wait:
  *  - the offsets (or lengths) of the NEXT step's inputs are asked for at the top of a step;
  *  - an input's first NC = 4 chunks are loaded together from its own byte address (no partial chunk at the head).  Round 4:
- *    BUFFER loads through a resource re-based, per step, on the first input of the tile and bounded 8 bytes short of the
- *    batch's last byte: the address of a chunk is one 32-bit offset + an immediate (the first version added 64-bit
+ *    BUFFER loads through a resource re-based, per step, on the first input of the tile and bounded 4 bytes short of the
+ *    batch's last byte (8 in round 4, which lost the last bytes of an input ending at total - 8 .. - 11: see generic_body32): the address of a chunk is one 32-bit offset + an immediate (the first version added 64-bit
  *    addresses and selected a safe address for the lanes without that chunk: ~20 vector instructions a step), a chunk that
  *    lies beyond the batch reads zeros instead of faulting, and the only tiles that take the out-of-line byte assembly are
  *    the ones that really touch the batch's last 8 bytes (or span 4 GiB);
@@ -1596,16 +1597,30 @@ __device__ __forceinline__ void write_result_plain(const WalkArgs &a, uint64_t w
 enum { FR_ANY = 0, FR_OFF64 = 1, FR_OFF32 = 2, FR_LENS = 3, FR_STRIDE = 4 };
 
 /*
- * Round 5 (second half): the same walk with everything in 32 bits -- the form walk_generic<.., PLAIN, a packed front> takes,
- * decided on the device, whenever the batch is below 4 GiB and 2^29 inputs (every batch retest / rx ever make).  The ISA
- * accounting of the kernel above put ~170 instructions of per-tile prologue and ~60 of loop
- * control around a walk of 32-70: 64-bit offsets, a window re-based per tile with its readfirstlanes, a three-way slow
- * test, clamped metadata indices, a run-time resume test.  Here:
- *  - ONE buffer resource over the whole batch (bounded 8 bytes short of its last byte, as the window was), one over the
- *    metadata array: a chunk's address is the input's 32-bit byte offset + an immediate, an index beyond n reads zeros;
- *  - u64 offsets are read as their low halves by one 12-byte load (off[i].lo, off[i].hi, off[i+1].lo);
- *  - the slow test is one compare: does an input of this tile end within the batch's last 8 bytes;
- *  - no resume / second-table / eager arguments are looked at (PLAIN).
+ * walk_lines32 (round 5, second half): walk_generic's walk for the batches retest / rx actually make -- a plain walk (end
+ * states / accept bitmap) of lines packed back to back, the batch below 4 GiB and 2^29 lines -- with everything in 32 bits.
+ * The host front knows a batch's size; a device front launches this kernel AND walk_generic (AND walk_ragged) and offsets_pick
+ * says on the device which one runs.  What was measured on the way (24e6 lines of 8-64 bytes on the C3 table, profiles/r08*):
+ *  - the per-tile prologue.  The ISA accounting of walk_generic had ~170 instructions of prologue
+ *    and ~60 of loop control around a walk of 32-70: 64-bit offsets, a window re-based per tile with its readfirstlanes, a
+ *    three-way slow test, clamped metadata indices, a run-time resume test.  Here ONE buffer resource spans the batch and one
+ *    the metadata (a chunk's address is the line's 32-bit byte offset + an immediate; an index beyond n reads zeros), u64
+ *    offsets are read as their low halves by one 12-byte load, the edge test is one compare, nothing of resume / ids / eager
+ *    sets is looked at.  Alone that was worth 0-10 % (0.485 -> 0.485 / 0.44 ms by front): the kernel was not instruction-bound;
+ *  - it is LATENCY-bound (a tile's chunks are asked for and waited for; SQ_WAIT_ANY 0.6 of the wave cycles, VALU 58 % busy), so
+ *    what counts is wavefronts per CU: 76 registers let ONE 16-wavefront workgroup on a CU (4 per SIMD) where two of 12 fit
+ *    (6 per SIMD): fsm_hip.hip sizes the workgroup from the kernel's register count -- 0.485 -> 0.386 ms; <= 80 registers held
+ *    by __launch_bounds__(1024, 6);
+ *  - the previous tile's fin[] lookup is asked for first and its stores come after the walk (loads return in order: nothing that
+ *    is waited for may sit behind the chunks); a lane that lacks chunk j asks beyond the resource (zeros, no memory request:
+ *    the texture addresser was 55-64 % busy with every lane asking for four chunks): 0.386 -> 0.350 ms = 0.41 of HBM peak on
+ *    sum(len) + 12 bytes a line (walk_generic: 0.32); 8-16 byte lines 0.294 -> 0.199 ms;
+ *  - the light policies (column tables, lds, comb ...) have the registers for a SECOND tile in flight (PF): tile t + 1's chunks
+ *    are asked for before tile t is walked: + 10 % on 8-16 byte lines, nothing on 8-64 (the addresser again);
+ *  - an input's FIRST chunk skips the chunk-level skip tests when no byte is a self-loop of the start state (step16_noskip);
+ *  - the lengths front's prefix sum is seven DPP adds (wave_excl_prefix32), its tile base a scalar load.
+ * The resource ends 4 bytes short of the batch and the <= 8 lines that end in its last 8 bytes walk their last <= 23 bytes
+ * byte by byte (see the note at `nrec` below: round 4's bound lost bytes).
  */
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
@@ -1636,8 +1651,11 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 	/* (a value loaded from global memory sits in a vector register even when every lane loaded the same word, and a buffer
 	 * resource built from it makes every load through it a waterfall loop) */
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total_v);
-	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-	const uint32_t n = (uint32_t)a.n, ntiles = (n + 63u) >> 6, tstride = gridDim.x * nw;
+	/* (the workgroup's size comes out of the dispatch packet by a vector load: said to be uniform, or the tile counter, the
+	 * stride and everything indexed by them sit in vector registers -- the lengths front's build did that and spilled) */
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const uint32_t nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+	const uint32_t n = (uint32_t)a.n, ntiles = (n + 63u) >> 6, tstride = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * nw));
 	/* (the saturating subtraction is a vector instruction: back to a scalar register, or the resource is a vector one) */
 	const uint32_t lim8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total >= 8u ? total - 8u : 0u));
 	/* The resource ends 4 bytes short of the batch, the edge test is at 8: gfx950 returns a dword of a buffer load only when the
@@ -1666,7 +1684,10 @@ __device__ __forceinline__ void generic_body32(const WalkArgs &a, const Pol &pol
 			nb = v.x; ne = v.y;
 		} else {
 			ne = __builtin_amdgcn_raw_buffer_load_b32(meta, (int)(i * 4u), 0, 0);
-			ntb = (uint32_t)a.tbase[tile < ntiles ? tile : ntiles];
+			/* (read as constant memory -- the pre-pass that wrote it is an earlier kernel -- so that it is a scalar load into a
+			 * scalar register: as ordinary global memory it was a vector load of one address and a vector register per lane) */
+			typedef const uint64_t __attribute__((address_space(4))) *const_u64p;
+			ntb = (uint32_t)reinterpret_cast<const_u64p>(reinterpret_cast<uintptr_t>(a.tbase))[tile < ntiles ? tile : ntiles];
 		}
 	};
 	/* where the inputs of the tile whose metadata was fetched last lie.  lenw = the bytes that are walked in chunks: all of them,
@@ -1833,6 +1854,7 @@ template <class Pol> struct lines_prefetch { static constexpr bool value = true;
 template <> struct lines_prefetch<CombSelfPol> { static constexpr bool value = false; };
 template <> struct lines_prefetch<LdsSelfPol> { static constexpr bool value = false; };
 template <> struct lines_prefetch<SparsePol> { static constexpr bool value = false; };
+template <> struct lines_prefetch<TinyPol<uint64_t>> { static constexpr bool value = false; };   /* sixteen 64-bit columns a chunk */
 
 /* The record walk (SparsePol) stays on walk_generic: one build of walk_lines32<SparsePol> lost the state of a lane between an
  * input's first and second chunk in ~45 % of its launches (8+ wavefronts per workgroup; inputs whose match straddles byte 16),

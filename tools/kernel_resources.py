@@ -16,6 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "libfsm_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 UNITS = ["kern_tiny", "kern_lds", "kern_comb", "kern_glob"]
+# --strict also holds the kernels the bench lines run to a bound on SGPR spills (scalar registers parked in vector lanes: an
+# instruction each way, and in the short-lines kernels they sat inside the per-tile path -- 23-37 of them in round 4)
+HOT_SSPILL = [("walk_lines32<", 8), ("walk_ldsdma<CombSelfPol, 128, 2, 768>", 0), ("walk_ldsdma<Tiny5Pol, 128, 2, 1024>", 0),
+              ("walk_direct<Comb256Pol, 8, 1>", 0), ("walk_lazy<", 0), ("walk_ragged<Tiny5Pol, 768, 0>", 24), ("walk_ragged<CombSelfPol, 768, 0>", 48)]
 
 
 def demangle(names):
@@ -47,21 +51,25 @@ def main():
                          int(f.get("vgpr_spill_count", 0)), int(f.get("sgpr_spill_count", 0)), int(f.get("private_segment_fixed_size", 0))))
     names = demangle([r[1] for r in rows])
     lines = []
-    bad = 0
+    bad = hot_bad = 0
     for r, nm in zip(rows, names):
         nm = nm.replace("fsmhip::", "").replace("(fsmhip::WalkArgs)", "").replace("void ", "")
         flag = ""
         if r[5] or r[7]:
             flag = "  <-- spills/scratch"
             bad += 1
+        for pat, lim in HOT_SSPILL:
+            if pat in nm and r[6] > lim:
+                flag += f"  <-- hot kernel: {r[6]} SGPR spills > {lim}"
+                hot_bad += 1
         lines.append(f"{r[0]:10s} vgpr={r[2]:3d} agpr={r[3]:3d} sgpr={r[4]:3d} vspill={r[5]:3d} sspill={r[6]:3d} scratch={r[7]:4d}  {nm}{flag}")
     lines.sort()
-    lines.append(f"# {len(rows)} kernels, {bad} with VGPR spills or scratch")
+    lines.append(f"# {len(rows)} kernels, {bad} with VGPR spills or scratch, {hot_bad} hot kernels over their SGPR-spill bound")
     text = "\n".join(lines)
     print(text)
     if outp:
         open(outp[0], "w").write(text + "\n")
-    if strict and bad:
+    if strict and (bad or hot_bad):
         sys.exit(1)
 
 
