@@ -440,8 +440,11 @@ def _short_kernel(name, width=72):
     """rocprofv3's kernel name without the namespace, cut to `width` characters"""
     if not name:
         return name
+    import re
     name = str(name).replace("fsmhip::", "").replace(" (mean length < 96 B, decided on the device)", "")
-    name = name.replace(" (mean length below the pick threshold, decided on the device)", " (picked on device)").replace(" (decided on the device)", " (picked on device)")
+    # "(... decided / picked on the device[: why][, 1 of N launched])" -> "(picked on device[, 1 of N])"
+    name = re.sub(r" \((?:mean length below the pick threshold, decided|decided|picked) on the device(?:: [^)]*?)?(?:, (1 of \d) launched)?\)",
+                  lambda m: " (picked on device" + (", " + m.group(1) if m.group(1) else "") + ")", name)
     return name if len(name) <= width else name[:width - 1] + "~"
 
 

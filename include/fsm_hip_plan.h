@@ -113,6 +113,14 @@ double fsm_hip_gather_probe_ms(const void *d_base, size_t bytes, size_t ngathers
  * of "bytes" walked by the whole device (every lane walks `steps`), -1 on error.  d_scratch4: 4 writable device bytes. */
 double fsm_hip_lds_chain_probe_gbps(size_t table_bytes, int waves, int blocks_per_cu, size_t steps, void *d_scratch4, void *hip_stream);
 
+/* The workgroup size (wavefronts: max_waves, max_waves - 4, ... >= 8) the library gives a latency-bound per-lane kernel
+ * (walk_lines32, walk_generic on an LDS table) that uses `vgprs` vector registers beside a table whose LDS lets
+ * `workgroups_by_lds` workgroups share a CU: the one that keeps most wavefronts resident (a SIMD holds 512 / registers of
+ * them, 8 at most, in steps of 8 registers; a workgroup of W puts ceil(W / 4) on each SIMD; 32 per CU at most), the larger
+ * one on a tie.  76 registers, 2 by LDS, 16 -> 12 (two workgroups of 12 where one of 16 fits: -20 % on 8-64 byte lines).
+ * Pure arithmetic (no device needed): exported so that the rule is testable and visible. */
+int fsm_hip_waves_by_occupancy(int vgprs, int workgroups_by_lds, int max_waves);
+
 #ifdef __cplusplus
 }
 #endif

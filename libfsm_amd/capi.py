@@ -1037,6 +1037,13 @@ def lds_chain_probe_gbps(table_bytes: int, waves: int, blocks_per_cu: int, steps
     return float(r)
 
 
+def waves_by_occupancy(vgprs: int, workgroups_by_lds: int, max_waves: int = 16) -> int:
+    """fsm_hip_waves_by_occupancy: the workgroup size (wavefronts) a latency-bound per-lane kernel gets (pure arithmetic)."""
+    lib = load_library()
+    lib.fsm_hip_waves_by_occupancy.restype = C.c_int
+    return int(lib.fsm_hip_waves_by_occupancy(C.c_int(vgprs), C.c_int(workgroups_by_lds), C.c_int(max_waves)))
+
+
 def pack_affixes(items: Sequence[bytes]) -> np.ndarray:
     """[len<=7, b0..b6] entries for the affix generator."""
     t = np.zeros((len(items), 8), dtype=np.uint8)

@@ -755,6 +755,12 @@ static int waves_by_occupancy(int vgprs, int by_lds, int wmax)
 	return best;
 }
 
+extern "C" int fsm_hip_waves_by_occupancy(int vgprs, int workgroups_by_lds, int max_waves)
+{
+	if (max_waves < 8) return max_waves;
+	return waves_by_occupancy(vgprs, workgroups_by_lds < 1 ? 1 : workgroups_by_lds, max_waves > 16 ? 16 : max_waves);
+}
+
 static void debug_stage(hipStream_t s, const char *what)
 {
 	static const int lvl = getenv("FSM_HIP_DEBUG") ? atoi(getenv("FSM_HIP_DEBUG")) : 0;
@@ -790,7 +796,22 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	/* the 32-bit lines kernel: plain outputs, a packed front, < 2^29 inputs; the batch's size: known (1 / 0) or not (-1) */
 	const bool lines_cand = !eager && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr) &&
 		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len) && d->plan.layout != FSM_HIP_LAYOUT_SPARSE;   /* (launch.h lines32_ok) */
-	const int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
+	int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
+	if (fits32 < 0) {
+		/* a device front with u64 offsets / lengths alone: the batch's size is on the device -- but it cannot end beyond the
+		 * ALLOCATION its base points into.  Fewer than 4 GiB from the base to the allocation's end (every batch but a huge one in
+		 * a huge block): walk_generic's own body is not needed and is not launched.  (Not asked during a stream capture: the
+		 * query is not a stream operation, and an API that is not may end a capture.) */
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+			hipDeviceptr_t ab = nullptr;
+			size_t asz = 0;
+			if (hipMemGetAddressRange(&ab, &asz, (hipDeviceptr_t)const_cast<uint8_t *>(a.base)) == hipSuccess && ab != nullptr) {
+				const uint64_t room = reinterpret_cast<uint64_t>(ab) + asz - reinterpret_cast<uint64_t>(a.base);
+				if (room < ((uint64_t)1 << 32)) fits32 = 1;
+			} else (void)hipGetLastError();
+		} else (void)hipGetLastError();
+	}
 	const bool pick = pick_len || fits32 < 0;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
@@ -1070,9 +1091,12 @@ extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 		DevGuard dg(d->device);
 		if (dg.ok() && md->timed && hipEventSynchronize(md->ev1) == hipSuccess &&
 		    hipMemcpy(&flag, md->last_pick_flag, sizeof flag, hipMemcpyDeviceToHost) == hipSuccess && flag <= 2u && !md->last_kernel_pick[flag].empty()) {
+			int cands = 0;
+			for (const auto &nm : md->last_kernel_pick) cands += nm.empty() ? 0 : 1;
 			md->last_kernel = md->last_kernel_pick[flag];
-			md->last_kernel += flag == PICK_RAGGED ? " (decided on the device)" : flag == PICK_LINES32 ? " (picked on the device: short lines, a batch below 4 GiB)"
-			                                                                   : " (mean length below the pick threshold, decided on the device)";
+			md->last_kernel += flag == PICK_RAGGED ? " (decided on the device" : flag == PICK_LINES32 ? " (picked on the device: short lines, a batch below 4 GiB"
+			                                                                  : " (mean length below the pick threshold, decided on the device";
+			md->last_kernel += cands == 2 ? ", 1 of 2 launched)" : cands == 3 ? ", 1 of 3 launched)" : ")";
 		}
 		md->last_pick_flag = nullptr;
 	}

@@ -566,3 +566,33 @@ def test_lazy_form_on_random_dfas(built):
         r = check_lazy(pa, decode_want(flat, pa))
         made += r is not None
     assert made >= 4
+
+
+def test_workgroup_size_by_occupancy(built):
+    """fsm_hip_waves_by_occupancy: the rule that sizes the workgroup of the latency-bound per-lane kernels (walk_lines32) from
+    the kernel's register count -- round 5: two 12-wavefront workgroups per CU where one of 16 fitted were worth 20 % on short
+    lines.  Checked against a brute-force restatement of the hardware limits (512 registers per SIMD lane in steps of 8, 8
+    wavefronts per SIMD, 32 per CU, the table's LDS)."""
+    import libfsm_amd as hip
+
+    def brute(vg, by_lds, wmax):
+        per_simd = min(8, 512 // ((vg + 7) // 8 * 8))
+        best, best_res = wmax, 0
+        for w in range(wmax, 7, -4):
+            blocks = min(per_simd // ((w + 3) // 4), by_lds, 32 // w)
+            if blocks * w > best_res:
+                best, best_res = w, blocks * w
+        return best
+
+    assert hip.waves_by_occupancy(76, 2, 16) == 12      # walk_lines32<CombSelfPol> beside the C3 table: 2 x 12, not 1 x 16
+    assert hip.waves_by_occupancy(80, 2, 16) == 12
+    assert hip.waves_by_occupancy(88, 2, 16) == 16      # 5 wavefronts per SIMD: one workgroup either way, the larger one
+    assert hip.waves_by_occupancy(64, 2, 16) == 16      # 8 per SIMD: two of 16
+    assert hip.waves_by_occupancy(64, 1, 16) == 16      # the table's LDS allows one
+    assert hip.waves_by_occupancy(40, 8, 16) == 16
+    assert hip.waves_by_occupancy(0, 2, 16) == 16       # unknown register count: what the caller had
+    assert hip.waves_by_occupancy(76, 2, 4) == 4        # small workgroups are left alone
+    for vg in range(8, 257, 4):
+        for by_lds in (1, 2, 3, 4, 8):
+            for wmax in (8, 12, 16):
+                assert hip.waves_by_occupancy(vg, by_lds, wmax) == brute(vg, by_lds, wmax), (vg, by_lds, wmax)
