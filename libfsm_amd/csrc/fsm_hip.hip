@@ -726,10 +726,13 @@ static int kernel_vgprs(const void *kfn)
 		for (const auto &e : cache) if (e.first == kfn) return e.second;
 	}
 	hipFuncAttributes at;
-	const int r = hipFuncGetAttributes(&at, kfn) == hipSuccess ? at.numRegs : 0;
+	if (hipFuncGetAttributes(&at, kfn) != hipSuccess) {   /* (not remembered: asked again at the next launch) */
+		(void)hipGetLastError();
+		return 0;
+	}
 	std::lock_guard<std::mutex> lk(cache_mu);
-	cache.emplace_back(kfn, r);
-	return r;
+	cache.emplace_back(kfn, at.numRegs);
+	return at.numRegs;
 }
 
 /* The per-lane kernels on an LDS table are bound by latency (a tile's chunks are asked for and waited for at once): what
