@@ -40,9 +40,10 @@ enum {
 	FSM_HIP_KNOB_NOSKIP        = 13, /* 1: self-loop layouts never skip a whole chunk (measurement aid: every byte pays its test) */
 	FSM_HIP_KNOB_PK_RMIN       = 16, /* retired with walk_packed (accepted, ignored)                 */
 	FSM_HIP_KNOB_PK_RMAX       = 17, /* retired (accepted, ignored)                                   */
-	FSM_HIP_KNOB_PICK_MEAN     = 18, /* variable-length batches whose mean input length (bytes) is below this go to walk_generic,
-	                                  * the others to walk_ragged; default 96 (the host fronts know the mean, the device fronts
-	                                  * ask a small kernel: walk_aux.h offsets_pick) */
+	FSM_HIP_KNOB_PICK_MEAN     = 18, /* variable-length batches whose mean input length (bytes) is below this go to a per-lane
+	                                  * kernel, the others to walk_ragged; -1 (default): 128 where the per-lane kernel is
+	                                  * walk_lines32 (plain walks of packed lines), 96 where it is walk_generic (the host fronts
+	                                  * know the mean, the device fronts ask a small kernel: walk_aux.h offsets_pick) */
 	FSM_HIP_KNOB_PK_DEBUG      = 19, /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_SPARSE_FAST   = 20, /* sparse layout, fixed-stride rows: 3 (default where the automaton has a lazy form) states beyond the
 	                                  * LDS set are entered without their record, a Bloom filter in LDS says when to fetch it

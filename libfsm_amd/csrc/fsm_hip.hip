@@ -102,7 +102,8 @@ struct fsm_hip_dfa {
 	int knob_noskip = 0;         /* 1: chunk skip off (measurement) */
 	int knob_sparse_fast = 1;    /* sparse layout: entry-as-state walk (0: the id-as-state chain loop, for A/B runs) */
 	bool sparse_fast_ok = true;  /* the record array sits inside one 4 GiB window (SparseFastPol::enter) */
-	int knob_pick_mean = 96;     /* variable-length batches whose mean input length is below this many bytes go to walk_generic */
+	int knob_pick_mean = -1;     /* variable-length batches whose mean input length is below this many bytes go to a per-lane kernel;
+	                              * -1: 128 where walk_lines32 is the per-lane kernel, 96 for walk_generic (pick_mean_of()) */
 	unsigned flags = 0;
 	/* The pair table (lds2) wins on fixed-stride rows but leaves no LDS for the ragged kernel's tiles: a dfa planned that way keeps a
 	 * SECOND automaton image (lds / combself / ...) for its variable-length, unaligned and resumed batches */
@@ -553,6 +554,14 @@ extern "C" void fsm_hip_dfa_free(struct fsm_hip_dfa *d)
 /* launch                                                             */
 /* ------------------------------------------------------------------ */
 
+/* Where the per-lane kernels hand over to walk_ragged (mean input length, bytes).  walk_generic: 96 (round 3).  walk_lines32 is
+ * faster than that kernel and still wins at a mean of 96 (64-128 byte lines: 2.40 vs 1.86 TB/s on the column table, 2.35 vs 1.40
+ * on the C3 table), walk_ragged from ~160 on (64-256 bytes: 1.81 vs 2.69, 1.86 vs 2.09): 128 (profiles/r08r_*). */
+static int pick_mean_of(const fsm_hip_dfa *d, bool lines32)
+{
+	return d->knob_pick_mean >= 0 ? d->knob_pick_mean : lines32 ? 128 : 96;
+}
+
 /* per_lane: take walk_generic unless a knob says otherwise -- the inputs average < 96 bytes (walk_ragged works in
  * 128-byte segments: 0.7-1.2 vs 1.5-2.1 TB/s at 8-64 bytes, profiles/r03t_*); huge: the batch may hold an input the
  * ragged kernel's 32-bit piece count cannot (>= 2^36 bytes) */
@@ -833,7 +842,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		a.pick_flag = md->d_pick + (md->pick_next++ % PICK_FLAGS);
 		a.skip_flag = a.pick_flag;
 		/* bit 0: walk_ragged is a candidate (else every batch counts as short); bit 1: so is walk_lines32 */
-		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)d->knob_pick_mean, (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u));
+		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)pick_mean_of(d, false), (uint32_t)pick_mean_of(d, true),
+		                   (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u));
 		e = hipGetLastError();
 	}
 	/* the per-lane kernels (short inputs): walk_generic unless the batch is known to fit 32 bits, walk_lines32 unless known not to */
@@ -1242,11 +1252,13 @@ static int exec_host(const struct fsm_hip_dfa *d,
 	BatchHint hint;
 	hint.bytes = in_bytes;
 	if (off != nullptr || off32 != nullptr || packed_len) {
-		hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
+		/* a plain walk of packed lines: walk_lines32 is the per-lane kernel (below 4 GiB and 2^29 lines, not the record walk) */
+		const bool l32 = in_bytes < ((uint64_t)1 << 32) && n < 0x1FFFFFF0ull && d->plan.layout != FSM_HIP_LAYOUT_SPARSE;
+		hint.short_mean = in_bytes / n < (size_t)pick_mean_of(d, l32);
 	} else if (len != nullptr) {   /* the average of the lengths, not of the rows they sit in */
 		uint64_t sum = 0;
 		for (size_t i = 0; i < n; i++) sum += len[i];
-		hint.short_mean = sum / n < (uint64_t)d->knob_pick_mean;
+		hint.short_mean = sum / n < (uint64_t)pick_mean_of(d, false);
 	}
 	if (off || off32 || packed_len) {
 		if (exec_packed_device(d, hc.dev<unsigned char>(p_in), hc.dev<uint64_t>(p_off), hc.dev<uint32_t>(p_off32), packed_len ? hc.dev<uint32_t>(p_len) : nullptr, n,
@@ -1393,7 +1405,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	case FSM_HIP_KNOB_PK_RMAX:
 	case FSM_HIP_KNOB_PK_DEBUG: break;   /* retired with walk_packed (round 4): accepted, ignored */
 	case FSM_HIP_KNOB_SPARSE_FAST: d->knob_sparse_fast = value < 0 || value > 3 ? (d->d_lazy ? 3 : 1) : value; break;
-	case FSM_HIP_KNOB_PICK_MEAN: if (value < 0) { errno = EINVAL; return -1; } d->knob_pick_mean = value; break;
+	case FSM_HIP_KNOB_PICK_MEAN: if (value < -1) { errno = EINVAL; return -1; } d->knob_pick_mean = value; break;   /* -1: the defaults */
 	case FSM_HIP_KNOB_DMA_BUFS: break;   /* retired: two DMA tiles per wave measured slower (profiles/r02m_ab_one_vs_two_dma_tiles.txt) */
 	default: errno = EINVAL; return -1;
 	}
@@ -1906,7 +1918,7 @@ static int ids_host(const struct fsm_hip_dfa *d, const unsigned char *base, size
 	const int p_out = hc.add(HostCall::OUT, nullptr, id_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (ids_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n, mode,
-	               hc.dev<uint32_t>(p_out), hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
+	               hc.dev<uint32_t>(p_out), hc.d->hs, host_hint(in_bytes, len, off, n, pick_mean_of(d, false))) != 0) return -1;
 	return hc.end();
 }
 
@@ -2083,7 +2095,7 @@ extern "C" int fsm_hip_exec_batch_resume_packed(const struct fsm_hip_dfa *d,
 	if (hc.begin() != 0) return -1;
 	BatchHint hint;
 	hint.bytes = in_bytes;
-	hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
+	hint.short_mean = in_bytes / n < (size_t)pick_mean_of(d, false);
 	const void *dm = hc.dev<unsigned char>(p_meta);
 	if (resume_device(hc.d, hc.dev<unsigned char>(p_in), 0, meta_form == FSM_HIP_META_LENGTHS ? static_cast<const uint32_t *>(dm) : nullptr,
 	                  meta_form == FSM_HIP_META_OFF64 ? static_cast<const uint64_t *>(dm) : nullptr, n,
@@ -2123,7 +2135,7 @@ static int resume_host(const struct fsm_hip_dfa *d, const unsigned char *base, s
 	const int p_end = hc.add(HostCall::OUT, nullptr, end_out, n * sizeof(uint32_t));
 	if (hc.begin() != 0) return -1;
 	if (resume_device(hc.d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
-	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
+	                  hc.dev<uint32_t>(p_st), hc.dev<uint32_t>(p_end), nullptr, hc.d->hs, host_hint(in_bytes, len, off, n, pick_mean_of(d, false))) != 0) return -1;
 	return hc.end();
 }
 
@@ -2330,7 +2342,7 @@ extern "C" int fsm_hip_exec_batch_packed_all(const struct fsm_hip_dfa *d,
 	if (hc.begin() != 0) return -1;
 	BatchHint hint;
 	hint.bytes = in_bytes;
-	hint.short_mean = in_bytes / n < (size_t)d->knob_pick_mean;
+	hint.short_mean = in_bytes / n < (size_t)pick_mean_of(d, false);
 	const void *dm = hc.dev<unsigned char>(p_meta);
 	if (all_device(d, hc.dev<unsigned char>(p_in), 0, meta_form == FSM_HIP_META_LENGTHS ? static_cast<const uint32_t *>(dm) : nullptr,
 	               meta_form == FSM_HIP_META_OFF64 ? static_cast<const uint64_t *>(dm) : nullptr,
@@ -2355,7 +2367,7 @@ static int eager_host(const struct fsm_hip_dfa *d, const unsigned char *base, si
 	const int p_eo = hc.add(HostCall::OUT, nullptr, eager_out, n * fsm_hip_eager_words(d) * sizeof(uint64_t));
 	if (hc.begin() != 0) return -1;
 	if (eager_device(d, hc.dev<unsigned char>(p_in), stride, hc.dev<uint32_t>(p_len), hc.dev<uint64_t>(p_off), n,
-	                 hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs, host_hint(in_bytes, len, off, n, d->knob_pick_mean)) != 0) return -1;
+	                 hc.dev<uint32_t>(p_end), hc.dev<uint64_t>(p_eo), hc.d->hs, host_hint(in_bytes, len, off, n, pick_mean_of(d, false))) != 0) return -1;
 	return hc.end();
 }
 

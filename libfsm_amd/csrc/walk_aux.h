@@ -18,7 +18,7 @@ namespace fsmhip {
 /* cand bit 0: walk_ragged is a candidate (else every batch goes to a per-lane kernel); bit 1: walk_lines32 is one -- taken for a
  * short-lines batch that ends below 4 GiB (its last offset, not its size: the kernel's offsets are relative to the base) */
 __global__ void __launch_bounds__(256)
-offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t cand)
+offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t threshold32, uint32_t cand)
 {
 	__shared__ uint64_t part[256];
 	uint64_t bytes = 0, cnt = a.n, last = ~(uint64_t)0;
@@ -40,8 +40,11 @@ offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t cand)
 		cnt = ns;
 	} else bytes = a.n * a.stride;
 	if (threadIdx.x == 0) {
-		const bool shrt = !(cand & 1u) || bytes / (cnt ? cnt : 1u) < threshold;
-		*a.pick_flag = !shrt ? (uint32_t)PICK_RAGGED : (cand & 2u) && last < ((uint64_t)1 << 32) ? (uint32_t)PICK_LINES32 : (uint32_t)PICK_GENERIC;
+		/* (threshold32: where walk_lines32 hands over to walk_ragged -- later than walk_generic does: fsm_hip.hip pick_mean_of) */
+		const uint64_t mean = bytes / (cnt ? cnt : 1u);
+		const bool l32 = (cand & 2u) && last < ((uint64_t)1 << 32);
+		const bool shrt = !(cand & 1u) || mean < (l32 ? threshold32 : threshold);
+		*a.pick_flag = !shrt ? (uint32_t)PICK_RAGGED : l32 ? (uint32_t)PICK_LINES32 : (uint32_t)PICK_GENERIC;
 	}
 }
 

@@ -635,7 +635,13 @@ def test_pair_table_dfa_keeps_a_second_image_for_variable_length_batches(hip):
     end, bm = dfa.exec_batch_offsets(packed, off)
     assert np.array_equal(end, want) and np.array_equal(_bits(bm, n), want != NO)
     name = dfa.last_kernel_name()
-    assert "walk_ragged" in name and "Lds2Pol" not in name, name
+    # (mean 128 bytes: at the hand-over between walk_lines32 and walk_ragged -- either, on the second image)
+    assert ("walk_ragged" in name or "walk_lines32" in name) and "Lds2Pol" not in name, name
+    dfa.tune(hip.KNOB_PICK_MEAN, 96)                                     # round 4's hand-over: these lines go to walk_ragged
+    end, bm = dfa.exec_batch_offsets(packed, off)
+    assert np.array_equal(end, want) and np.array_equal(_bits(bm, n), want != NO)
+    assert "walk_ragged" in dfa.last_kernel_name() and "Lds2Pol" not in dfa.last_kernel_name(), dfa.last_kernel_name()
+    dfa.tune(hip.KNOB_PICK_MEAN, -1)
     end, _ = dfa.exec_batch(rows, lens)                                  # stride + lengths: the same
     assert np.array_equal(end, want) and "Lds2Pol" not in dfa.last_kernel_name()
     ids = dfa.exec_offsets_ids(packed, off, 1)
