@@ -73,6 +73,12 @@ for step in "$@"; do
 	        timeout 600 python tools/pmc_kernel.py --match walk_generic --sets "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_IFETCH SQ_INSTS_SMEM;SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ GRBM_GUI_ACTIVE;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQC_ICACHE_BUSY_CYCLES" --out gpurun_out/${TAG}_genic.json -- python tests/tools/ragged.py > gpurun_out/${TAG}_genic.txt 2>&1; tail -90 gpurun_out/${TAG}_genic.txt ;;
 	lds2)   timeout 500 python tests/tools/lds2_probe.py > gpurun_out/${TAG}_lds2.txt 2>&1; echo "lds2 rc=$?"; tail -24 gpurun_out/${TAG}_lds2.txt ;;
 	benchfull) timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err ;;
+	lines32ab) export RAGGED_N=${RAGGED_N:-24000000} RAGGED_DISTS=${PK_DISTS:-short8-64,short8-16} RAGGED_CASES=${PK_CASES:-c2:packed:-1,c3:packed:-1,c2:off32:-1,c3:off32:-1,c2:lengths:-1,c3:lengths:-1}
+	        # early knob: -1 the shipped choice, 33 walk_generic's own body, 257 no second tile in flight, 4097 every lane asks for every chunk, 65 first-chunk skip tests kept
+	        RAGGED_EARLY=${LINES32_EARLY:--1,33,257,4097} timeout 500 python tests/tools/ragged.py 2>&1 | grep "front=" > gpurun_out/${TAG}_lines32_ab.txt; cut -c1-160 gpurun_out/${TAG}_lines32_ab.txt ;;
+	lines32x) export RAGGED_N=12000000 RAGGED_DISTS=short32-128,mid64-128,mid64-192,mid64-256,mid128-256 RAGGED_CASES=c2:packed:-1,c2:packed:2,c2:packed:3,c3:packed:-1,c3:packed:2,c3:packed:3
+	        timeout 500 python tests/tools/ragged.py 2>&1 | grep "front=" > gpurun_out/${TAG}_lines32_crossover.txt; cut -c1-160 gpurun_out/${TAG}_lines32_crossover.txt ;;
+	linesstress) LAYOUTS=${LAYOUTS:-0,1,2,3,4,5,6,8,9} MIXES=${MIXES:-0-200,8-64,8-16} MODES=${MODES:--1,2} REPS=${REPS:-100} timeout 1300 python tests/tools/lines_stress.py > gpurun_out/${TAG}_lines_stress.txt 2>&1; echo "stress rc=$?"; tail -2 gpurun_out/${TAG}_lines_stress.txt ;;
 	c5tests) timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config5 or literal_set or aho_corasick" > gpurun_out/${TAG}_c5tests.log 2>&1; tail -3 gpurun_out/${TAG}_c5tests.log ;;
 	esac
 done
