@@ -198,7 +198,10 @@ def kernels_sha16():
     (tools/rocpd_summary.py stores it; a kernel edit makes bench.py drop `traffic` until tools/profile.sh is rerun)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("walk_kernels.h", "walk_lazy.h", "launch.h"):
+    # everything that decides what a launch fetches: the kernels, which kernel / grid / workgroup a launch gets
+    # (fsm_hip.hip pick_cfg / waves_by_occupancy, launch.h, kern_*.hip), the table layouts (plan.cpp) and the other fronts
+    for f in ("walk_kernels.h", "walk_lazy.h", "walk_aux.h", "launch.h", "fsm_hip.hip", "plan.cpp", "plan.h", "multi.hip",
+              "kern_tiny.hip", "kern_lds.hip", "kern_comb.hip", "kern_glob.hip"):
         with open(os.path.join(ROOT, "libfsm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

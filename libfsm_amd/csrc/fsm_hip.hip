@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <utility>
@@ -108,8 +109,10 @@ struct fsm_hip_dfa {
 	/* The pair table (lds2) wins on fixed-stride rows but leaves no LDS for the ragged kernel's tiles: a dfa planned that way keeps a
 	 * SECOND automaton image (lds / combself / ...) for its variable-length, unaligned and resumed batches */
 	fsm_hip_dfa *alt = nullptr;
-	const fsm_hip_dfa *last_used = nullptr;   /* which of the two the last launch went to (timing / kernel name) */
-	bool uploaded = false;       /* the layout's tables are on the device (FSM_HIP_DEFER_UPLOAD: not before the first single-dfa call) */
+	std::atomic<const fsm_hip_dfa *> last_used{nullptr};   /* which of the two the last launch went to (timing / kernel name); written by concurrent callers */
+	std::atomic<bool> uploaded{false};   /* the layout's tables are on the device (FSM_HIP_DEFER_UPLOAD: not before the first single-dfa call);
+	                                      * release-stored under mu once everything is in place, acquire-loaded without it */
+	int upload_errno = 0;        /* a failed upload is not retried over its partial allocations (fsm_hip_dfa_free releases them): every later call fails with this */
 };
 
 /* GLOBAL layout: how much of the table head (rows nearest the start state) every workgroup
@@ -165,7 +168,7 @@ typedef std::lock_guard<std::recursive_mutex> DfaLock;
 static const fsm_hip_dfa *route(const fsm_hip_dfa *d, bool fixed_stride_fast)
 {
 	const fsm_hip_dfa *t = d->alt != nullptr && !fixed_stride_fast ? d->alt : d;
-	const_cast<fsm_hip_dfa *>(d)->last_used = t;
+	const_cast<fsm_hip_dfa *>(d)->last_used.store(t, std::memory_order_relaxed);
 	return t;
 }
 
@@ -363,7 +366,7 @@ static int dfa_upload(fsm_hip_dfa *d)
 				const uint64_t g = reinterpret_cast<uint64_t>(t) + p.sparse_img[5], bytes = (uint64_t)p.S1 * 16u;
 				if ((g >> 32) != ((g + bytes) >> 32)) d->sparse_fast_ok = false;
 			}
-			if (p.lazy_lds_bytes != 0 && p.lazy_lds_bytes <= d->lds_limit) {
+			if (p.lazy_lds_bytes != 0 && ((p.lazy_lds_bytes + 15u) & ~15u) + FSMHIP_LAZY_QBYTES <= d->lds_limit) {
 				HIP_TRY(upload(&d->d_lazy, p.lazy_img));
 				HIP_TRY(hipMalloc((void **)&d->d_lazy_ctr, LAZY_CTRS * sizeof(uint32_t)));
 				a.lazy = d->d_lazy;
@@ -463,18 +466,20 @@ static int dfa_upload(fsm_hip_dfa *d)
 	HIP_TRY(hipEventCreate(&d->ev0));
 	HIP_TRY(hipEventCreate(&d->ev1));
 	HIP_TRY(hipStreamCreateWithFlags(&d->hs, hipStreamNonBlocking));
-	d->uploaded = true;
+	d->uploaded.store(true, std::memory_order_release);
 	return 0;
 fail:
+	d->upload_errno = errno != 0 ? errno : EIO;
 	return -1;
 }
 
 static int ensure_uploaded(const fsm_hip_dfa *cd)
 {
-	if (cd->uploaded) return 0;
+	if (cd->uploaded.load(std::memory_order_acquire)) return 0;
 	fsm_hip_dfa *d = const_cast<fsm_hip_dfa *>(cd);
 	DfaLock lk(d->mu);
-	if (d->uploaded) return 0;
+	if (d->uploaded.load(std::memory_order_relaxed)) return 0;
+	if (d->upload_errno != 0) { errno = d->upload_errno; return -1; }
 	DevGuard dg(d->device);
 	if (!dg.ok()) { errno = ENODEV; return -1; }
 	return dfa_upload(d);
@@ -618,6 +623,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	    (stride / 16u) % 4u == 0) {
 		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
 		c.mode = IN_LAZY;
+		c.nt = d->knob_nt > 0;      /* nontemporal input loads: A/B knob (FSM_HIP_KNOB_NT) */
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
 		c.nb = 4;
 		c.waves = 16;
@@ -625,14 +631,19 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
 		return c;
 	}
-	if (layout == FSM_HIP_LAYOUT_SPARSE && !eager && d->d_lazy != nullptr && d->knob_sparse_fast == 3 && d->knob_input_mode < 0 && d->knob_lazy_lines) {
+	if (layout == FSM_HIP_LAYOUT_SPARSE && !eager && d->d_lazy != nullptr && d->knob_sparse_fast == 3 && d->knob_input_mode < 0 && d->knob_lazy_lines && !many) {   /* (many: 2^32 inputs or more -- its queue entries hold 32-bit indexes) */
 		/* ... and on everything else such an automaton is asked (round 5): inputs of any length and metadata form, strides that
 		 * are not a multiple of 64, unaligned rows, resumed walks -- one input per lane slot with lane refill (walk_lazy_lines) */
 		c.mode = IN_LAZY_LINES;
 		c.lazy_abs = d->plan.lazy_img[11] != 0 || resumed;   /* a resumed input may start in DEAD */
-		c.nb = 4;
+		/* whole chunks per slot and turn: 4, or 2 where the inputs are short (launch_walk decides -- on the device where the host
+		 * cannot know: 8-64 byte lines 410 against 364 GB/s, 0-1024 bytes 533 against 557; FSM_HIP_KNOB_NB forces one) */
+		c.nb = d->knob_nb == 2 ? 2 : 4;
 		c.waves = 16;
-		c.lds = d->plan.lazy_lds_bytes;
+		/* the table + the wavefronts' queues: all the LDS there is (plan.cpp leaves at least FSMHIP_LAZY_QBYTES: 112 entries per
+		 * wavefront; the kernel uses up to 128) */
+		c.lds = ((d->plan.lazy_lds_bytes + 15u) & ~15u) + 16u * 128u * 16u;
+		if (c.lds > d->lds_limit) c.lds = d->lds_limit;
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
 		return c;
 	}
@@ -809,22 +820,31 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const bool lines_cand = !eager && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr) &&
 		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len) && d->plan.layout != FSM_HIP_LAYOUT_SPARSE;   /* (launch.h lines32_ok) */
 	int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
-	if (fits32 < 0) {
-		/* a device front with u64 offsets / lengths alone: the batch's size is on the device -- but it cannot end beyond the
+	bool skip_generic = false;
+	if (fits32 < 0 && pick_len) {
+		/* a device front with u64 offsets / lengths alone: the batch's size is on the device -- but it should not end beyond the
 		 * ALLOCATION its base points into.  Fewer than 4 GiB from the base to the allocation's end (every batch but a huge one in
-		 * a huge block): walk_generic's own body is not needed and is not launched.  (Not asked during a stream capture: the
-		 * query is not a stream operation, and an API that is not may end a capture.) */
+		 * a huge block): walk_generic's own body is not needed and is not launched.  The reported range is a HINT, not a proof
+		 * (memory mapped in pieces may report one piece): fits32 stays "unknown", offsets_pick still looks at the batch's last
+		 * offset, and is told that walk_generic was not launched (cand bit 2 clear) -- a batch of 4 GiB and more then goes to
+		 * walk_ragged, which is launched and takes any batch; where walk_ragged is no candidate walk_generic is always launched.
+		 * (Not asked during a stream capture: the query is not a stream operation, and an API that is not may end a capture.) */
 		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
 		if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
 			hipDeviceptr_t ab = nullptr;
 			size_t asz = 0;
 			if (hipMemGetAddressRange(&ab, &asz, (hipDeviceptr_t)const_cast<uint8_t *>(a.base)) == hipSuccess && ab != nullptr) {
 				const uint64_t room = reinterpret_cast<uint64_t>(ab) + asz - reinterpret_cast<uint64_t>(a.base);
-				if (room < ((uint64_t)1 << 32)) fits32 = 1;
+				if (room < ((uint64_t)1 << 32)) skip_generic = true;
 			} else (void)hipGetLastError();
 		} else (void)hipGetLastError();
 	}
-	const bool pick = pick_len || fits32 < 0;
+	/* the lazy walk on variable-length inputs: two forms, 2 or 4 whole chunks a turn; the hand-over is at a mean of 56 bytes */
+	const uint32_t lazy_mean = 56u;
+	const bool lazy_lines = c.mode == IN_LAZY_LINES && varlen && d->knob_nb <= 0;
+	const bool lazy_pick = lazy_lines && known_bytes == 0 && !hint.short_mean;
+	const bool lazy_short = lazy_lines && !lazy_pick && (known_bytes != 0 ? known_bytes / a.n < lazy_mean : hint.short_mean);
+	const bool pick = pick_len || fits32 < 0 || lazy_pick;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events, the flag ring and the tile-base block are per dfa */
@@ -842,8 +862,11 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		a.pick_flag = md->d_pick + (md->pick_next++ % PICK_FLAGS);
 		a.skip_flag = a.pick_flag;
 		/* bit 0: walk_ragged is a candidate (else every batch counts as short); bit 1: so is walk_lines32 */
-		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)pick_mean_of(d, false), (uint32_t)pick_mean_of(d, true),
-		                   (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u));
+		if (lazy_pick)   /* PICK_GENERIC = the short form, PICK_RAGGED = the long one */
+			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, lazy_mean, lazy_mean, 1u | 4u);
+		else
+			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)pick_mean_of(d, false), (uint32_t)pick_mean_of(d, true),
+			                   (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u) | (fits32 != 1 && !skip_generic ? 4u : 0u));
 		e = hipGetLastError();
 	}
 	/* the per-lane kernels (short inputs): walk_generic unless the batch is known to fit 32 bits, walk_lines32 unless known not to */
@@ -851,7 +874,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	if (e == hipSuccess && per_lane) {
 		const LaunchCfg g0 = c.mode == IN_GENERIC ? c : pick_cfg(d, false, a.stride, eager, true, false);
 		for (int w32 = 0; w32 < 2 && e == hipSuccess; w32++) {
-			if (w32 ? fits32 == 0 : fits32 == 1) continue;
+			if (w32 ? fits32 == 0 : (fits32 == 1 || skip_generic)) continue;
 			WalkArgs ag = a;
 			ag.run_when = w32 ? PICK_LINES32 : PICK_GENERIC;
 			LaunchCfg g = g0;
@@ -881,12 +904,24 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		}
 		debug_stage(s, "walk (per-lane)");
 	}
+	if (e == hipSuccess && lazy_pick) {
+		/* the short form beside the long one (below); offsets_pick lets one of them run */
+		LaunchCfg c2 = c;
+		c2.nb = 2;
+		WalkArgs a2 = a;
+		a2.run_when = PICK_GENERIC;
+		c2.kfn = nullptr;
+		e = launch_layout(d, eager, c2, a2, dim3((unsigned)nblocks), dim3((unsigned)c2.waves * 64u), s);
+		if (e == hipSuccess) md->last_kernel_pick[PICK_GENERIC] = kernel_name(c2.kfn, s);
+	}
 	if (e == hipSuccess && c.mode != IN_GENERIC) {
+		LaunchCfg cl = c;
+		if (lazy_short) cl.nb = 2;
 		a.run_when = PICK_RAGGED;
-		c.kfn = nullptr;
-		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
+		cl.kfn = nullptr;
+		e = launch_layout(d, eager, cl, a, dim3((unsigned)nblocks), dim3((unsigned)cl.waves * 64u), s);
 		if (e == hipSuccess) {
-			md->last_kernel = kernel_name(c.kfn, s);
+			md->last_kernel = kernel_name(cl.kfn, s);
 			md->last_kernel_pick[PICK_RAGGED] = md->last_kernel;
 		}
 		debug_stage(s, "walk");
@@ -1094,7 +1129,7 @@ extern "C" int fsm_hip_exec_batch_lengths_device(const struct fsm_hip_dfa *d,
 extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return "";
-	if (d->last_used != nullptr && d->last_used != d) return fsm_hip_last_kernel_name(d->last_used);   /* the launch went to the second image */
+	if (const fsm_hip_dfa *lu = d->last_used.load(std::memory_order_relaxed); lu != nullptr && lu != d) return fsm_hip_last_kernel_name(lu);   /* the launch went to the second image */
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);
 	if (md->last_pick_flag != nullptr) {
@@ -1119,7 +1154,7 @@ extern "C" const char *fsm_hip_last_kernel_name(const struct fsm_hip_dfa *d)
 extern "C" double fsm_hip_last_kernel_ms(const struct fsm_hip_dfa *d)
 {
 	if (d == nullptr) return -1.0;
-	if (d->last_used != nullptr && d->last_used != d) return fsm_hip_last_kernel_ms(d->last_used);
+	if (const fsm_hip_dfa *lu = d->last_used.load(std::memory_order_relaxed); lu != nullptr && lu != d) return fsm_hip_last_kernel_ms(lu);
 	DfaLock lk(const_cast<fsm_hip_dfa *>(d)->mu);
 	if (!d->timed) return -1.0;
 	float ms = 0.f;

@@ -51,7 +51,9 @@ static inline hipError_t launch_fn(walk_fn k, const LaunchCfg &c, const WalkArgs
 	}
 	hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, grid, block, c.lds, s, a);
+	WalkArgs b = a;
+	b.lds_bytes = c.lds;
+	hipLaunchKernelGGL(k, grid, block, c.lds, s, b);
 	c.kfn = (const void *)k;
 	return hipGetLastError();
 }

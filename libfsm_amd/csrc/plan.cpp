@@ -144,12 +144,71 @@ try {
 		std::vector<uint8_t> vis(S1, 0);
 		vis[d->start] = 1;
 		q.push_back(d->start);
+		std::vector<uint32_t> lvl(S1, 0);
 		for (size_t h = 0; h < q.size(); h++) {
 			uint32_t s = q[h];
 			const uint32_t *row = &nx[(size_t)s * 256];
 			for (uint32_t c = 0; c < C; c++) {
 				uint32_t t = row[rep[c]];
-				if (!vis[t]) { vis[t] = 1; q.push_back(t); }
+				if (!vis[t]) { vis[t] = 1; lvl[t] = lvl[s] + 1u; q.push_back(t); }
+			}
+		}
+		/* Big automata (a literal set's trie below its first levels): breadth-first numbering scatters a path over the levels --
+		 * the records of the states one word walks through lie megabytes apart, and a walk that has to fetch the record of every
+		 * deep state it enters (walk_lazy.h: the states from F up) pays a cold miss per byte: 8-64 byte lines of which every 8th
+		 * ends in a literal ran at 260 GB/s where lines without one ran at 410 (tests/tools/c5_lines_probe.py --plant 8).  Below
+		 * the levels that can matter for LDS residency (the ones holding the first 16 Ki states, and the level after them: the
+		 * first one a resident record leads to) the states are numbered depth-first by SIBLING BLOCKS: a state's children (in
+		 * the breadth-first tree, class order) get consecutive ids when the state is visited -- what the CONSEC records and the
+		 * lazy walk's first + rank arithmetic need, exactly as before -- and then the first child's subtree is numbered before
+		 * the second child's: along a chain of single-child states the ids are consecutive, eight 16-byte records to a memory
+		 * line. */
+		if (q.size() > 65536u && getenv("FSM_HIP_PLAN_BFS") == nullptr) {   /* (the variable: an A/B aid, breadth-first all the way down) */
+			std::vector<uint32_t> cnt;
+			for (uint32_t s : q) { if (lvl[s] >= cnt.size()) cnt.resize(lvl[s] + 1u, 0); cnt[lvl[s]]++; }
+			uint32_t keep = 0;          /* levels [0, keep) stay breadth-first */
+			uint64_t cum = 0;
+			while (keep < cnt.size() && cum + cnt[keep] <= 16384u) cum += cnt[keep++];
+			if (keep < cnt.size()) keep++;
+			if (keep < cnt.size()) {
+				/* children lists of the breadth-first tree, in discovery (= class) order: q itself, level by level, is that order */
+				std::vector<uint32_t> parent(S1, NOEDGE), first(S1, NOEDGE), nchild(S1, 0);
+				{
+					std::vector<uint8_t> v2(S1, 0);
+					v2[d->start] = 1;
+					for (size_t h = 0; h < q.size(); h++) {
+						const uint32_t s = q[h];
+						const uint32_t *row = &nx[(size_t)s * 256];
+						for (uint32_t c = 0; c < C; c++) {
+							const uint32_t t = row[rep[c]];
+							if (!v2[t]) { v2[t] = 1; parent[t] = s; }
+						}
+					}
+				}
+				/* the children of s are a contiguous run of q (breadth-first order): first[s] = where it starts */
+				for (size_t h = 1; h < q.size(); h++) {
+					const uint32_t t = q[h], ps = parent[t];
+					if (first[ps] == NOEDGE) first[ps] = (uint32_t)h;
+					nchild[ps]++;
+				}
+				std::vector<uint32_t> order;
+				order.reserve(q.size());
+				size_t h0 = 0;
+				while (h0 < q.size() && lvl[q[h0]] < keep) order.push_back(q[h0++]);
+				/* the states of level keep - 1, in order: each one's block of children, then depth-first below */
+				std::vector<uint32_t> stack;
+				for (size_t h = 0; h < h0; h++) {
+					if (lvl[q[h]] != keep - 1u) continue;
+					stack.push_back(q[h]);
+					while (!stack.empty()) {
+						const uint32_t s = stack.back();
+						stack.pop_back();
+						if (nchild[s] == 0) continue;
+						for (uint32_t k = 0; k < nchild[s]; k++) order.push_back(q[first[s] + k]);
+						for (uint32_t k = nchild[s]; k-- > 0;) stack.push_back(q[first[s] + k]);   /* the first child's subtree first */
+					}
+				}
+				if (order.size() == q.size()) q.swap(order);
 			}
 		}
 		for (uint32_t s = 0; s < S; s++) if (!vis[s]) q.push_back(s); /* unreachable */
@@ -782,6 +841,11 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 
 	/* 1. the LDS set: the longest prefix of states (breadth-first from the start state) whose excepted targets are
 	 * consecutive ids, and whose X + b stays inside the set for every bit b */
+	/* the variable-length kernel keeps its queue of input tails behind the table (walk_lazy.h FSMHIP_LAZY_QBYTES: 16 wavefronts x
+	 * 112 entries x 16 bytes): the image is planned into what that leaves */
+	const uint32_t queue_bytes = 16u * 112u * 16u;
+	if (lds_limit <= queue_bytes) return;
+	lds_limit -= queue_bytes;
 	const uint32_t room = lds_limit > 1024u + 16384u + 32u ? lds_limit - 1024u - 16384u - 32u : 0u;
 	const uint32_t Hcap = room / 16u;
 	std::vector<FRec> LR;

@@ -16,7 +16,10 @@
 namespace fsmhip {
 
 /* cand bit 0: walk_ragged is a candidate (else every batch goes to a per-lane kernel); bit 1: walk_lines32 is one -- taken for a
- * short-lines batch that ends below 4 GiB (its last offset, not its size: the kernel's offsets are relative to the base) */
+ * short-lines batch that ends below 4 GiB (its last offset, not its size: the kernel's offsets are relative to the base);
+ * bit 2: walk_generic was launched (the host leaves it out where the allocation behind the base suggests that no batch can reach
+ * 4 GiB -- a hint: a short-lines batch that does reach it then goes to walk_ragged, which the host launches in that case).
+ * Only a kernel that was launched is ever picked: a flag naming another would leave the outputs unwritten. */
 __global__ void __launch_bounds__(256)
 offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t threshold32, uint32_t cand)
 {
@@ -44,7 +47,7 @@ offsets_pick(const WalkArgs a, uint32_t threshold, uint32_t threshold32, uint32_
 		const uint64_t mean = bytes / (cnt ? cnt : 1u);
 		const bool l32 = (cand & 2u) && last < ((uint64_t)1 << 32);
 		const bool shrt = !(cand & 1u) || mean < (l32 ? threshold32 : threshold);
-		*a.pick_flag = !shrt ? (uint32_t)PICK_RAGGED : l32 ? (uint32_t)PICK_LINES32 : (uint32_t)PICK_GENERIC;
+		*a.pick_flag = !shrt ? (uint32_t)PICK_RAGGED : l32 ? (uint32_t)PICK_LINES32 : (cand & 4u) || !(cand & 1u) ? (uint32_t)PICK_GENERIC : (uint32_t)PICK_RAGGED;
 	}
 }
 

@@ -112,6 +112,7 @@ struct WalkArgs {
 	/* sparse layout, lazy form (walk_lazy.h): the image of plan.cpp build_lazy; a zeroed tile counter, or NULL */
 	const void     *lazy;
 	uint32_t       *tile_ctr;
+	uint32_t        lds_bytes;   /* dynamic LDS of this launch (launch.h launch_fn fills it in): walk_lazy_lines sizes its queues by what lies behind the table */
 };
 
 #define FSMHIP_STATE_START 0xFFFFFFFDu

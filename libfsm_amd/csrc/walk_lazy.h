@@ -187,7 +187,7 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 /* ROWS inputs per lane (independent chains: the instruction-level parallelism a second workgroup per CU would give),
  * NB 16-byte chunks per row in flight.  a.tile_ctr != NULL: the wavefronts claim their tiles of 64 * ROWS inputs from that
  * counter (zeroed on the launch stream) instead of striding: the tail of the persistent grid balances to one tile. */
-template <bool ABS, int ROWS, int NB>
+template <bool ABS, int ROWS, int NB, bool NT = false>
 __global__ void __launch_bounds__(1024)
 walk_lazy(const WalkArgs a)
 {
@@ -246,7 +246,7 @@ walk_lazy(const WalkArgs a)
 #pragma unroll
 			for (int j = 0; j < NB; j++)
 #pragma unroll
-				for (int r = 0; r < ROWS; r++) cur[j][r] = q[r][g * NB + j];
+				for (int r = 0; r < ROWS; r++) cur[j][r] = NT ? __builtin_nontemporal_load(&q[r][g * NB + j]) : q[r][g * NB + j];
 #pragma unroll
 			for (int j = 0; j < NB; j++) {
 				uint32_t sh[ROWS][16];
@@ -304,29 +304,40 @@ walk_lazy(const WalkArgs a)
  * wavefronts claim pieces of LAZY_PIECE consecutive inputs from the launch's counter, a slot in need takes the piece's next
  * input by its rank among the needy lanes (one ballot + mbcnt; the lengths-only front adds a wavefront prefix sum over the
  * takers' lengths to a running byte offset), so the 64 x ROWS inputs in flight stay within a few KB of one another whatever
- * their lengths.  Per turn every slot loads its next NB 16-byte chunks from its own byte address (global loads: an input
- * starts anywhere; the chunk that would reach beyond the batch's last byte is assembled byte by byte) and the chunks are
- * walked in lockstep; a chunk in which some lane's input ends takes the TAIL form of the step.  Results are written by the
- * lane when its input ends (the accept bitmap by atomic OR: cleared on the launch stream).
+ * their lengths.
  *
- * Measured (1e5-literal automaton, 2e7 lines of 0-1024 bytes, profiles/r07d_*): 524 GB/s where walk_ragged<SparsePol> gave 153
- * and the fixed-stride lazy walk does 889.  With 64 x ROWS inputs per wavefront some input ends in 98 % of the chunk steps, so
- * nearly every step is the masked one: 30.75 vector instructions per byte against 23.6, and 40.6 per USEFUL byte with the
- * refill, the loads and the slots idle at a turn's end (the fixed-stride walk: 25); waits are 72 % of the wave cycles at four
- * wavefronts per SIMD.  Two cheaper-looking forms were built and dropped (same box, same lines):
- *   - chunks aligned to the input's END (the partial chunk first, only a turn's first step masked): 37 instructions per
- *     useful byte but 128 VGPRs + 112 bytes of scratch -- 470 GB/s;
- *   - unmasked steps, the state caught as it passes the input's last byte (+ 2 instructions per byte, not + 7): the
- *     compiler parks the turn's later chunks in scratch (192-224 bytes, loads and stores inside the step blocks) -- not run.
- * The budget is the 128 registers of a 16-wave workgroup beside a 131 KiB table: two chains of walk state, their four chunks
- * and the 64-bit cursor / length / index of a slot leave nothing for a third form of the step.
+ * Round 6: WHOLE chunks and TAILS part ways.  Round 5's kernel walked every slot's next NB chunks in lockstep and masked the
+ * bytes beyond an input's end inside the step -- and with 64 x ROWS inputs per wavefront some input ends in 98 % of the chunk
+ * steps, so nearly every step was the masked one (30.75 vector instructions per byte against 25.2, 40.6 per USEFUL byte:
+ * profiles/r07d_*).  Now
+ *   - a turn walks, per slot, the next min(NB, rem / 16) WHOLE 16-byte chunks of its input (all asked for at once at the turn's
+ *     head, from the input's own byte address: whole chunks lie inside the input, no edge case) with the UNMASKED step of the
+ *     fixed-stride kernel.  A slot with fewer than NB whole chunks left walks zeros after them; its state is snapshotted at
+ *     the chunk boundary (one compare + two selects per CHUNK, not per byte) and restored at the turn's end;
+ *   - the last rem % 16 bytes of an input -- its TAIL -- are not walked by the slot: (input index, state, byte offset, count)
+ *     goes into a per-wavefront queue in LDS (16 bytes an entry behind the table: plan.cpp leaves the room), the slot takes the
+ *     next input at once, and when the queue cannot take a row's tails the wavefront walks up to 64 queued tails at once, one
+ *     per lane, with the masked form of the step: one masked step per 64 inputs instead of one per chunk.  Inputs shorter
+ *     than 16 bytes are all tail: they go from the piece to the queue.
+ * Memory traffic other than the own-record gathers happens at the turn's head only: the vector memory counter retires in
+ * order, so any load in flight delays the first gather wait behind it (a chunk asked for per step instead of NB per turn
+ * measured 12 % slower on 1 KiB lines).
+ * Measured, 4 GB of lines on the 1e5-literal automaton (tests/tools/c5_lines_probe.py; round 5's kernel: 523 / 243 GB/s on the
+ * first two): 0-1024 bytes 559, 8-64 bytes 363; all 1024 bytes 754, all 64 bytes 770 (the fixed-stride kernel: 900).
+ * Built and dropped: a slot changing inputs in MID-turn (its next input chosen at the turn's head, the old input's queue entry
+ * pre-written and the state ORed in at the step its whole chunks end): no idle slots, but the bookkeeping costs more than
+ * they did -- 565 / 308 on the same two mixes, 618 on 64-byte lines.
+ * Results are written by the lane that finishes an input (the accept bitmap by atomic OR: cleared on the launch stream).
  */
 #define FSMHIP_LAZY_PIECE 256u
+#define FSMHIP_LAZY_QMIN 112u                                          /* queue entries per wavefront that plan.cpp guarantees */
+#define FSMHIP_LAZY_QBYTES (16u * FSMHIP_LAZY_QMIN * 16u)              /* 16 wavefronts x 112 entries x 16 bytes = 28 KiB of LDS behind the table */
 
 template <bool ABS, int ROWS, int NB>
 __global__ void __launch_bounds__(1024)
 walk_lazy_lines(const WalkArgs a)
 {
+	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* the other form of this kernel took the batch (fsm_hip.hip launch_walk) */
 	extern __shared__ __align__(16) unsigned char lds[];
 	const uint32_t *lz = static_cast<const uint32_t *>(a.lazy);
 	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
@@ -358,28 +369,97 @@ walk_lazy_lines(const WalkArgs a)
 	const uint64_t safe = reinterpret_cast<uint64_t>(a.btab);
 	typedef u32x4 __attribute__((aligned(1))) u32x4_any;
 	typedef const u32x4_any __attribute__((address_space(1))) *glb_chunk_p;
+	typedef u32x4 __attribute__((address_space(3))) *lds_q_p;
+
+	/* the wavefront's tail queue: entry = {input index, tail offset lo, state id | tail length << 24, E | tail offset hi << 16}
+	 * (state ids < 2^24: plan.cpp; E <= H < 2^16; the offset is relative to the batch's base: < 2^48; fewer than 2^32 inputs: the
+	 * host checks).  As many entries as the LDS behind the table holds (a.lds_bytes: this launch's), 128 at most. */
+	const uint32_t qoff = (lz[6] + 15u) & ~15u, nwv = blockDim.x >> 6;
+	uint32_t qcap = (a.lds_bytes - qoff) / (16u * nwv);
+	qcap = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcap < 128u ? qcap : 128u));
+	const uint32_t qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qoff + (threadIdx.x >> 6) * (qcap * 16u)));
+	uint32_t qcount = 0;
+
+	/* up to 64 queued tails, one per lane, the masked step; the results are final.  (Two per lane -- up to 128 a pass -- measured
+	 * SLOWER wherever tails are many: 329 against 363 GB/s on 8-64 byte lines, 453 against 544 on 37-byte ones.) */
+	auto flush = [&]() {
+		const uint32_t m = qcount < 64u ? qcount : 64u;
+		const bool have = lane < m;
+		qcount -= m;
+		const u32x4 e = *(lds_q_p)(uintptr_t)(qbase + (qcount + (have ? lane : 0u)) * 16u);
+		const uint32_t fli = e.x, id0 = e.z & 0xFFFFFFu, E0 = e.w & 0xFFFFu;
+		const uint32_t cnt = have ? (e.z >> 24) & 15u : 0u;
+		const uint64_t ad = base + (e.y | ((uint64_t)(e.w >> 16) << 32));
+		u32x4 w = u32x4{0u, 0u, 0u, 0u};
+		if (have) {
+			if (ad + 16u <= limit) w = *(glb_chunk_p)ad;
+			else w = load_chunk_edge(ad, true, limit, safe);
+		}
+		LazyState s = lazy_enter(cx, id0, E0);
+		uint32_t sh[16], bacc = 0u;
+#pragma unroll
+		for (int k = 0; k < 16; k++) sh[k] = *(lazy_u32_p)(uintptr_t)(byte_of(w, k) * 4u);
+#pragma unroll
+		for (int k = 0; k < 16; k++) bacc |= (uint32_t)k < cnt ? sh[k] : 0u;
+#pragma unroll
+		for (int k = 0; k < 16; k++) lazy_step<ABS, true>(cx, s, sh[k], bacc, (uint32_t)k < cnt);
+		if (__builtin_amdgcn_ballot_w64((int32_t)bacc < 0) != 0u) {
+			if ((int32_t)bacc < 0) {
+				uint32_t cid = id0, cE = E0;
+				lazy_careful<ABS>(cx, simg, car, cid, cE, w, cnt);
+				s.id = cid;
+			}
+		}
+		if (have) write_result_lane(a, fli, s.id);
+	};
+	/* the lanes with p set queue their tails (cnt in 1..15 bytes at cur); the queue is walked first when they do not fit */
+	auto push = [&](bool p, uint32_t li, uint32_t id, uint32_t E, uint64_t cur, uint32_t cnt) {
+		const uint64_t pm = __ballot(p);
+		if (pm == 0u) return;
+		const uint32_t k = (uint32_t)__popcll(pm);
+		if (qcount + k > qcap) flush();       /* (more than qcap - 64 >= 48 queued: 64 of them walked, or all -- and k <= 64 fit) */
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+		if (p) {
+			const uint64_t rel = cur - base;
+			*(lds_q_p)(uintptr_t)(qbase + (qcount + rank) * 16u) = u32x4{li, (uint32_t)rel, id | (cnt << 24), E | ((uint32_t)(rel >> 32) << 16)};
+		}
+		qcount += k;
+	};
 
 	/* the wavefront's piece: inputs [pnext, pend); run = byte offset of input pnext (lengths-only front) */
 	uint64_t pnext = 0, pend = 0, run = 0;
 	bool more = true;
 
-	uint64_t li[ROWS], cur[ROWS], rem[ROWS];
+	uint32_t li[ROWS], rem[ROWS];     /* rem: bytes left, or 0xFFFFFFF0 while an input has that many and more (the retire step asks again) */
+	uint64_t cur[ROWS];
 	bool act[ROWS];
 	LazyState st[ROWS];
 #pragma unroll
 	for (int r = 0; r < ROWS; r++) {
-		li[r] = 0; cur[r] = safe; rem[r] = 0; act[r] = false;
+		li[r] = 0; cur[r] = base; rem[r] = 0; act[r] = false;
 		st[r] = lazy_enter(cx, a.start, a.start);
 	}
 
 	for (;;) {
-		/* ---- refill: ended inputs are written, free slots take the next inputs of the piece ---- */
+		/* ---- retire + refill: an input with fewer than 16 bytes left leaves its slot (no bytes left: its result is written;
+		 * else its tail is queued), free slots take the next inputs of the piece ---- */
 #pragma unroll
 		for (int r = 0; r < ROWS; r++) {
 			for (;;) {
-				if (act[r] && rem[r] == 0u) {
-					write_result_lane(a, li[r], st[r].id);
-					act[r] = false;
+				bool fin = act[r] && rem[r] < 16u;
+				if (__any(fin)) {
+					/* a piece of an input of 4 GiB and more has ended where the input has not (u64 offsets and fixed strides can say so;
+					 * lengths and u32 offsets cannot): it goes on with what is really left */
+					if (fin && rem[r] == 0u && (f_off || (!f_off32 && !f_lens && a.len == nullptr)) && !(ABS && (a.early & 1u) && st[r].id >= a.abs_min)) {
+						const uint64_t endb = f_off ? a.off[(uint64_t)li[r] + 1u] : ((uint64_t)li[r] + 1u) * a.stride;
+						const uint64_t left = base + endb - cur[r];
+						rem[r] = left > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)left;
+						fin = rem[r] < 16u;
+					}
+					if (fin && rem[r] == 0u) write_result_lane(a, li[r], st[r].id);
+					push(fin && rem[r] != 0u, li[r], st[r].id, st[r].E, cur[r], rem[r]);
+					act[r] = act[r] && !fin;
+					rem[r] = fin ? 0u : rem[r];
 				}
 				const uint64_t needm = __ballot(!act[r]);
 				if (needm == 0u) break;
@@ -412,12 +492,14 @@ walk_lazy_lines(const WalkArgs a)
 					else { beg = i * a.stride; len = a.len != nullptr ? a.len[i] : a.stride; }
 				}
 				if (take) {
-					li[r] = i;
+					li[r] = (uint32_t)i;
 					cur[r] = base + beg;
-					rem[r] = len;
+					rem[r] = len > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)len;
 					act[r] = true;
 					const uint32_t code = start_code(a, i, true);
 					st[r] = lazy_enter(cx, code, code < cx.H ? code : car[code < lz[13] ? code : 0u]);
+					/* an input that starts in an absorbing state is done (fsm_exec stops pulling bytes at a missing edge, exec.c:133-138) */
+					if (ABS && (a.early & 1u) && code >= a.abs_min) rem[r] = 0u;
 				}
 				const uint32_t k = (uint32_t)__popcll(needm);
 				pnext += k < avail ? k : avail;
@@ -428,68 +510,67 @@ walk_lazy_lines(const WalkArgs a)
 		for (int r = 0; r < ROWS; r++) anyact = anyact || act[r];
 		if (!__any(anyact)) break;
 
-		/* ---- the next NB chunks of every slot ---- */
+		/* ---- the next whole chunks of every slot (every active slot has at least one; a free slot has rem = 0: none) ---- */
 		u32x4 w[NB][ROWS];
 #pragma unroll
 		for (int j = 0; j < NB; j++)
 #pragma unroll
 			for (int r = 0; r < ROWS; r++) {
 				w[j][r] = u32x4{0u, 0u, 0u, 0u};
-				if (act[r] && rem[r] > 16u * (uint32_t)j) {
-					const uint64_t ad = cur[r] + 16u * (uint32_t)j;
-					if (ad + 16u <= limit) w[j][r] = *(glb_chunk_p)ad;
-					else w[j][r] = load_chunk_edge(ad, true, limit, safe);
-				}
+				if (rem[r] >= 16u * (uint32_t)(j + 1)) w[j][r] = *(glb_chunk_p)(cur[r] + 16u * (uint32_t)j);
 			}
 
+		/* (snid, snE): the state at the start of the chunk a slot is in while it has whole chunks, frozen from its last whole
+		 * chunk's end on -- what the exact re-walk of a chunk starts from, and what the slot goes back to at the turn's end */
+		uint32_t snid[ROWS], snE[ROWS];
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) { snid[r] = st[r].id; snE[r] = st[r].E; }
 #pragma unroll 1
 		for (uint32_t j = 0; j < (uint32_t)NB; j++) {
-			uint32_t cnt[ROWS];
-			bool some = false, full = true;
+			bool some = false;
 #pragma unroll
 			for (int r = 0; r < ROWS; r++) {
-				const uint64_t left = act[r] && rem[r] > 16u * j ? rem[r] - 16u * j : 0u;
-				cnt[r] = left < 16u ? (uint32_t)left : 16u;
-				some = some || cnt[r] != 0u;
-				full = full && cnt[r] == 16u;
+				const bool upto = rem[r] >= 16u * j;          /* chunk j, or the boundary right behind the slot's last whole chunk */
+				snid[r] = upto ? st[r].id : snid[r];
+				snE[r] = upto ? st[r].E : snE[r];
+				some = some || rem[r] >= 16u * j + 16u;
 			}
 			if (!__any(some)) break;
-			uint32_t sh[ROWS][16];
+			/* (the byte -> shift lookups eight bytes at a time, and their OR taken at once: left to itself the compiler ORs the
+			 * sixteen shifts into the sentinel word at the block's END and keeps them alive for it -- 40 registers, scratch) */
+			uint32_t bacc[ROWS];
 #pragma unroll
-			for (int r = 0; r < ROWS; r++)
+			for (int r = 0; r < ROWS; r++) bacc[r] = 0u;
 #pragma unroll
-				for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(w[0][r], k) * 4u);
-			uint32_t sid[ROWS], sE[ROWS], bacc[ROWS];
-#pragma unroll
-			for (int r = 0; r < ROWS; r++) { sid[r] = st[r].id; sE[r] = st[r].E; bacc[r] = 0u; }
-			if (__all(full)) {
+			for (int h = 0; h < 2; h++) {
+				uint32_t sh[ROWS][8];
 #pragma unroll
 				for (int r = 0; r < ROWS; r++)
 #pragma unroll
-					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
+					for (int k = 0; k < 8; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(w[0][r], 8 * h + k) * 4u);
 #pragma unroll
-				for (int k = 0; k < 16; k++)
+				for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+					for (int k = 0; k < 8; k++) bacc[r] |= sh[r][k];
+					__asm__ volatile("" : "+v"(bacc[r]));
+				}
+#pragma unroll
+				for (int k = 0; k < 8; k++)
 #pragma unroll
 					for (int r = 0; r < ROWS; r++) lazy_step<ABS, false>(cx, st[r], sh[r][k], bacc[r]);
-			} else {
-#pragma unroll
-				for (int r = 0; r < ROWS; r++)
-#pragma unroll
-					for (int k = 0; k < 16; k++) bacc[r] |= (uint32_t)k < cnt[r] ? sh[r][k] : 0u;
-#pragma unroll
-				for (int k = 0; k < 16; k++)
-#pragma unroll
-					for (int r = 0; r < ROWS; r++) lazy_step<ABS, true>(cx, st[r], sh[r][k], bacc[r], (uint32_t)k < cnt[r]);
 			}
 			uint32_t ball = 0;
 #pragma unroll
-			for (int r = 0; r < ROWS; r++) ball |= bacc[r];
+			for (int r = 0; r < ROWS; r++) {
+				bacc[r] = rem[r] >= 16u * j + 16u ? bacc[r] : 0u;       /* (whatever the zeros past a slot's chunks met is nobody's business) */
+				ball |= bacc[r];
+			}
 			if (__builtin_amdgcn_ballot_w64((int32_t)ball < 0) != 0u) {
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) {
 					if ((int32_t)bacc[r] < 0) {
-						uint32_t cid = sid[r], cE = sE[r];
-						lazy_careful<ABS>(cx, simg, car, cid, cE, w[0][r], cnt[r]);
+						uint32_t cid = snid[r], cE = snE[r];
+						lazy_careful<ABS>(cx, simg, car, cid, cE, w[0][r]);
 						st[r] = lazy_enter(cx, cid, cE);
 					}
 				}
@@ -502,13 +583,18 @@ walk_lazy_lines(const WalkArgs a)
 		}
 #pragma unroll
 		for (int r = 0; r < ROWS; r++) {
-			const uint64_t adv = rem[r] < 16u * (uint32_t)NB ? rem[r] : 16u * (uint32_t)NB;
+			/* a slot that ran out of whole chunks inside the turn goes back to where they ended (the filter word / A / D of the state
+			 * it is in are re-read either way: a state entered through an own-record exception carries A for a word it never read) */
+			const bool back = rem[r] < 16u * (uint32_t)NB;
+			st[r] = lazy_enter(cx, back ? snid[r] : st[r].id, back ? snE[r] : st[r].E);
+			const uint32_t adv = back ? rem[r] & ~15u : 16u * (uint32_t)NB;
 			cur[r] += adv;
 			rem[r] -= adv;
 			/* an absorbing state ends the input early (fsm_exec stops pulling bytes at a missing edge, exec.c:133-138) */
 			if (ABS && (a.early & 1u) && act[r] && st[r].id >= a.abs_min) rem[r] = 0u;
 		}
 	}
+	while (qcount != 0u) flush();
 }
 
 } // namespace fsmhip
