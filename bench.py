@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged", "c3_eager40"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c3u", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged", "c3_eager40"],
                     help="c*_short / c*_ragged: the packed-lines front alone (what the default run reports as sub_results), for profiling")
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
@@ -78,6 +78,8 @@ def parse():
 
 def c3_affixes(which="c3"):
     pats = bytes(np.load(os.path.join(ROOT, "tests", "golden", which + ".npz"))["patterns"]).split(b"\n")
+    if which == "c3u":   # unanchored patterns <letters>[0-9]$: no prefix; a row accepted by pattern i ends with its letters + the digit i % 10
+        return [b""], [p[:p.index(b"[")] + str(i % 10).encode() for i, p in enumerate(pats)]
     return [p[1:p.index(b"[" if which == "c3" else b"(")] for p in pats], [b"x", b"yz"]
 
 
@@ -144,6 +146,10 @@ def generate(hip, workload, d_ptr, n, L, first, words=None, buf=None):
     elif workload == "c3t":   # pattern rows alternate digit / [a-f] after the prefix: a state change on every byte
         pf, sf = c3_affixes("c3t")
         hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
+    elif workload == "c3u":   # every row random over [a-z0-9]; every 2nd one ends with a pattern's letters + a digit
+        pf, sf = c3_affixes("c3u")
+        al = os.environ.get("FSM_BENCH_C3U_ALPHA", "").encode() or ALNUM       # (a measurement aid: e.g. digits only = a walk that never leaves the first rows)
+        hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, al, al, pf, sf, 2)
     else:
         pf, sf = c3_affixes()
         hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
@@ -159,6 +165,10 @@ def generate_host(hip, workload, n, L, first, words=None):
     if workload == "c3t":
         pf, sf = c3_affixes("c3t")
         return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
+    if workload == "c3u":
+        pf, sf = c3_affixes("c3u")
+        al = os.environ.get("FSM_BENCH_C3U_ALPHA", "").encode() or ALNUM
+        return hip.gen_affix_inputs_host(n, L, first, SEED, al, al, pf, sf, 2)
     pf, sf = c3_affixes()
     return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
 
@@ -201,7 +211,7 @@ def kernels_sha16():
     # everything that decides what a launch fetches: the kernels, which kernel / grid / workgroup a launch gets
     # (fsm_hip.hip pick_cfg / waves_by_occupancy, launch.h, kern_*.hip), the table layouts (plan.cpp) and the other fronts
     for f in ("walk_kernels.h", "walk_lazy.h", "walk_aux.h", "launch.h", "fsm_hip.hip", "plan.cpp", "plan.h", "multi.hip",
-              "kern_tiny.hip", "kern_lds.hip", "kern_comb.hip", "kern_glob.hip"):
+              "kern_tiny.hip", "kern_lds.hip", "kern_comb.hip", "kern_glob.hip", "kern_glob16.hip"):
         with open(os.path.join(ROOT, "libfsm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -386,7 +396,7 @@ def node_front(a):
     import libfsm_amd as hip
     hip.load_library()
     L = a.len
-    wl = a.workload if a.workload in ("c2", "c3", "c3t") else "c3"
+    wl = a.workload if a.workload in ("c2", "c3", "c3t", "c3u") else "c3"
     flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
     ndev = torch.cuda.device_count()
     devices = list(range(ndev))
@@ -557,6 +567,9 @@ WORKLOAD_TEXT = {
     "c3": "c3: BASELINE configs[2] -- 1024 anchored PCRE unioned into one %d-state DFA, ",
     "c3t": ("c3t: the transition-dense twin of configs[2] -- 1024 patterns ^<pfx>([0-9][a-f])+(x|yz)$ unioned into one %d-state DFA, "
             "half the rows alternating digit / letter so that a live row changes state on EVERY byte, "),
+    "c3u": ("c3u: the UNANCHORED (rx-style, src/rx/main.c:487-566) twin of configs[2] -- 1024 patterns <3-4 letters>[0-9]$ with the implicit "
+            "leading .* unioned into one complete %d-state DFA (no DEAD default, a state change on almost every byte), rows random over [a-z0-9], "
+            "every 2nd one ending in a pattern, "),
     "c5": "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), ",
 }
 
@@ -750,7 +763,7 @@ def main():
                                       f"workload at this size (kernel {str(t.get('kernel'))[:60]}); recorded, not measured in this run")
             except Exception:
                 traffic = None
-        text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl in ("c3", "c3t") else (len(words), flat.nstates) if wl == "c5" else ())
+        text = WORKLOAD_TEXT[wl] % ((flat.nstates,) if wl in ("c3", "c3t", "c3u") else (len(words), flat.nstates) if wl == "c5" else ())
         if variant == "noskip":
             text += "chunk skip disabled (every byte pays its self-loop test: the transition-dense bound of this table), "
         if variant == "loadskip":
@@ -1153,7 +1166,7 @@ def main():
         if a.workload == "c3":
             plan.append(("c3", "noskip", None))
             plan.append(("c3", "loadskip", None))
-        for wl in ("c3", "c3t", "c2", "c5"):
+        for wl in ("c3", "c3t", "c3u", "c2", "c5"):
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
         # the short / packed front of retest and rx, at steady-state size, on the C2 and C3 tables

@@ -86,7 +86,9 @@ enum {
 	FSM_HIP_PLAN_EW_MASK     = 21, /* u64[] */
 	FSM_HIP_PLAN_TINY5_COL   = 22, /* u32[256], <= 6 states: 5-bit fields of 5 * next state */
 	FSM_HIP_PLAN_COMB_RNG    = 23, /* u16[] by comb row offset: self-loop byte range lo | hi << 8 (0x0080: none) */
-	FSM_HIP_PLAN_LAZY        = 24  /* u32[] image of the sparse layout's lazy form (plan.cpp build_lazy); empty: the automaton has none */
+	FSM_HIP_PLAN_LAZY        = 24, /* u32[] image of the sparse layout's lazy form (plan.cpp build_lazy); empty: the automaton has none */
+	FSM_HIP_PLAN_GLOB_TAB16  = 25, /* u16[S1*C], global layout of an automaton of <= 65 535 states: the next state's ROW (empty otherwise) */
+	FSM_HIP_PLAN_GLOB16_RANK = 26  /* u32[S1]: the row of every renumbered state in that table (rows in visit-frequency order); empty: row = state */
 };
 
 /* lds_limit 0 = 160 KiB (gfx950).  NULL + errno on failure. */

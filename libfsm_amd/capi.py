@@ -316,7 +316,7 @@ class Plan:
                  comb256=(12, np.uint32), comb256_off=(13, np.uint32), comb256_fin=(14, np.uint32), comb_smask=(15, np.uint32),
                  emask=(16, np.uint64), eager_ids=(17, np.uint32), sparse=(18, np.uint32),
                  ew_off=(19, np.uint32), ew_word=(20, np.uint32), ew_mask=(21, np.uint64), tiny5_col=(22, np.uint32),
-                 comb_rng=(23, np.uint16), lazy=(24, np.uint32))
+                 comb_rng=(23, np.uint16), lazy=(24, np.uint32), glob_tab16=(25, np.uint16), glob16_rank=(26, np.uint32))
 
     def __init__(self, flat: FlatDfa, flags: int = 0, lds_limit: int = 0):
         lib = load_library()

@@ -93,6 +93,7 @@ struct fsm_hip_dfa {
 	int knob_input_mode = -1;    /* -1 auto */
 	int knob_nb = 0;             /* 0 auto */
 	uint32_t glob_row_bytes = 4;
+	bool glob16 = false;         /* GLOBAL layout, <= 65 535 states: 2-byte entries (Glob16Pol) */
 	uint64_t glob_tab_bytes = 0;
 	int knob_seg = 0;            /* 0 auto (128) */
 	int knob_prefetch = -1;      /* -1 auto (on) */
@@ -123,7 +124,10 @@ static void set_hot_bytes(fsm_hip_dfa *d, uint32_t want)
 {
 	uint64_t hot = want;
 	if (hot > d->glob_tab_bytes) hot = d->glob_tab_bytes;
-	if (hot + lds_bytes_btab() + 8u * 4096u > d->lds_limit) hot = d->lds_limit - lds_bytes_btab() - 8u * 4096u;
+	/* (the 4-byte table leaves room for eight wavefronts' LDS-DMA tiles; the 2-byte one is walked with per-lane loads and takes
+	 * all of LDS: every row there is a step that stays out of L2) */
+	const uint32_t keep = d->glob16 ? 64u : 8u * 4096u;
+	if (hot + lds_bytes_btab() + keep > d->lds_limit) hot = d->lds_limit - lds_bytes_btab() - keep;
 	hot -= hot % d->glob_row_bytes;
 	d->proto.tab_bytes = (uint32_t)hot;
 	d->table_lds = GlobPol::lds_bytes((uint32_t)hot);
@@ -337,6 +341,23 @@ static int dfa_upload(fsm_hip_dfa *d)
 			break;
 		}
 		case FSM_HIP_LAYOUT_GLOBAL: {
+			if (!p.glob_tab16.empty()) {
+				/* <= 65 535 states: 2-byte entries = the next state's index (Glob16Pol) */
+				uint16_t *t16 = nullptr;
+				HIP_TRY(upload(&t16, p.glob_tab16));
+				d->d_tab = t16;
+				HIP_TRY(upload(&d->d_fin, p.glob16_fin));      /* rows in visit-frequency order (plan.cpp): fin follows */
+				for (int b = 0; b < 256; b++) btab[b] = p.cls[b];
+				a.start = p.glob16_rank.empty() ? p.start : p.glob16_rank[p.start];
+				a.abs_min = p.abs_min;
+				a.fin_div = 1;
+				a.dflt = p.C * 2u;          /* bytes per row */
+				d->glob16 = true;
+				d->glob_row_bytes = p.C * 2u;
+				d->glob_tab_bytes = (uint64_t)p.glob_tab16.size() * 2u;
+				set_hot_bytes(d, 160u * 1024u);
+				break;
+			}
 			uint32_t *t = nullptr;
 			HIP_TRY(upload(&t, p.glob_tab));
 			d->d_tab = t;
@@ -393,11 +414,11 @@ static int dfa_upload(fsm_hip_dfa *d)
 			case FSM_HIP_LAYOUT_COMB:
 			case FSM_HIP_LAYOUT_COMBSELF: d->enc_host[n2] = p.comb_off[n2]; break;
 			case FSM_HIP_LAYOUT_COMB256: d->enc_host[n2] = p.comb256_off[n2]; break;
-			default: d->enc_host[n2] = n2 * p.C * 4u; break;
+			default: d->enc_host[n2] = !p.glob_tab16.empty() ? (p.glob16_rank.empty() ? n2 : p.glob16_rank[n2]) : n2 * p.C * 4u; break;   /* global: the row's byte offset, or (2-byte entries) its row */
 			}
 		}
 		d->fin_host = (p.layout == FSM_HIP_LAYOUT_COMB || p.layout == FSM_HIP_LAYOUT_COMBSELF) ? p.comb_fin
-			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : p.fin;
+			: p.layout == FSM_HIP_LAYOUT_COMB256 ? p.comb256_fin : (p.layout == FSM_HIP_LAYOUT_GLOBAL && !p.glob_tab16.empty()) ? p.glob16_fin : p.fin;
 		if (!p.emask.empty()) {
 			/* eager masks indexed like fin; thresholds in encoded-state units */
 			const size_t F = d->fin_host.size();
@@ -610,7 +631,7 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		if (m == IN_DIRECT) {
 			/* the sparse layout waits on gathers, not on its input: 4 chunks keep it under 64 VGPRs;
 			 * the eager kernel is instantiated for 4 chunks only */
-			c.nb = d->knob_nb == 4 || d->knob_nb == 8 ? d->knob_nb : (layout == FSM_HIP_LAYOUT_SPARSE ? 4 : 8);
+			c.nb = d->knob_nb == 4 || d->knob_nb == 8 ? d->knob_nb : (layout == FSM_HIP_LAYOUT_SPARSE || d->glob16 ? 4 : 8);   /* (the 2-byte global table: 4 chunks x TWO inputs per lane, kern_glob16.hip) */
 			if (eager || !c.prefetch) c.nb = 4;
 			if ((stride / 16u) % 8u != 0) c.nb = 4;
 			if ((stride / 16u) % 4u != 0) m = -1;   /* rows shorter than / not a multiple of 64 bytes */
@@ -648,6 +669,15 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		return c;
 	}
 	if (c.sparse_fast == 3) c.sparse_fast = d->sparse_fast_ok ? 1 : 0;
+	/* a staging path asked for by knob beside a table that leaves no LDS for one wavefront's tile (the 2-byte global table takes
+	 * all of it): the per-lane kernel of the same class of input */
+	if ((mode == IN_LDSDMA && d->table_lds + 64u * (uint32_t)c.seg > d->lds_limit) || (mode == IN_RAGGED && d->table_lds + ragged_wave_lds > d->lds_limit)) {
+		mode = mode == IN_LDSDMA ? IN_DIRECT : IN_GENERIC;
+		if (mode == IN_DIRECT) {
+			c.nb = d->knob_nb == 8 && (stride / 16u) % 8u == 0 ? 8 : 4;
+			if ((stride / 16u) % 4u != 0) mode = IN_GENERIC;
+		}
+	}
 	c.mode = mode;
 	const uint32_t per_wave = mode == IN_LDSDMA ? 64u * (uint32_t)c.seg : mode == IN_RAGGED ? ragged_wave_lds : 0u;
 	/* waves per block: as many behind one table copy as LDS holds, 16 at most: the tiny layouts keep a
@@ -705,7 +735,7 @@ static hipError_t launch_layout(const fsm_hip_dfa *d, int eager, const LaunchCfg
 	case FSM_HIP_LAYOUT_COMB256:  return launch_comb(POL_COMB256, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_COMBSELF: return launch_comb(POL_COMBSELF, eager, c, a, grid, block, s);
 	case FSM_HIP_LAYOUT_SPARSE:   return launch_glob(POL_SPARSE, eager, c, a, grid, block, s);
-	default:                      return launch_glob(POL_GLOB, eager, c, a, grid, block, s);
+	default:                      return d->glob16 ? launch_glob16(eager, c, a, grid, block, s) : launch_glob(POL_GLOB, eager, c, a, grid, block, s);
 	}
 }
 
@@ -1403,7 +1433,7 @@ extern "C" int fsm_hip_dfa_info(const struct fsm_hip_dfa *d, struct fsm_hip_dfa_
 	case FSM_HIP_LAYOUT_COMB256: out->table_bytes = p.comb256.size() * 4; break;
 	case FSM_HIP_LAYOUT_COMBSELF: out->table_bytes = p.comb.size() * 10 + 256; break;
 	case FSM_HIP_LAYOUT_SPARSE: out->table_bytes = p.sparse_img.size() * 4; break;
-	default: out->table_bytes = p.glob_tab.size() * 4; break;
+	default: out->table_bytes = p.glob_tab16.empty() ? p.glob_tab.size() * 4 : p.glob_tab16.size() * 2; break;
 	}
 	LaunchCfg c = pick_cfg(d, true, 1024, 0);
 	out->lds_bytes = c.lds;
@@ -1506,6 +1536,8 @@ extern "C" int fsm_hip_plan_get(const struct fsm_hip_plan *pl, int what, const v
 	case FSM_HIP_PLAN_COMB_OFF: *data = p.comb_off.data(); *count = p.comb_off.size(); return 0;
 	case FSM_HIP_PLAN_COMB_FIN: *data = p.comb_fin.data(); *count = p.comb_fin.size(); return 0;
 	case FSM_HIP_PLAN_GLOB_TAB: *data = p.glob_tab.data(); *count = p.glob_tab.size(); return 0;
+	case FSM_HIP_PLAN_GLOB_TAB16: *data = p.glob_tab16.data(); *count = p.glob_tab16.size(); return 0;
+	case FSM_HIP_PLAN_GLOB16_RANK: *data = p.glob16_rank.data(); *count = p.glob16_rank.size(); return 0;
 	case FSM_HIP_PLAN_SPARSE: *data = p.sparse_img.data(); *count = p.sparse_img.size(); return 0;
 	case FSM_HIP_PLAN_LAZY: *data = p.lazy_img.data(); *count = p.lazy_img.size(); return 0;
 	case FSM_HIP_PLAN_COMB256: *data = p.comb256.data(); *count = p.comb256.size(); return 0;

@@ -40,6 +40,7 @@ hipError_t launch_tiny(int pol, int eager, const LaunchCfg &c, const WalkArgs &a
 hipError_t launch_lds(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
 hipError_t launch_comb(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
 hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);
+hipError_t launch_glob16(int eager, const LaunchCfg &c, const WalkArgs &a, dim3 grid, dim3 block, hipStream_t s);   /* Glob16Pol: kern_glob16.hip */
 
 typedef void (*walk_fn)(const WalkArgs);
 

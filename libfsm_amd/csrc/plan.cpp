@@ -432,6 +432,53 @@ try {
 		if ((uint64_t)S1 * C * 4u >= 0xFFFFFFFFull) return ENOTSUP;
 		p.glob_tab.resize((size_t)S1 * C);
 		for (size_t i = 0; i < p.glob_tab.size(); i++) p.glob_tab[i] = p.dense[i] * C * 4u;
+		p.glob_tab16.clear();
+		p.glob16_rank.clear();
+		p.glob16_fin.clear();
+		if (S1 <= 65535u) {
+			/* Row order.  Only the head of the table is in LDS, and a step that leaves it costs the whole wavefront an L2 round
+			 * trip: which rows are there decides the rate.  Breadth-first order is a proxy (near the start = visited often) that
+			 * is wrong where it matters -- the 4 133-state union of rx-style patterns <letters>[0-9]$: the end states (three
+			 * letters, then one of TEN digits) are ten times likelier than the four-letter prefix states of the same depth.
+			 * So: the occupancy of every state under a memoryless byte source over printable ASCII (every other byte at 1 % of
+			 * a printable one's weight), by power iteration from the start state, averaged over the iterations (a periodic
+			 * automaton has no limit); the non-absorbing states sorted by it.  The absorbing ones keep their places at the end
+			 * (codes >= abs_min: what the kernels' retire test means).  Eager-output ranges are in renumbered order: no re-ordering. */
+			std::vector<uint32_t> order(S1);
+			for (uint32_t n = 0; n < S1; n++) order[n] = n;
+			if (p.emask.empty() && (uint64_t)S1 * C <= (4u << 20)) {
+				std::vector<double> w(C, 0.0);
+				double W = 0;
+				for (unsigned b = 0; b < 256; b++) { const double x = (b >= 0x20 && b <= 0x7e) ? 1.0 : 0.01; w[p.cls[b]] += x; W += x; }
+				std::vector<double> pi(S1, 0.0), nx2(S1, 0.0), acc(S1, 0.0);
+				pi[p.start] = 1.0;
+				const int iters = 48;
+				for (int it = 0; it < iters; it++) {
+					std::fill(nx2.begin(), nx2.end(), 0.0);
+					for (uint32_t n = 0; n < S1; n++) {
+						if (pi[n] == 0.0) continue;
+						const double m = pi[n] / W;
+						const uint32_t *row = &p.dense[(size_t)n * C];
+						for (uint32_t c = 0; c < C; c++) nx2[row[c]] += m * w[c];
+					}
+					pi.swap(nx2);
+					if (it >= 8) for (uint32_t n = 0; n < S1; n++) acc[n] += pi[n];
+				}
+				std::stable_sort(order.begin(), order.begin() + p.abs_min, [&](uint32_t x, uint32_t y) { return acc[x] > acc[y]; });
+				p.glob16_rank.assign(S1, 0);
+				for (uint32_t r = 0; r < S1; r++) p.glob16_rank[order[r]] = r;
+			}
+			p.glob_tab16.resize((size_t)S1 * C);
+			p.glob16_fin.resize(S1);
+			for (uint32_t r = 0; r < S1; r++) {
+				const uint32_t n = order[r];
+				p.glob16_fin[r] = p.fin[n];
+				for (uint32_t c = 0; c < C; c++) {
+					const uint32_t t = p.dense[(size_t)n * C + c];
+					p.glob_tab16[(size_t)r * C + c] = (uint16_t)(p.glob16_rank.empty() ? t : p.glob16_rank[t]);
+				}
+			}
+		}
 		p.layout = FSM_HIP_LAYOUT_GLOBAL;
 		return 0;
 	};

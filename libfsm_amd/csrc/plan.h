@@ -89,6 +89,12 @@ struct Plan {
 	uint32_t comb256_dflt = 0, comb256_abs_min_off = 0;
 	/* GLOBAL: u32 entries [S1][C], entry = next_state * C * 4 (byte offset) */
 	std::vector<uint32_t> glob_tab;
+	/* GLOBAL, <= 65 535 states: the same table with 2-byte entries (next state's INDEX): twice the rows in the LDS copy of
+	 * its head, half the L2 footprint (Glob16Pol, walk_kernels.h) */
+	std::vector<uint16_t> glob_tab16;
+	/* ... its rows in the order of how often a walk over TEXT is in them (glob16_rank[renumbered state] = row; empty: the
+	 * renumbered order): the LDS copy of the table's head then holds the rows that matter, not the ones nearest the start */
+	std::vector<uint32_t> glob16_rank, glob16_fin;
 	/* SPARSE: base-row records (see build_sparse in plan.cpp); states are plain renumbered ids */
 	std::vector<uint32_t> sparse_img;
 	uint32_t sparse_lds_bytes = 0;    /* leading part of the image that the kernel mirrors in LDS */

@@ -643,6 +643,70 @@ struct GlobPol {
 };
 
 /*
+ * Glob16Pol: GlobPol for automata of <= 65 535 states -- 2-byte entries (the next state's INDEX; the row address is one
+ * v_mad_u32_u24), so the LDS copy of the table's head holds twice the rows and the rest half the L2 lines.  The regime: the
+ * COMPLETE DFA of an unanchored pattern list as rx builds one (src/rx/main.c:487-566, :1338-1385: every pattern carries the
+ * implicit leading .*, the union has no DEAD default and changes state on almost every byte), a few thousand states whose
+ * dense table is 2-4 x LDS: column defaults do not compress it (every (state, letter) pair leads to its own bigram state) and
+ * GlobPol kept 1 059 of its 4 133 rows in LDS -- with 64 inputs per wavefront some lane left them in most steps and every
+ * step paid the L2 round trip: 0.20 of the HBM peak.  Here breadth-first numbering + 58-byte rows put every state a random
+ * input reaches with probability > 1e-3 in LDS, the lookup is an explicit ds_read (not a flat load of a selected address),
+ * and the L2 path sits behind a wave-uniform branch that is rarely taken.
+ */
+struct Glob16Pol {
+	static constexpr bool heavy_next = false;
+	typedef uint32_t P;        /* class * 2 */
+	typedef uint32_t S;        /* state index */
+	__device__ __forceinline__ S init(uint32_t code) const { return code; }
+	__device__ __forceinline__ static uint32_t code(S s) { return s; }
+	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
+	typedef const uint16_t __attribute__((address_space(3))) *lds_u16p;
+	const uint8_t *bp;         /* LDS byte -> class map */
+	const unsigned char *tab;  /* device table */
+	uint32_t hot_lds;          /* LDS byte address of the copy of the table's first hot_bytes */
+	uint32_t hot_bytes, row_bytes;
+
+	__host__ __device__ static uint32_t lds_bytes(uint32_t tab_bytes) { return FSMHIP_BTAB_BYTES + ((tab_bytes + 15u) & ~15u); }
+	__device__ __forceinline__ void setup(unsigned char *lds, const WalkArgs &a)
+	{
+		bp = setup_btab(lds, a);
+		copy_table(lds + FSMHIP_BTAB_BYTES, a);
+		hot_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + FSMHIP_BTAB_BYTES);
+		hot_bytes = a.tab_bytes;
+		row_bytes = a.dflt;        /* bytes per row: classes * 2 */
+		tab = static_cast<const unsigned char *>(a.tab);
+	}
+	__device__ __forceinline__ P pre(uint32_t b) const { return (uint32_t)bp[b] * 2u; }
+	__device__ __forceinline__ uint32_t next(uint32_t st, P c2) const
+	{
+		const uint32_t ad = __umul24(st, row_bytes) + c2;
+		const bool cold = ad >= hot_bytes;
+		uint32_t v = *(lds_u16p)(uintptr_t)(hot_lds + (cold ? 0u : ad));
+		if (__any(cold)) {
+			if (cold) v = *reinterpret_cast<const uint16_t *>(tab + ad);
+		}
+		return v;
+	}
+	/* two inputs per lane (step16's ROWS == 2 form): both LDS reads in flight together, ONE vote for the L2 path.  A 128 KiB
+	 * table leaves room for one 16-wavefront workgroup per CU -- four dependent chains per SIMD where the small LDS layouts
+	 * have eight; the second input per lane gives the missing ones back (digits-only rows, which never leave the first rows:
+	 * 2.2 TB/s with one input per lane). */
+	__device__ __forceinline__ void next2(uint32_t &s0, uint32_t &s1, P c0, P c1) const
+	{
+		const uint32_t ad0 = __umul24(s0, row_bytes) + c0, ad1 = __umul24(s1, row_bytes) + c1;
+		const bool cold0 = ad0 >= hot_bytes, cold1 = ad1 >= hot_bytes;
+		uint32_t v0 = *(lds_u16p)(uintptr_t)(hot_lds + (cold0 ? 0u : ad0));
+		uint32_t v1 = *(lds_u16p)(uintptr_t)(hot_lds + (cold1 ? 0u : ad1));
+		if (__any(cold0 | cold1)) {
+			if (cold0) v0 = *reinterpret_cast<const uint16_t *>(tab + ad0);
+			if (cold1) v1 = *reinterpret_cast<const uint16_t *>(tab + ad1);
+		}
+		s0 = v0;
+		s1 = v1;
+	}
+};
+
+/*
  * SparsePol: base-row records (plan.cpp build_sparse).  A state is its renumbered id; its 16-byte
  * record {bits lo, bits hi, base | DENSE | CONSEC | FULLBASE, offset} comes from LDS for the H states nearest the
  * start state and from HBM/L2 for the rest.  A lane follows base links until a record has the class's
@@ -1191,6 +1255,24 @@ __device__ __forceinline__ auto mask_absorbing(const Pol &pol, const typename Po
 template <class Pol>
 __device__ __forceinline__ u32x4 mask_absorbing(const Pol &, const typename Pol::S &, const u32x4 &w, long) { return w; }
 
+/* the dependent chains of ROWS inputs per lane over a chunk, interleaved byte by byte; a policy with next2 walks two inputs'
+ * bytes in one call (Glob16Pol: one vote for its L2 path instead of two) */
+template <class Pol, int ROWS>
+__device__ __forceinline__ auto step16_rows_chain(const Pol &pol, typename Pol::S (&st)[ROWS], const typename Pol::P (&pre)[ROWS][16], int)
+	-> typename std::enable_if<ROWS == 2, decltype(pol.next2(st[0], st[0], pre[0][0], pre[0][0]), void())>::type
+{
+#pragma unroll
+	for (int k = 0; k < 16; k++) pol.next2(st[0], st[ROWS - 1], pre[0][k], pre[ROWS - 1][k]);
+}
+template <class Pol, int ROWS>
+__device__ __forceinline__ void step16_rows_chain(const Pol &pol, typename Pol::S (&st)[ROWS], const typename Pol::P (&pre)[ROWS][16], long)
+{
+#pragma unroll
+	for (int k = 0; k < 16; k++)
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) st[r] = pol.next(st[r], pre[r][k]);
+}
+
 template <class Pol, int ROWS>
 __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROWS], const u32x4 (&w)[ROWS])
 {
@@ -1207,10 +1289,7 @@ __device__ __forceinline__ void step16(const Pol &pol, typename Pol::S (&st)[ROW
 		walk_chunk(pol, st[0], pre[0], 0);
 		return;
 	}
-#pragma unroll
-	for (int k = 0; k < 16; k++)
-#pragma unroll
-		for (int r = 0; r < ROWS; r++) st[r] = pol.next(st[r], pre[r][k]);
+	step16_rows_chain<Pol, ROWS>(pol, st, pre, 0);
 }
 
 /* ------------------------------------------------------------------ */

@@ -16,6 +16,7 @@ own sources) and freezes its answers as small .npz fixtures:
   c1.npz           BASELINE config 1/2 DFA: PCRE [Ll]ibf+(sm)* det+min, end-id 0,
                    with fsm_exec answers on generator inputs (parameters stored).
   c3.npz           BASELINE config 3: 1024 anchored PCRE unioned + determinised
+  c3u.npz          its unanchored (rx-style) twin: 1024 patterns <letters>[0-9]$ with the implicit leading .*, a complete ~4100-state DFA
                    (rx-style, not minimised), end-id = pattern index, with
                    fsm_exec + end-id answers on 512 x 1 KiB inputs.
 
@@ -324,6 +325,41 @@ def gen_c3t():
     print("c3t: accepts", int((ret == 1).sum()), "of", len(ret))
 
 
+def c3u_patterns(n=1024, seed=C3_SEED + 13):
+    """The UNANCHORED twin of C3, as rx builds a pattern list (src/rx/main.c:487-566 re_comp without ^, determinise, minimise,
+    fsm_setendid(line); :1338-1385 fsm_union_array + fsm_determinise): 1 024 patterns <3-4 lowercase>[0-9]$ -- no left anchor, so
+    every one carries the implicit leading .* -- whose union is a COMPLETE DFA of ~4 100 states: no DEAD default, no run of
+    self-loops, a state change on almost every byte, end-id = pattern.  (Unanchored on the right as well, a pattern's accept state
+    absorbs and the union has to remember which subset of the 1 024 has matched so far: it does not determinise in any budget.)"""
+    rng = random.Random(seed)
+    pats = []
+    while len(pats) < n:
+        k = rng.randint(3, 4)
+        pats.append(("".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(k)) + "[0-9]$").encode())
+    return pats
+
+
+def c3u_suffixes(pats):
+    """what a row must end with to be accepted by pattern i: its letters and one digit (i % 10)"""
+    return [p[:p.index(b"[")] + str(i % 10).encode() for i, p in enumerate(pats)]
+
+
+def gen_c3u():
+    from libfsm_amd import gen_affix_inputs_host
+    pats = c3u_patterns()
+    f = RefFsm.union_res("pcre", pats, 0)
+    flat = f.flatten()
+    print("c3u: states", flat.nstates, "end states", int(flat.is_end.sum()))
+    alnum = b"abcdefghijklmnopqrstuvwxyz0123456789"
+    data = gen_affix_inputs_host(512, 1024, 0, 0x5EEDF5A1, alnum, alnum, [b""], c3u_suffixes(pats), 2)
+    ret, end = f.exec_stride(data)
+    io, ii = endid_csr(f, end)
+    flat.save(os.path.join(OUT, "c3u.npz"), in_rows=data, ret=ret, end=end, ids_off=io, ids=ii,
+              patterns=np.frombuffer(b"\n".join(pats), np.uint8),
+              meta=np.frombuffer(json.dumps(dict(source="unanchored (rx-style) twin of BASELINE.json configs[2]", seed=C3_SEED + 13, npatterns=len(pats))).encode(), np.uint8))
+    print("c3u: accepts", int((ret == 1).sum()), "of", len(ret), "multi-id ends", int(sum(1 for k in range(len(ret)) if io[k + 1] - io[k] > 1)))
+
+
 def c_unescape(lit: str) -> bytes:
     """A C string literal body -> bytes (the escapes the reference's test sources use)."""
     out, i = bytearray(), 0
@@ -627,6 +663,7 @@ if __name__ == "__main__":
     gen_c1()
     gen_c3()
     gen_c3t()
+    gen_c3u()
     gen_eager()
     gen_fsm_corpus()
     gen_recorded()

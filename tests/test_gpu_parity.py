@@ -63,7 +63,7 @@ def test_golden_vectors_all_layouts(hip, path):
         dfa.close()
 
 
-@pytest.mark.parametrize("name", ["c1.npz", "c3.npz", "c3t.npz"])
+@pytest.mark.parametrize("name", ["c1.npz", "c3.npz", "c3t.npz", "c3u.npz"])
 def test_fast_paths_every_mode(hip, name):
     """Fixed-stride aligned rows through every input path: direct (NB = 4, 8; with and without the register
     double-buffer), LDS-DMA (64 / 128-byte segments, nontemporal or not), generic, ragged; 1..16 waves;

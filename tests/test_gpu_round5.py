@@ -595,11 +595,14 @@ def test_last_kernel_name_after_a_device_side_pick(hip):
         # the batch's base points into an allocation of a few hundred KB: it cannot reach 4 GiB, so walk_generic's own body (what a
         # batch of 4 GiB and more needs) is not among the kernels launched -- walk_lines32 and walk_ragged are
         assert "1 of 2 launched" in name, name
-    # a table that leaves no LDS for walk_ragged's tiles, or per-lane loads forced: ONE kernel, no choice on the device
+    # a table that leaves no LDS for walk_ragged's tiles, or per-lane loads forced: the two per-lane kernels.  (Round 5 left
+    # walk_generic out here on the strength of the allocation's size; that is a hint, not a proof -- memory mapped in pieces may
+    # report one piece -- and with walk_ragged out of the race nothing launched could take a batch of 4 GiB and more: round 6
+    # launches it and lets the batch's last offset decide.)
     dfa.tune(hip.KNOB_INPUT_MODE, 2)
     dfa.exec_batch_offsets_device(tb.data_ptr(), to.data_ptr(), len(strs), te.data_ptr(), 0)
     name = dfa.last_kernel_name()
-    assert "walk_lines32" in name and "launched" not in name and "on the device" not in name, name
+    assert "walk_lines32" in name and "1 of 2 launched" in name and " | " not in name, name
     dfa.close()
 
 

@@ -35,7 +35,7 @@ def test_golden_counts():
     assert sum(len(Golden(p).ret) for p in paths) == 115  # ... 115 cases
 
 
-@pytest.mark.parametrize("name", ["c1.npz", "c3.npz", "endids_union_det.npz", "re_strings_1.npz"])
+@pytest.mark.parametrize("name", ["c1.npz", "c3.npz", "c3u.npz", "endids_union_det.npz", "re_strings_1.npz"])
 def test_table_walker_equals_group_scan(name):
     import os
     from common import GOLDEN

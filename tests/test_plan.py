@@ -277,6 +277,15 @@ def check_plan(flat, layout):
         st = np.arange(S1)[:, None] * Cn * 4
         e = tab[(st + cls[bytes_][None, :] * 4) // 4]
         got = e // (Cn * 4)
+        # ... and its 2-byte form (Glob16Pol: the next state's index at row * C * 2 + class * 2) where the automaton has <= 65 535 states
+        t16 = p.get("glob_tab16").astype(np.int64)
+        assert (len(t16) != 0) == (S1 <= 65535)
+        if len(t16):
+            rank = p.get("glob16_rank").astype(np.int64)          # rows in visit-frequency order (empty: renumbered order)
+            if len(rank) == 0:
+                rank = np.arange(S1)
+            assert np.array_equal(np.sort(rank), np.arange(S1)) and np.array_equal(rank[p.abs_min:], np.arange(p.abs_min, S1))
+            assert np.array_equal(t16[rank[:, None] * Cn + cls[bytes_][None, :]], rank[got])
     assert np.array_equal(got, want)
     return True
 
