@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c3u", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged", "c3_eager40"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3t", "c3u", "lds2", "c5", "c2_short", "c3_short", "c2_ragged", "c3_ragged", "c5_short", "c5_ragged", "c3_eager40"],
                     help="c*_short / c*_ragged: the packed-lines front alone (what the default run reports as sub_results), for profiling")
     ap.add_argument("--subs", default="auto", choices=["auto", "none"],
                     help="auto: at N = 1 also measure the other configs and report them as sub_results")
@@ -97,6 +97,18 @@ def c5_words(nwords):
 
 
 _C5_FLAT = {}
+LDS2_ALPHA = b"abcdefghijkl"
+
+
+def lds2_flat(hip):
+    """the pair-table regime (FSM_HIP_LAYOUT_LDS2: one LDS lookup per TWO input bytes): 70 literals of 3-7 letters over a
+    12-letter alphabet, unanchored with end-ids (no absorbing state) -- the first case of tests/tools/lds2_probe.py"""
+    if "lds2" not in _C5_FLAT:
+        rng = np.random.RandomState(len(LDS2_ALPHA) * 131 + 70)
+        al = np.frombuffer(LDS2_ALPHA, np.uint8)
+        words = sorted(set(bytes(al[rng.randint(0, len(al), rng.randint(3, 8))]) for _ in range(70)))
+        _C5_FLAT["lds2"] = hip.FlatDfa.from_strings(words, 0, list(range(len(words))))
+    return _C5_FLAT["lds2"]
 
 
 def c5_flat(hip, nwords):
@@ -143,6 +155,8 @@ def generate(hip, workload, d_ptr, n, L, first, words=None, buf=None):
         return
     if workload == "c2":
         hip.gen_inputs_device(d_ptr, n, L, first, SEED, None, b"Libfsm", 8)
+    elif workload == "lds2":
+        hip.gen_inputs_device(d_ptr, n, L, first, SEED, LDS2_ALPHA)
     elif workload == "c3t":   # pattern rows alternate digit / [a-f] after the prefix: a state change on every byte
         pf, sf = c3_affixes("c3t")
         hip.gen_affix_inputs_device(d_ptr, n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
@@ -162,6 +176,8 @@ def generate_host(hip, workload, n, L, first, words=None):
         return rows
     if workload == "c2":
         return hip.gen_inputs_host(n, L, first, SEED, None, b"Libfsm", 8)
+    if workload == "lds2":
+        return hip.gen_inputs_host(n, L, first, SEED, LDS2_ALPHA)
     if workload == "c3t":
         pf, sf = c3_affixes("c3t")
         return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2, body2=b"abcdef")
@@ -171,6 +187,23 @@ def generate_host(hip, workload, n, L, first, words=None):
         return hip.gen_affix_inputs_host(n, L, first, SEED, al, al, pf, sf, 2)
     pf, sf = c3_affixes()
     return hip.gen_affix_inputs_host(n, L, first, SEED, ALNUM, b"0123456789", pf, sf, 2)
+
+
+def rccl_identity(torch):
+    """what the collective library says about itself: its version as torch reports it and the shared object mapped into this
+    process (the first N > 1 run has to explain itself from one line)"""
+    out = {}
+    try:
+        v = torch.cuda.nccl.version()
+        out["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001
+        out["rccl_version"] = "unknown: " + repr(e)[:60]
+    try:
+        libs = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln})
+        out["rccl_library"] = libs[0] if libs else None
+    except OSError:
+        out["rccl_library"] = None
+    return out
 
 
 def host_cores():
@@ -288,7 +321,7 @@ def cpu_baseline(hip, workload, flat, L, rows, gpu_end_sample, words=None):
     out = {"cores": 1, "unit": "GB/s"}
     gb = rows.size / 1e9
     nrows = len(rows)
-    if workload == "c5" or not pyoracle.have_ref():
+    if workload in ("c5", "lds2") or not pyoracle.have_ref():   # (lds2: a literal set the library's own builder made -- the automaton is given, not derived from a regex the reference could compile)
         o = get_oracle(flat)
         want = o.table_walk(rows)
         out.update(kind="port", value=round(gb / o.last_seconds, 5),
@@ -521,11 +554,15 @@ def compact_line(res, detail_path=DETAIL_FILE, limit=LINE_LIMIT):
     if "full_parity" in res:
         out["full_parity"] = _pick(res["full_parity"], ("rows", "mismatches", "cpu_threads", "seconds"))
     if "multi_gpu" in res:
-        out["multi_gpu"] = _pick(res["multi_gpu"], ("walk_kernel_ms_per_rank", "exchange_exposed_ms_per_step", "backend", "world_size"))
+        out["multi_gpu"] = _pick(res["multi_gpu"], ("walk_kernel_ms_per_rank", "exchange_exposed_ms_per_step", "backend", "world_size", "rccl_version", "rccl_library"))
     if isinstance(res.get("node_front"), dict):
         out["node_front"] = _pick(res["node_front"], ("devices", "uses_rccl", "ms_per_step", "value_GBps", "async_ms_per_step", "async_value_GBps", "error"))
     if isinstance(res.get("multi_dfa"), dict):
         out["multi_dfa"] = _pick(res["multi_dfa"], ("dfas", "lines", "launches", "ms_per_call_multi", "ms_per_call_one_by_one", "speedup", "parity"))
+    if isinstance(res.get("multi_dfa_bulk"), dict):
+        out["multi_dfa_bulk"] = _pick(res["multi_dfa_bulk"], ("dfas", "lines_per_dfa", "launches", "ms_per_call", "walked_GBps", "one_dfa_at_a_time_ms_extrapolated", "parity", "error"))
+        if isinstance(res["multi_dfa_bulk"].get("roofline"), dict):
+            out["multi_dfa_bulk"]["frac"] = res["multi_dfa_bulk"]["roofline"].get("frac")
     if res.get("sub_results"):
         out["sub_results"] = [compact_sub(s) for s in res["sub_results"]]
     out["detail"] = detail_path
@@ -570,6 +607,8 @@ WORKLOAD_TEXT = {
     "c3u": ("c3u: the UNANCHORED (rx-style, src/rx/main.c:487-566) twin of configs[2] -- 1024 patterns <3-4 letters>[0-9]$ with the implicit "
             "leading .* unioned into one complete %d-state DFA (no DEAD default, a state change on almost every byte), rows random over [a-z0-9], "
             "every 2nd one ending in a pattern, "),
+    "lds2": ("lds2: the pair-table regime -- 70 literals of 3-7 letters over a 12-letter alphabet, unanchored with end-ids (a dense "
+             "mid-size DFA with few byte classes: one LDS lookup per TWO input bytes), uniform random text over that alphabet, "),
     "c5": "c5: BASELINE configs[4] -- Aho-Corasick DFA of %d literals (%d states, table > LDS), ",
 }
 
@@ -662,6 +701,8 @@ def main():
         if wl == "c5":
             words = c5_words(a.c5_words)
             flat = c5_flat(hip, a.c5_words)
+        elif wl == "lds2":
+            flat = lds2_flat(hip)
         else:
             flat = hip.FlatDfa.load(os.path.join(ROOT, "tests", "golden", "c1.npz" if wl == "c2" else wl + ".npz"))
         flags = a.layout | (hip.NO_EARLY_RETIRE if a.no_early_retire else 0)
@@ -785,7 +826,7 @@ def main():
                              if world > 1 else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
-            **({"multi_gpu": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "walk_kernel_ms_per_rank": rank_kms,
+            **({"multi_gpu": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), **rccl_identity(torch), "walk_kernel_ms_per_rank": rank_kms,
                               "exchange_exposed_ms_per_step": round(max(0.0, ms_step - max(rank_kms)), 4),
                               "note": "ms_per_step minus the slowest rank's walk kernel: what the RCCL all-gather of the accept bitmap (overlapped with the next step's walk) and the host loop add"}}
                if rank_kms else {}),
@@ -1148,6 +1189,60 @@ def main():
                 "note": "wall time of a pass over all records, fsm_hip_dfa_create included (retest builds a DFA per record, src/retest/main.c:1056-1058); "
                         "end states against the reference's frozen fsm_exec answers"}
 
+    def run_multi_dfa_bulk():
+        """The many-DFA front at THROUGHPUT size: 1 024 automata (the 37 retest goldens, cycled) x 100 000 lines of 64 bytes each,
+        device pointers, ONE fsm_hip_exec_multi_device -- one launch whose workgroups of four wavefronts map to (dfa, 256 lines)
+        and share that dfa's table copy in LDS.  Beside it: the same jobs one dfa at a time (fsm_hip_exec_batch_offsets_device,
+        tables uploaded beforehand), which is also the parity check on a sample of the jobs."""
+        import glob
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from common import Golden
+        gs = [Golden(p) for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retest", "*.npz")))]
+        K, nl, ll = 1024, 100_000, 64
+        text = buf_all.view(-1)[: K * nl * ll]
+        hip.gen_inputs_device(text.data_ptr(), K * nl, ll, 0, SEED ^ 0x77, bytes(range(32, 127)))
+        off = (torch.arange(nl + 1, device="cuda", dtype=torch.int64) * ll)       # every job: 100 000 lines of 64 bytes, its own slice of the text
+        ends = end_all[: K * nl]
+        ds = [hip.HipDfa(gs[q % len(gs)].flat, hip.DEFER_UPLOAD) for q in range(K)]
+        jobs = [(text.data_ptr() + q * nl * ll, off.data_ptr(), nl, ends.data_ptr() + q * nl * 4, 0) for q in range(K)]
+        torch.cuda.synchronize()
+
+        def once():
+            hip.exec_multi_device(ds, jobs, stream=stream)
+        for _ in range(2):
+            once()
+        torch.cuda.synchronize()
+        launches, fused = hip.multi_last_launches(), hip.multi_last_fused_jobs()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        # parity + the one-by-one figure on every 64th job (its own dfa, its own planned layout)
+        sample = list(range(0, K, 64))
+        ok, t_one = True, 0.0
+        chk = torch.empty(nl, dtype=torch.int32, device="cuda")
+        for q in sample:
+            one = hip.HipDfa(gs[q % len(gs)].flat)
+            one.exec_batch_offsets_device(jobs[q][0], off.data_ptr(), nl, chk.data_ptr(), 0, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one.exec_batch_offsets_device(jobs[q][0], off.data_ptr(), nl, chk.data_ptr(), 0, stream=stream)
+            torch.cuda.synchronize()
+            t_one += time.perf_counter() - t1
+            ok = ok and bool(torch.equal(chk, ends[q * nl:(q + 1) * nl]))
+            one.close()
+        for d in ds:
+            d.close()
+        nbytes = K * nl * (ll + 8 + 4)
+        return {"dfas": K, "lines_per_dfa": nl, "line_bytes": ll, "launches": launches, "fused_jobs": fused, "ms_per_call": round(ms, 3),
+                "walked_GBps": round(K * nl * ll / ms / 1e6, 1),
+                "roofline": {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes": "64 B of text + 8 B offset + 4 B end state per line"},
+                "one_dfa_at_a_time_ms_extrapolated": round(t_one / len(sample) * K * 1e3, 1),
+                "parity": ("bit-exact" if ok else "MISMATCH") + f" ({len(sample)} of the jobs against their dfa's own walk of the same lines)"}
+
     if "_" in a.workload:       # the packed-lines front alone
         wl, kind = a.workload.split("_")
         r = run_eager40() if kind == "eager40" else run_lines(wl, kind)
@@ -1166,7 +1261,7 @@ def main():
         if a.workload == "c3":
             plan.append(("c3", "noskip", None))
             plan.append(("c3", "loadskip", None))
-        for wl in ("c3", "c3t", "c3u", "c2", "c5"):
+        for wl in ("c3", "c3t", "c3u", "lds2", "c2", "c5"):
             if wl != a.workload:
                 plan.append((wl, None, default_n(wl)))
         # the short / packed front of retest and rx, at steady-state size, on the C2 and C3 tables
@@ -1198,6 +1293,10 @@ def main():
             main_res["multi_dfa"] = run_multi_dfa()
         except Exception as e:  # noqa: BLE001
             main_res["multi_dfa"] = {"error": repr(e)[:300]}
+        try:
+            main_res["multi_dfa_bulk"] = run_multi_dfa_bulk()
+        except Exception as e:  # noqa: BLE001
+            main_res["multi_dfa_bulk"] = {"error": repr(e)[:300]}
         # leave the main workload's inputs in the buffer for the stream probe below
     if rank != 0:
         if world > 1:
@@ -1221,7 +1320,7 @@ def main():
                          measured_read_stream_GBps=None if stream_gbps is None else round(stream_gbps, 1),
                          frac_of_measured_stream=None if not stream_gbps else round(main_res["roofline"]["achieved"] / stream_gbps, 4)),
     }
-    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity", "multi_gpu", "multi_dfa"):
+    for k in ("cpu_baseline", "parity_vs_cpu_sample", "parity_sample", "full_parity", "multi_gpu", "multi_dfa", "multi_dfa_bulk"):
         if k in main_res:
             res[k] = main_res[k]
     # N = 1 on a box that shows several GPUs: the C multi-device front on all of them, in a subprocess of its own

@@ -276,12 +276,23 @@ int fsm_hip_exec(const struct fsm_hip_dfa *dfa,
 	int (*fsm_getc)(void *opaque), void *opaque,
 	fsm_state_t *end, struct fsm_capture *captures);
 
-/* cf. fsm_vm_match_buffer() src/libfsm/vm.c:218-229: 1 / 0, -1 on error. */
+/* cf. fsm_vm_match_buffer() src/libfsm/vm.c:218-229: 1 / 0, -1 on error.  (1 MiB and more: the engine below.) */
 int fsm_hip_match_buffer(const struct fsm_hip_dfa *dfa, const char *buf, size_t n);
 
-/* cf. fsm_vm_match_file() src/libfsm/vm.c:188-216: the file is read in 64 KiB chunks, the state
- * carried from chunk to chunk on the device; reading stops once the result is decided. */
+/* cf. fsm_vm_match_file() src/libfsm/vm.c:188-216 (what re(1) -x runs on every file it is given, src/re/main.c:1106-1181):
+ * 1 / 0, -1 + errno on error; a read error gives 0 as the reference's does.  A file of up to 256 KiB is one plain call.  A
+ * bigger one is read in 32 MiB windows (two pinned buffers: window k + 1 is read while k is walked); a window crosses PCIe
+ * once and is walked as 1 KiB pieces AT ONCE, one per lane, each from a guessed state (START), the guesses then corrected
+ * from the previous piece's result until none changes -- at that fixed point every piece has started where the sequential
+ * walk would have, so the result is exactly fsm_exec's over the whole file (file.hip).  A DFA built from patterns forgets
+ * within a piece and the second pass already stands; an automaton that counts pays one pass per piece, the sequential cost.
+ * Reading stops once the state can no longer change (DEAD or absorbing), as the VM's STOP does. */
 int fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f);
+/* the same engine over memory; *end_state (optional) receives the caller's end state id or FSM_HIP_NO_MATCH */
+int fsm_hip_match_buffer_big(const struct fsm_hip_dfa *dfa, const char *buf, size_t n, uint32_t *end_state);
+/* how the last such call of this process went: windows walked and passes over them (2 per window where every guess stood
+ * after its first correction; 0 / 0: a small input, one plain call) */
+void fsm_hip_match_last_passes(unsigned *windows, unsigned *passes);
 
 /* Flatten a struct fsm * into a malloc'd description (free with
  * fsm_hip_desc_free).  Exposed so callers can serialise the table. */
@@ -475,6 +486,27 @@ int fsm_hip_exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hi
 /* the same with DEVICE pointers inside b[] (the array itself is host memory); enqueued on hip_stream, not waited for.
  * Not capturable into a HIP graph (the descriptors ride in a staging block that the next call reuses). */
 int fsm_hip_exec_multi_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k, void *hip_stream);
+/* ... with end-ids delivered by the device, per job (what the reference's multi-pattern consumers want beside accept / reject:
+ * re(1) -z src/re/main.c:1152-1166, the generated matchers' `unsigned *id` src/libfsm/print/c.c:569-619): id_out (n entries,
+ * optional) gets what fsm_hip_exec_batch_ids writes under ids_mode -- the lowest id of the end state (FSM_HIP_IDS_EARLIEST),
+ * the index of its id set (FSM_HIP_IDS_RET, the dfa's own fsm_hip_ret_* tables), FSM_HIP_NO_ID for an end state without ids,
+ * FSM_HIP_NO_MATCH for a rejected input; FSM_HIP_IDS_ERROR refuses the whole submission (EINVAL, nothing launched) when a dfa
+ * that is asked for ids has an end state with more than one.  The id tables ride in the same copy as the automata's: a dfa
+ * created with FSM_HIP_DEFER_UPLOAD still uploads nothing of its own.  Jobs without id_out cost what they cost above. */
+struct fsm_hip_multi_batch_ids {
+	const unsigned char *base;
+	const uint64_t *off;          /* n + 1 */
+	size_t n;
+	uint32_t *end_out;
+	uint64_t *accept_bitmap;
+	uint32_t *id_out;
+};
+int fsm_hip_exec_multi_ids(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode);
+int fsm_hip_exec_multi_ids_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode, void *hip_stream);
+/* The device-pointer forms fuse every job whose plain next-state table fits the kernel's LDS copy (16 384 entries), whatever
+ * its line count: workgroups of four wavefronts map to (dfa, 256 consecutive lines) and share one copy of that dfa's table --
+ * 1 024 small automata x 1e5 lines each are ONE launch (round 5 sent every job above 65 536 lines through its dfa's own walk,
+ * one launch each). */
 /* kernels the last fsm_hip_exec_multi* call of this process launched (1 when every job was small), and how many jobs rode
  * in the fused one */
 unsigned fsm_hip_multi_last_launches(void);

@@ -732,6 +732,22 @@ class HipDfa:
             raise _oserr("fsm_hip_match_file")
         return r
 
+    def match_buffer_big(self, data: bytes):
+        """fsm_hip_match_buffer_big: (1 / 0, caller's end state or NO_MATCH) of ONE input walked by the whole device."""
+        e = C.c_uint32(NO_MATCH)
+        buf = (C.c_char * max(len(data), 1)).from_buffer_copy(data if len(data) else b"\0")
+        C.set_errno(0)
+        r = self._lib.fsm_hip_match_buffer_big(C.c_void_p(self._h), buf, C.c_size_t(len(data)), C.byref(e))
+        if r < 0:
+            raise _oserr("fsm_hip_match_buffer_big")
+        return r, e.value
+
+    def match_last_passes(self):
+        """(windows, passes) of the last match_file / match_buffer_big call of this process"""
+        w, p_ = C.c_uint(0), C.c_uint(0)
+        self._lib.fsm_hip_match_last_passes(C.byref(w), C.byref(p_))
+        return w.value, p_.value
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.fsm_hip_last_kernel_ms(self._h))
 
@@ -956,6 +972,48 @@ def exec_multi_device(dfas: Sequence["HipDfa"], jobs: Sequence[tuple], stream: i
     C.set_errno(0)
     if lib.fsm_hip_exec_multi_device(hs, arr, C.c_size_t(k), C.c_void_p(stream or None)) != 0:
         raise _oserr("fsm_hip_exec_multi_device")
+
+
+class MultiBatchIds(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("off", C.c_void_p), ("n", C.c_size_t), ("end_out", C.c_void_p), ("accept_bitmap", C.c_void_p), ("id_out", C.c_void_p)]
+
+
+def exec_multi_ids(dfas: Sequence["HipDfa"], jobs: Sequence[Sequence[bytes]], ids_mode: int):
+    """fsm_hip_exec_multi_ids: job q = the strings jobs[q] through dfas[q], ONE submission, end-ids by the device.
+    Returns [(end, bitmap, ids), ...]."""
+    lib = load_library()
+    k = len(jobs)
+    keep, arr, outs = [], (MultiBatchIds * max(k, 1))(), []
+    for q, strs in enumerate(jobs):
+        n = len(strs)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in strs])
+        base = np.frombuffer(b"".join(strs) or b"\0", dtype=np.uint8)
+        end = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+        ids = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+        bm = np.zeros((n + 63) // 64, dtype=np.uint64)
+        keep += [off, base, end, bm, ids]
+        arr[q].base, arr[q].off, arr[q].n = base.ctypes.data, off.ctypes.data, n
+        arr[q].end_out, arr[q].accept_bitmap, arr[q].id_out = (end.ctypes.data, bm.ctypes.data, ids.ctypes.data) if n else (None, None, None)
+        outs.append((end, bm, ids))
+    hs = (C.c_void_p * max(k, 1))(*[d._h for d in dfas])
+    C.set_errno(0)
+    if lib.fsm_hip_exec_multi_ids(hs, arr, C.c_size_t(k), C.c_int(ids_mode)) != 0:
+        raise _oserr("fsm_hip_exec_multi_ids")
+    return outs
+
+
+def exec_multi_ids_device(dfas: Sequence["HipDfa"], jobs: Sequence[tuple], ids_mode: int, stream: int = 0):
+    """fsm_hip_exec_multi_ids_device: jobs[q] = (d_base, d_off, n, d_end, d_bitmap, d_ids) device pointers (0 = NULL)."""
+    lib = load_library()
+    k = len(jobs)
+    arr = (MultiBatchIds * max(k, 1))()
+    for q, (b, o, n, e, m, i) in enumerate(jobs):
+        arr[q].base, arr[q].off, arr[q].n, arr[q].end_out, arr[q].accept_bitmap, arr[q].id_out = b or None, o or None, n, e or None, m or None, i or None
+    hs = (C.c_void_p * max(k, 1))(*[d._h for d in dfas])
+    C.set_errno(0)
+    if lib.fsm_hip_exec_multi_ids_device(hs, arr, C.c_size_t(k), C.c_int(ids_mode), C.c_void_p(stream or None)) != 0:
+        raise _oserr("fsm_hip_exec_multi_ids_device")
 
 
 def multi_last_launches() -> int:

@@ -848,7 +848,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const bool pick_len = varlen && known_bytes == 0 && !hint.short_mean && d->knob_input_mode < 0 && c.mode == IN_RAGGED;
 	/* the 32-bit lines kernel: plain outputs, a packed front, < 2^29 inputs; the batch's size: known (1 / 0) or not (-1) */
 	const bool lines_cand = !eager && a.out2 == nullptr && a.state_io == nullptr && (a.off != nullptr || a.off32 != nullptr || a.tbase != nullptr) &&
-		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len) && d->plan.layout != FSM_HIP_LAYOUT_SPARSE;   /* (launch.h lines32_ok) */
+		a.n < 0x1FFFFFF0ull && !(a.early & 32u) && (c.mode == IN_GENERIC || pick_len);
 	int fits32 = !lines_cand ? 0 : a.off32 != nullptr ? 1 : known_bytes != 0 ? (known_bytes < ((uint64_t)1 << 32) ? 1 : 0) : -1;
 	bool skip_generic = false;
 	if (fits32 < 0 && pick_len) {
@@ -1843,13 +1843,11 @@ fail:
  *   ret:      index of the state's id set in the de-duplicated list of sets, ordered by
  *             count, then memcmp of the id arrays -- the order build_retlist() produces
  *             (src/libfsm/vm/retlist.c:93-138, cmp_ret). */
-static int ensure_ids(fsm_hip_dfa *d)
+typedef std::vector<uint32_t> IdSet;
+/* the de-duplicated id sets of the end states in build_retlist()'s order (src/libfsm/vm/retlist.c:93-138), from the plan alone */
+static void build_ret_sets(const Plan &p, std::vector<uint32_t> &ret_off, std::vector<uint32_t> &ret_ids, std::map<IdSet, uint32_t> &index)
 {
-	if (ensure_uploaded(d) != 0) return -1;
-	DfaLock lk(d->mu);
-	if (d->ids_ready) return 0;
-	const Plan &p = d->plan;
-	typedef std::vector<uint32_t> Set;
+	typedef IdSet Set;
 	std::vector<Set> sets;
 	/* end states = those appearing in fin */
 	std::vector<uint8_t> is_end(p.nstates, 0);
@@ -1863,14 +1861,49 @@ static int ensure_ids(fsm_hip_dfa *d)
 		return !a.empty() && memcmp(a.data(), b.data(), a.size() * sizeof(uint32_t)) < 0;
 	});
 	sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
-	std::map<Set, uint32_t> index;
-	d->ret_off.assign(1, 0);
-	d->ret_ids.clear();
+	ret_off.assign(1, 0);
+	ret_ids.clear();
+	index.clear();
 	for (uint32_t k = 0; k < sets.size(); k++) {
 		index[sets[k]] = k;
-		d->ret_ids.insert(d->ret_ids.end(), sets[k].begin(), sets[k].end());
-		d->ret_off.push_back((uint32_t)d->ret_ids.size());
+		ret_ids.insert(ret_ids.end(), sets[k].begin(), sets[k].end());
+		ret_off.push_back((uint32_t)ret_ids.size());
 	}
+}
+
+/* for multi.hip (dfa_access.h): what fsm_hip_exec_batch_ids writes for an input that ends in renumbered state n (Plan::dense's
+ * numbering), mode EARLIEST or RET, from the plan alone -- a dfa created with FSM_HIP_DEFER_UPLOAD stays without tables of its
+ * own.  *conflict: the lowest caller's end state with more than one id, or NO_MATCH (what FSM_HIP_IDS_ERROR refuses). */
+namespace fsmhip {
+int dfa_ids_by_state(const fsm_hip_dfa *d, int mode, std::vector<uint32_t> &out, uint32_t *conflict)
+{
+	const Plan &p = d->plan;
+	std::vector<uint32_t> ro, ri;
+	std::map<IdSet, uint32_t> index;
+	if (mode == FSM_HIP_IDS_RET) build_ret_sets(p, ro, ri, index);
+	out.assign(p.S1, FSM_HIP_NO_MATCH);
+	uint32_t cf = FSM_HIP_NO_MATCH;
+	for (uint32_t n = 0; n < p.S1; n++) {
+		const uint32_t s = p.fin[n];
+		if (s == FSM_HIP_NO_MATCH) continue;
+		const uint32_t a = p.endid_off[s], b = p.endid_off[s + 1];
+		if (b - a > 1 && s < cf) cf = s;
+		out[n] = mode == FSM_HIP_IDS_RET ? index[IdSet(p.endids.begin() + a, p.endids.begin() + b)] : (b > a ? p.endids[a] : FSM_HIP_NO_ID);
+	}
+	if (conflict) *conflict = cf;
+	return 0;
+}
+}
+
+static int ensure_ids(fsm_hip_dfa *d)
+{
+	if (ensure_uploaded(d) != 0) return -1;
+	DfaLock lk(d->mu);
+	if (d->ids_ready) return 0;
+	const Plan &p = d->plan;
+	typedef IdSet Set;
+	std::map<Set, uint32_t> index;
+	build_ret_sets(p, d->ret_off, d->ret_ids, index);
 	std::vector<uint32_t> fe(d->fin_host.size(), FSM_HIP_NO_MATCH), fr(d->fin_host.size(), FSM_HIP_NO_MATCH);
 	for (size_t i = 0; i < d->fin_host.size(); i++) {
 		const uint32_t s = d->fin_host[i];

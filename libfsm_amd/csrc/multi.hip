@@ -41,9 +41,11 @@ struct MultiJob {
 	const uint32_t *dense;   /* [S1][C] next (renumbered) state */
 	const uint32_t *cls4;    /* [64] byte -> class, four to a word */
 	const uint32_t *fin;     /* [S1] caller's end state id or NO_MATCH */
+	const uint32_t *fid;     /* [S1] what fsm_hip_exec_batch_ids writes for an input ending there, or null */
 	const uint8_t  *base;
 	const uint64_t *off;     /* n + 1 */
 	uint32_t *end_out;       /* or null */
+	uint32_t *id_out;        /* or null */
 	uint64_t *bitmap;        /* or null */
 	uint64_t n;
 	uint64_t limit;          /* bytes of this job's text that may be read (>= off[n]); 0: off[n] */
@@ -55,6 +57,7 @@ struct MultiJob {
 static_assert(sizeof(MultiJob) % 16 == 0, "descriptors are read as aligned records");
 
 typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+constexpr uint32_t MULTI_WAVES = 4;                    /* wavefronts per workgroup: MULTI_WAVES * 64 consecutive lines of ONE job share a table copy */
 
 __device__ __forceinline__ uint32_t byte_at(const u32x4m &w, int k)
 {
@@ -62,42 +65,50 @@ __device__ __forceinline__ uint32_t byte_at(const u32x4m &w, int k)
 	return (d >> (8 * (k & 3))) & 0xffu;
 }
 
-/* one workgroup = one wavefront = 64 consecutive lines of ONE job */
-__global__ void __launch_bounds__(64)
+/* one workgroup = MULTI_WAVES wavefronts = 256 consecutive lines of ONE job.  (Round 5: one wavefront per workgroup -- sized for
+ * retest's three lines a record; a job of 1e5 lines then copied its table into LDS once per 64 of them.)  Every pointer of the
+ * descriptor is device memory: the loads name that address space (no FLAT instruction: tests/test_abi.py). */
+__global__ void __launch_bounds__(MULTI_WAVES * 64)
 walk_multi(const MultiJob *jobs, const uint32_t *tile_job)
 {
+	typedef const uint32_t __attribute__((address_space(1))) *g_u32p;
+	typedef const uint64_t __attribute__((address_space(1))) *g_u64p;
+	typedef const uint8_t __attribute__((address_space(1))) *g_u8p;
+	typedef u32x4m __attribute__((aligned(1))) u32x4_any;
+	typedef const u32x4_any __attribute__((address_space(1))) *g_chunkp;
 	__shared__ uint32_t cls4[64];
 	__shared__ uint16_t tab[MULTI_LDS_ENTRIES];
 	const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_job[blockIdx.x]);
 	const MultiJob &j = jobs[ji];
-	const uint32_t lane = threadIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t C = j.C, S1 = j.S1;
 	const bool in_lds = j.lds_table != 0u;
-	cls4[lane] = j.cls4[lane];
+	const g_u32p dense = (g_u32p)(uintptr_t)j.dense, fin = (g_u32p)(uintptr_t)j.fin, fid = (g_u32p)(uintptr_t)j.fid;
+	const g_u64p off = (g_u64p)(uintptr_t)j.off;
+	if (tid < 64u) cls4[tid] = ((g_u32p)(uintptr_t)j.cls4)[tid];
 	if (in_lds)
-		for (uint32_t e = lane; e < S1 * C; e += 64u) tab[e] = (uint16_t)(j.dense[e] * C);   /* row offset of the next state */
+		for (uint32_t e = tid; e < S1 * C; e += MULTI_WAVES * 64u) tab[e] = (uint16_t)(dense[e] * C);   /* row offset of the next state */
 	__syncthreads();
 
-	const uint64_t tile = blockIdx.x - j.tile0, i = tile * 64u + lane;
+	const uint64_t tile = blockIdx.x - j.tile0, i = tile * (MULTI_WAVES * 64u) + tid;
 	const bool valid = i < j.n;
 	uint64_t beg = 0, len = 0;
-	if (valid) { beg = j.off[i]; len = j.off[i + 1] - beg; }
-	const uint64_t limit = j.limit != 0u ? j.limit : j.off[j.n];
+	if (valid) { beg = off[i]; len = off[i + 1] - beg; }
+	const uint64_t limit = j.limit != 0u ? j.limit : off[j.n];
 	const uint32_t unit = in_lds ? C : 1u;            /* the walk's state: row offset (LDS) or state index (global table) */
 	const uint32_t absorbing = j.abs_min * unit;
 	uint32_t s = j.start * unit;
-	const uint8_t *p = j.base + beg;
-	typedef u32x4m __attribute__((aligned(1))) u32x4_any;
+	const uint64_t p = reinterpret_cast<uint64_t>(j.base) + beg;
 
 	for (uint64_t t = 0; __any(t < len && s < absorbing); t += 16u) {
 		if (!(t < len && s < absorbing)) continue;
 		const uint32_t cnt = len - t < 16u ? (uint32_t)(len - t) : 16u;
 		u32x4m w = {0u, 0u, 0u, 0u};
 		if (beg + t + 16u <= limit) {
-			w = *reinterpret_cast<const u32x4_any *>(p + t);
+			w = *(g_chunkp)(p + t);
 		} else {
 			uint32_t d[4] = {0u, 0u, 0u, 0u};
-			for (uint32_t k = 0; k < cnt; k++) d[k >> 2] |= (uint32_t)p[t + k] << ((k & 3u) * 8u);
+			for (uint32_t k = 0; k < cnt; k++) d[k >> 2] |= (uint32_t)((g_u8p)(p + t))[k] << ((k & 3u) * 8u);
 			w = u32x4m{d[0], d[1], d[2], d[3]};
 		}
 #pragma unroll
@@ -105,18 +116,22 @@ walk_multi(const MultiJob *jobs, const uint32_t *tile_job)
 			if ((uint32_t)k < cnt) {
 				const uint32_t b = byte_at(w, k);
 				const uint32_t c = (cls4[b >> 2] >> ((b & 3u) * 8u)) & 0xffu;
-				s = in_lds ? (uint32_t)tab[s + c] : j.dense[(uint64_t)s * C + c];
+				if (in_lds) s = (uint32_t)tab[s + c];
+				else s = dense[(uint64_t)s * C + c];
 			}
 		}
 	}
+	const uint32_t fs = in_lds ? s / C : s;
 	uint32_t end = FSM_HIP_NO_MATCH;
-	if (valid) end = j.fin[in_lds ? s / C : s];
-	if (valid && j.end_out != nullptr) j.end_out[i] = end;
+	if (valid) end = fin[fs];
+	typedef uint32_t __attribute__((address_space(1))) *g_u32w;
+	typedef uint64_t __attribute__((address_space(1))) *g_u64w;
+	if (valid && j.end_out != nullptr) ((g_u32w)(uintptr_t)j.end_out)[i] = end;
+	if (valid && j.id_out != nullptr) ((g_u32w)(uintptr_t)j.id_out)[i] = fid[fs];
 	const uint64_t m = __ballot(valid && end != FSM_HIP_NO_MATCH);
-	if (j.bitmap != nullptr && lane == 0u) j.bitmap[tile] = m;
+	if (j.bitmap != nullptr && lane == 0u && (tile * MULTI_WAVES + (tid >> 6)) * 64u < j.n) ((g_u64w)(uintptr_t)j.bitmap)[tile * MULTI_WAVES + (tid >> 6)] = m;
 }
 
-/* per-device staging of the fused launch: one pinned block, one device block of the same layout */
 struct MultiCtx {
 	std::mutex mu;
 	hipStream_t s = nullptr;
@@ -168,20 +183,35 @@ int ctx_reserve(MultiCtx &cx, size_t bytes)
 
 /* where everything of a fused submission lies in the staging block (the same offsets on both sides) */
 struct Lay {
-	std::vector<size_t> dense, cls, fin, off, text, end, bm;   /* per fused job; (size_t)-1: not staged */
+	std::vector<size_t> dense, cls, fin, fid, off, text, end, bm, ids;   /* per fused job; (size_t)-1: not staged */
 	size_t jobs = 0, tiles = 0, in_end = 0, total = 0;
 	uint32_t ntiles = 0;
 };
 
-bool fusable(const Plan *p, size_t n, uint64_t bytes)
+/* host front: a job small enough to stage (its lines ride in the one copy); device front: any job whose plain table fits the
+ * kernel's LDS copy -- nothing of it is staged but the table, and MULTI_WAVES * 64 lines share each copy (round 5 fused on the
+ * line count alone there and sent 1e5-line jobs, one launch each, through their dfa's own walk; a job with a bigger table
+ * still goes that way: its planned layout beats a plain table in L2) */
+bool fusable(const Plan *p, size_t n, uint64_t bytes, bool host)
 {
-	return n != 0 && n <= MULTI_FUSE_LINES && bytes <= MULTI_FUSE_BYTES && p->S1 != 0 && p->dense.size() == (size_t)p->S1 * p->C &&
-	       p->dense.size() * 4u <= MULTI_FUSE_TABLE;
+	if (n == 0 || p->S1 == 0 || p->dense.size() != (size_t)p->S1 * p->C || p->dense.size() * 4u > MULTI_FUSE_TABLE) return false;
+	if (host) return n <= MULTI_FUSE_LINES && bytes <= MULTI_FUSE_BYTES;
+	return p->dense.size() <= MULTI_LDS_ENTRIES && n < ((size_t)1 << 31);
 }
+
+/* one job as the entry points hand it over (ids: optional) */
+struct JobView {
+	const unsigned char *base;
+	const uint64_t *off;
+	size_t n;
+	uint32_t *end_out;
+	uint64_t *accept_bitmap;
+	uint32_t *id_out;
+};
 
 /* Run the jobs idx[] (all on device `device`) of a submission.  host = true: b[] holds host pointers (lines and results are
  * staged); false: device pointers, launched on `stream` and not waited for. */
-int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, const std::vector<size_t> &idx,
+int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const JobView *b, int ids_mode, const std::vector<size_t> &idx,
 	bool host, hipStream_t stream, unsigned *launches, unsigned *fused_jobs)
 {
 	if (device < 0 || device >= MAXDEV) { errno = ENODEV; return -1; }
@@ -195,6 +225,7 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 
 	/* which jobs ride in the fused launch */
 	std::vector<size_t> fj, single;
+	std::vector<std::vector<uint32_t>> fids;      /* per fused job: ids by renumbered state (empty: none asked for) */
 	Lay L;
 	size_t o = 0;
 	{
@@ -203,27 +234,31 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 			const Plan *p = dfa_plan(dfa[q]);
 			const uint64_t bytes = b[q].n ? (host ? b[q].off[b[q].n] : 0) : 0;
 			if (b[q].n == 0) continue;
-			const size_t need = up16(p->dense.size() * 4u) + 256u + up16((size_t)p->S1 * 4u) +
-				(host ? up16((b[q].n + 1) * 8u) + up16((size_t)bytes + 16u) + up16(b[q].n * 4u) + up16(((b[q].n + 63u) / 64u) * 8u) : 0u);
-			if (fusable(p, b[q].n, bytes) && staged + need <= MULTI_STAGE_CAP) { fj.push_back(q); staged += need; }
+			const size_t need = up16(p->dense.size() * 4u) + 256u + 2u * up16((size_t)p->S1 * 4u) +
+				(host ? up16((b[q].n + 1) * 8u) + up16((size_t)bytes + 16u) + 2u * up16(b[q].n * 4u) + up16(((b[q].n + 63u) / 64u) * 8u) : 0u);
+			if (fusable(p, b[q].n, bytes, host) && staged + need <= MULTI_STAGE_CAP) { fj.push_back(q); staged += need; }
 			else single.push_back(q);
 		}
 	}
 	if (!fj.empty()) {
 		const size_t kf = fj.size();
 		uint64_t tiles = 0;
-		for (size_t q : fj) tiles += (b[q].n + 63u) / 64u;
+		for (size_t q : fj) tiles += (b[q].n + MULTI_WAVES * 64u - 1u) / (MULTI_WAVES * 64u);
 		if (tiles > 0x7FFFFFFFu) { errno = EINVAL; return -1; }
+		fids.resize(kf);
+		for (size_t f = 0; f < kf; f++)
+			if (b[fj[f]].id_out != nullptr && dfa_ids_by_state(dfa[fj[f]], ids_mode, fids[f], nullptr) != 0) return -1;
 		L.ntiles = (uint32_t)tiles;
 		L.jobs = o; o += up16(kf * sizeof(MultiJob));
 		L.tiles = o; o += up16((size_t)tiles * 4u);
-		L.dense.resize(kf); L.cls.resize(kf); L.fin.resize(kf); L.off.assign(kf, (size_t)-1); L.text.assign(kf, (size_t)-1);
-		L.end.assign(kf, (size_t)-1); L.bm.assign(kf, (size_t)-1);
+		L.dense.resize(kf); L.cls.resize(kf); L.fin.resize(kf); L.fid.assign(kf, (size_t)-1); L.off.assign(kf, (size_t)-1); L.text.assign(kf, (size_t)-1);
+		L.end.assign(kf, (size_t)-1); L.bm.assign(kf, (size_t)-1); L.ids.assign(kf, (size_t)-1);
 		for (size_t f = 0; f < kf; f++) {
 			const Plan *p = dfa_plan(dfa[fj[f]]);
 			L.dense[f] = o; o += up16(p->dense.size() * 4u);
 			L.cls[f] = o; o += 256u;
 			L.fin[f] = o; o += up16((size_t)p->S1 * 4u);
+			if (!fids[f].empty()) { L.fid[f] = o; o += up16((size_t)p->S1 * 4u); }
 			if (host) {
 				const size_t n = b[fj[f]].n;
 				L.off[f] = o; o += up16((n + 1) * 8u);
@@ -235,6 +270,7 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 			for (size_t f = 0; f < kf; f++) {
 				const size_t n = b[fj[f]].n;
 				if (b[fj[f]].end_out) { L.end[f] = o; o += up16(n * 4u); }
+				if (b[fj[f]].id_out) { L.ids[f] = o; o += up16(n * 4u); }
 				if (b[fj[f]].accept_bitmap) { L.bm[f] = o; o += up16(((n + 63u) / 64u) * 8u); }
 			}
 		L.total = o;
@@ -253,8 +289,10 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 			for (unsigned w = 0; w < 64; w++)
 				c4[w] = (uint32_t)p->cls[4 * w] | ((uint32_t)p->cls[4 * w + 1] << 8) | ((uint32_t)p->cls[4 * w + 2] << 16) | ((uint32_t)p->cls[4 * w + 3] << 24);
 			memcpy(cx.pin + L.fin[f], p->fin.data(), (size_t)p->S1 * 4u);
+			if (L.fid[f] != (size_t)-1) memcpy(cx.pin + L.fid[f], fids[f].data(), (size_t)p->S1 * 4u);
 			MultiJob &j = jobs[f];
 			memset(&j, 0, sizeof j);
+			j.fid = L.fid[f] != (size_t)-1 ? reinterpret_cast<const uint32_t *>(cx.dev + L.fid[f]) : nullptr;
 			j.dense = reinterpret_cast<const uint32_t *>(cx.dev + L.dense[f]);
 			j.cls4 = reinterpret_cast<const uint32_t *>(cx.dev + L.cls[f]);
 			j.fin = reinterpret_cast<const uint32_t *>(cx.dev + L.fin[f]);
@@ -266,12 +304,14 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 				j.base = cx.dev + L.text[f];
 				j.off = reinterpret_cast<const uint64_t *>(cx.dev + L.off[f]);
 				j.end_out = L.end[f] != (size_t)-1 ? reinterpret_cast<uint32_t *>(cx.dev + L.end[f]) : nullptr;
+				j.id_out = L.ids[f] != (size_t)-1 ? reinterpret_cast<uint32_t *>(cx.dev + L.ids[f]) : nullptr;
 				j.bitmap = L.bm[f] != (size_t)-1 ? reinterpret_cast<uint64_t *>(cx.dev + L.bm[f]) : nullptr;
 				j.limit = bytes + 16u;    /* the staged text is padded: whole 16-byte loads everywhere */
 			} else {
 				j.base = b[q].base;
 				j.off = b[q].off;
 				j.end_out = b[q].end_out;
+				j.id_out = b[q].id_out;
 				j.bitmap = b[q].accept_bitmap;
 				j.limit = 0;              /* the kernel reads off[n] */
 			}
@@ -279,13 +319,13 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 			j.C = p->C; j.S1 = p->S1; j.start = p->start; j.abs_min = p->abs_min;
 			j.tile0 = t0;
 			j.lds_table = p->dense.size() <= MULTI_LDS_ENTRIES ? 1u : 0u;
-			const uint32_t nt = (uint32_t)((n + 63u) / 64u);
+			const uint32_t nt = (uint32_t)((n + MULTI_WAVES * 64u - 1u) / (MULTI_WAVES * 64u));
 			for (uint32_t t = 0; t < nt; t++) tile_job[t0 + t] = (uint32_t)f;
 			t0 += nt;
 		}
 		hipStream_t s = host ? cx.s : stream;
 		MTRY(hipMemcpyAsync(cx.dev, cx.pin, L.in_end, hipMemcpyHostToDevice, s));
-		hipLaunchKernelGGL(walk_multi, dim3(L.ntiles), dim3(64), 0, s, reinterpret_cast<const MultiJob *>(cx.dev + L.jobs),
+		hipLaunchKernelGGL(walk_multi, dim3(L.ntiles), dim3(MULTI_WAVES * 64u), 0, s, reinterpret_cast<const MultiJob *>(cx.dev + L.jobs),
 		                   reinterpret_cast<const uint32_t *>(cx.dev + L.tiles));
 		MTRY(hipGetLastError());
 		(*launches)++;
@@ -299,8 +339,13 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 	}
 	/* the big ones: each dfa's own walk, beside the fused launch (host: its synchronous front; device: enqueued on the stream) */
 	for (size_t q : single) {
-		const int r = host ? fsm_hip_exec_batch_offsets(dfa[q], b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap)
-		                   : fsm_hip_exec_batch_offsets_device(dfa[q], b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, stream);
+		int r;
+		if (b[q].id_out == nullptr)
+			r = host ? fsm_hip_exec_batch_offsets(dfa[q], b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap)
+			         : fsm_hip_exec_batch_offsets_device(dfa[q], b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, stream);
+		else   /* every output of the job from ONE walk (fsm_hip_exec_batch_packed_all*) */
+			r = host ? fsm_hip_exec_batch_packed_all(dfa[q], b[q].base, FSM_HIP_META_OFF64, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, ids_mode, b[q].id_out, nullptr)
+			         : fsm_hip_exec_batch_packed_all_device(dfa[q], b[q].base, FSM_HIP_META_OFF64, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, ids_mode, b[q].id_out, nullptr, stream);
 		if (r != 0) { if (host && !fj.empty()) (void)hipStreamSynchronize(cx.s); return -1; }
 		(*launches)++;
 	}
@@ -309,16 +354,32 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const str
 		for (size_t f = 0; f < fj.size(); f++) {
 			const size_t q = fj[f], n = b[q].n;
 			if (L.end[f] != (size_t)-1) memcpy(b[q].end_out, cx.pin + L.end[f], n * 4u);
+			if (L.ids[f] != (size_t)-1) memcpy(b[q].id_out, cx.pin + L.ids[f], n * 4u);
 			if (L.bm[f] != (size_t)-1) memcpy(b[q].accept_bitmap, cx.pin + L.bm[f], ((n + 63u) / 64u) * 8u);
 		}
 	}
 	return 0;
 }
 
-int exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k, bool host, hipStream_t stream)
+int exec_multi(const struct fsm_hip_dfa *const *dfa, const JobView *b, int ids_mode, size_t k, bool host, hipStream_t stream)
 {
 	if (k == 0) { g_last_launches = 0; g_last_fused_jobs = 0; return 0; }
 	if (dfa == nullptr || b == nullptr) { errno = EINVAL; return -1; }
+	bool want_ids = false;
+	for (size_t q = 0; q < k; q++) want_ids = want_ids || b[q].id_out != nullptr;
+	if (want_ids) {
+		if (ids_mode != FSM_HIP_IDS_EARLIEST && ids_mode != FSM_HIP_IDS_RET && ids_mode != FSM_HIP_IDS_ERROR) { errno = EINVAL; return -1; }
+		if (ids_mode == FSM_HIP_IDS_ERROR) {
+			/* AMBIG_ERROR: an end state with more than one id is refused before anything is launched (as fsm_hip_exec_batch_ids) */
+			std::vector<uint32_t> tmp;
+			for (size_t q = 0; q < k; q++) {
+				uint32_t cf = FSM_HIP_NO_MATCH;
+				if (dfa[q] == nullptr) { errno = EINVAL; return -1; }
+				if (b[q].id_out != nullptr && (dfa_ids_by_state(dfa[q], FSM_HIP_IDS_EARLIEST, tmp, &cf) != 0 || cf != FSM_HIP_NO_MATCH)) { errno = EINVAL; return -1; }
+			}
+			ids_mode = FSM_HIP_IDS_EARLIEST;
+		}
+	}
 	for (size_t q = 0; q < k; q++) {
 		if (dfa[q] == nullptr || (b[q].n != 0 && b[q].off == nullptr)) { errno = EINVAL; return -1; }
 		if (host && b[q].n != 0) {
@@ -337,7 +398,7 @@ int exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_
 	for (int dv : devs) {
 		std::vector<size_t> idx;
 		for (size_t q = 0; q < k; q++) if (dfa_device(dfa[q]) == dv) idx.push_back(q);
-		if (run_device_group(dv, dfa, b, idx, host, stream, &launches, &fused) != 0) return -1;
+		if (run_device_group(dv, dfa, b, ids_mode, idx, host, stream, &launches, &fused) != 0) return -1;
 	}
 	g_last_launches = launches;
 	g_last_fused_jobs = fused;
@@ -346,14 +407,41 @@ int exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_
 
 } // namespace
 
+static std::vector<JobView> views(const struct fsm_hip_multi_batch *b, size_t k)
+{
+	std::vector<JobView> v(b ? k : 0);
+	for (size_t q = 0; q < v.size(); q++) v[q] = JobView{b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, nullptr};
+	return v;
+}
+static std::vector<JobView> views(const struct fsm_hip_multi_batch_ids *b, size_t k)
+{
+	std::vector<JobView> v(b ? k : 0);
+	for (size_t q = 0; q < v.size(); q++) v[q] = JobView{b[q].base, b[q].off, b[q].n, b[q].end_out, b[q].accept_bitmap, b[q].id_out};
+	return v;
+}
+
 extern "C" int fsm_hip_exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k)
 {
-	return exec_multi(dfa, b, k, true, nullptr);
+	const std::vector<JobView> v = views(b, k);
+	return exec_multi(dfa, k && b ? v.data() : nullptr, 0, k, true, nullptr);
 }
 
 extern "C" int fsm_hip_exec_multi_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k, void *hip_stream)
 {
-	return exec_multi(dfa, b, k, false, static_cast<hipStream_t>(hip_stream));
+	const std::vector<JobView> v = views(b, k);
+	return exec_multi(dfa, k && b ? v.data() : nullptr, 0, k, false, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int fsm_hip_exec_multi_ids(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode)
+{
+	const std::vector<JobView> v = views(b, k);
+	return exec_multi(dfa, k && b ? v.data() : nullptr, ids_mode, k, true, nullptr);
+}
+
+extern "C" int fsm_hip_exec_multi_ids_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode, void *hip_stream)
+{
+	const std::vector<JobView> v = views(b, k);
+	return exec_multi(dfa, k && b ? v.data() : nullptr, ids_mode, k, false, static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" unsigned fsm_hip_multi_last_launches(void) { return g_last_launches.load(); }

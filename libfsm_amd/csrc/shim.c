@@ -334,6 +334,10 @@ fsm_hip_match_buffer(const struct fsm_hip_dfa *dfa, const char *buf, size_t n)
 {
 	uint32_t end = FSM_HIP_NO_MATCH;
 	uint64_t off[2];
+	if (n >= ((size_t) 1 << 20)) {
+		/* worth the whole device: pieces walked at once from guessed states, corrected until they stand (file.hip) */
+		return fsm_hip_match_buffer_big(dfa, buf, n, NULL);
+	}
 	off[0] = 0;
 	off[1] = n;
 	if (fsm_hip_exec_batch_offsets(dfa, (const unsigned char *) buf, off, 1, &end, NULL) != 0) {
@@ -384,53 +388,7 @@ fsm_hip_exec(const struct fsm_hip_dfa *dfa,
 	return 1;
 }
 
-/*
- * fsm_vm_match_file() keeps a struct vm_state across 4 KiB fread()s and stops reading as soon as
- * the VM has decided (src/libfsm/vm.c:188-216).  Same shape here on the streaming front: the state
- * is carried through fsm_hip_exec_batch_resume() chunk by chunk (64 KiB: one launch per chunk), and
- * reading stops once the state can no longer change -- DEAD (a missing edge, the VM's STOP fail) or
- * an absorbing state (the VM's STOP success shortcut, vm/ir.c:763-766).  A read error gives 0, as
- * the reference's ferror() check does.  Memory use is one chunk, whatever the file size.
- */
-int
-fsm_hip_match_file(const struct fsm_hip_dfa *dfa, FILE *f)
-{
-	enum { CHUNK = 65536 };
-	unsigned char *buf;
-	uint32_t st = FSM_HIP_STATE_START, end = FSM_HIP_NO_MATCH;
-	size_t got;
-	int first = 1;
-
-	if (dfa == NULL || f == NULL) {
-		errno = EINVAL;
-		return -1;
-	}
-	buf = malloc(CHUNK);
-	if (buf == NULL) {
-		errno = ENOMEM;
-		return -1;
-	}
-	for (;;) {
-		got = fread(buf, 1, CHUNK, f);
-		if (got == 0 && !first) {
-			break;
-		}
-		first = 0;
-		/* an empty file still needs one call: it accepts iff the start state is an end state */
-		if (fsm_hip_exec_batch_resume(dfa, buf, CHUNK, (uint32_t[]){ (uint32_t) got }, 1, &st, &end) != 0) {
-			free(buf);
-			return -1;
-		}
-		if (got < CHUNK || st == FSM_HIP_STATE_DEAD || fsm_hip_state_is_absorbing(dfa, st) == 1) {
-			break;
-		}
-	}
-	free(buf);
-	if (ferror(f)) {
-		return 0;
-	}
-	return end != FSM_HIP_NO_MATCH;
-}
+/* fsm_hip_match_file(): file.hip (the whole device on one input) */
 
 /* ---- on-disk form of a flat DFA description -------------------------- */
 /*

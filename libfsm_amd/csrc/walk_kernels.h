@@ -637,8 +637,14 @@ struct GlobPol {
 	__device__ __forceinline__ P pre(uint32_t b) const { return bp[b]; }
 	__device__ __forceinline__ uint32_t next(uint32_t st, P c) const
 	{
-		if (st < hot_bytes) return *reinterpret_cast<const uint32_t *>(hot + st + c * 4u);
-		return *reinterpret_cast<const uint32_t *>(tab + st + c * 4u);
+		/* explicit address spaces (see SparsePol::next_t: no FLAT load of a selected address) */
+		typedef const uint32_t __attribute__((address_space(3))) *lds_u32p;
+		typedef const uint32_t __attribute__((address_space(1))) *glb_u32p;
+		const uint32_t ad = st + c * 4u;
+		const bool cold = ad >= hot_bytes;
+		uint32_t v = *(lds_u32p)(uintptr_t)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)hot + (cold ? 0u : ad));
+		if (cold) v = *(glb_u32p)(uintptr_t)(tab + ad);
+		return v;
 	}
 };
 
@@ -661,6 +667,7 @@ struct Glob16Pol {
 	__device__ __forceinline__ static uint32_t code(S s) { return s; }
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	typedef const uint16_t __attribute__((address_space(3))) *lds_u16p;
+	typedef const uint16_t __attribute__((address_space(1))) *glb_u16p;
 	const uint8_t *bp;         /* LDS byte -> class map */
 	const unsigned char *tab;  /* device table */
 	uint32_t hot_lds;          /* LDS byte address of the copy of the table's first hot_bytes */
@@ -683,7 +690,7 @@ struct Glob16Pol {
 		const bool cold = ad >= hot_bytes;
 		uint32_t v = *(lds_u16p)(uintptr_t)(hot_lds + (cold ? 0u : ad));
 		if (__any(cold)) {
-			if (cold) v = *reinterpret_cast<const uint16_t *>(tab + ad);
+			if (cold) v = *(glb_u16p)(uintptr_t)(tab + ad);
 		}
 		return v;
 	}
@@ -698,8 +705,8 @@ struct Glob16Pol {
 		uint32_t v0 = *(lds_u16p)(uintptr_t)(hot_lds + (cold0 ? 0u : ad0));
 		uint32_t v1 = *(lds_u16p)(uintptr_t)(hot_lds + (cold1 ? 0u : ad1));
 		if (__any(cold0 | cold1)) {
-			if (cold0) v0 = *reinterpret_cast<const uint16_t *>(tab + ad0);
-			if (cold1) v1 = *reinterpret_cast<const uint16_t *>(tab + ad1);
+			if (cold0) v0 = *(glb_u16p)(uintptr_t)(tab + ad0);
+			if (cold1) v1 = *(glb_u16p)(uintptr_t)(tab + ad1);
 		}
 		s0 = v0;
 		s1 = v1;
@@ -728,7 +735,10 @@ struct SparsePol {
 	__device__ __forceinline__ static void finish(const WalkArgs &, uint64_t, bool, S) {}
 	typedef const u32x4 __attribute__((address_space(3))) *lds_rec_p;
 	typedef const uint32_t __attribute__((address_space(3))) *lds_u32_p;
+	typedef const u32x4 __attribute__((address_space(1))) *glb_rec_p;
+	typedef const uint32_t __attribute__((address_space(1))) *glb_u32_p;
 	const uint16_t *pm;        /* LDS: byte -> class | bit << 8 */
+	uint32_t ldense_lds;       /* LDS byte address of the first dense rows */
 	const uint32_t *ldense;    /* LDS: first dense rows         */
 	const u32x4 *lrec;         /* LDS: first H records (generic pointer: see the note on flat loads above) */
 	uint32_t lrec_lds;         /* the same as an LDS byte address, for the turns that are known to stay in LDS */
@@ -746,6 +756,7 @@ struct SparsePol {
 		HDE = hdr[2];
 		pm = reinterpret_cast<const uint16_t *>(lds + 64);
 		ldense = reinterpret_cast<const uint32_t *>(lds + hdr[3]);
+		ldense_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + hdr[3]);
 		lrec = reinterpret_cast<const u32x4 *>(lds + hdr[4]);
 		lrec_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds + hdr[4]);
 		grec = reinterpret_cast<const u32x4 *>(g + hdr[5]);
@@ -787,15 +798,20 @@ struct SparsePol {
 		/* first turn: the record of the state itself, LDS or global (one flat load of a selected address) */
 		bool first = true;
 		while (live) {
+			/* The record: LDS for the H states nearest the start state, device memory for the rest -- by an explicit ds_read_b128
+			 * (of record 0 for the lanes beyond H: an LDS read cannot fault) and an explicit global_load under the other lanes'
+			 * mask.  Rounds 2-5 left the choice to a generic pointer: ONE flat_load of a selected address, measured 10 % faster
+			 * on the record walk (422 vs 385 GB/s, profiles/r02_c5_steps.txt) -- but a FLAT instruction whose lanes split between
+			 * LDS and memory comes back over two paths, counts on both wait counters and may complete out of order, and the two
+			 * intermittent wrong-answer builds this project has met (round 2, round 5: profiles/r08i_*) were both kernels with
+			 * such loads inside lane-divergent loops.  Neither could be pinned on the instruction; the record walk is no longer
+			 * the fast path of anything (the lazy walk is), so the product now contains no FLAT load at all (tests/test_abi.py
+			 * checks the code objects). */
 			u32x4 r;
-			if (first) {
-				if (st < H) r = lrec[st]; else r = grec[st];
-			} else {
-				/* later turns visit bases, and a base is nearly always one of the LDS-resident records
-				 * nearest the start state: a plain ds_read_b128, no address selection */
-				if (__builtin_expect(st < H, 1)) r = *(lds_rec_p)(uintptr_t)(lrec_lds + st * 16u);
-				else r = grec[st];
-			}
+			const bool inl = st < H;
+			(void)first;
+			r = *(lds_rec_p)(uintptr_t)(lrec_lds + (inl ? st : 0u) * 16u);
+			if (!inl) r = *(glb_rec_p)(uintptr_t)(grec + st);
 			first = false;
 			const uint64_t bits = (uint64_t)r.x | ((uint64_t)r.y << 32);
 			const bool hit = (bits & sel) != 0u;
@@ -807,9 +823,9 @@ struct SparsePol {
 			if (dense || (hit && !(r.z & 0x40000000u))) {
 				if (dense) {
 					const uint32_t o = r.w + cls;
-					if (o < HDE) v = ldense[o]; else v = gdense[o];
+					if (o < HDE) v = *(lds_u32_p)(uintptr_t)(ldense_lds + o * 4u); else v = *(glb_u32_p)(uintptr_t)(gdense + o);
 				} else {
-					v = exc[v];
+					v = *(glb_u32_p)(uintptr_t)(exc + v);
 				}
 			}
 			const bool done = hit || fb || dense;
@@ -867,9 +883,11 @@ struct SparseFastPol : SparsePol {
 	 * for it, a select for the high half -- where a 64-bit select + 64-bit shift-add cost 8 vector operations per byte */
 	__device__ __forceinline__ S enter(uint32_t id) const
 	{
+		/* (explicit address spaces, as in SparsePol::next_t -- and for its reason; rounds 3-5 made this ONE flat load of a
+		 * selected address) */
 		const bool in = id < H;
-		const uint32_t lo = (in ? lrec_lo : grec_lo) + id * 16u, hi = in ? lrec_hi : grec_hi;
-		const u32x4 r = *reinterpret_cast<const u32x4 *>(((uint64_t)hi << 32) | lo);
+		u32x4 r = *(lds_rec_p)(uintptr_t)(lrec_lds + (in ? id : 0u) * 16u);
+		if (!in) r = *(glb_rec_p)(uintptr_t)(grec + id);
 		S s = { r.x, r.y, r.z, r.w, id };
 		return s;
 	}
@@ -1637,8 +1655,9 @@ __device__ __noinline__ u32x4 load_chunk_edge(uint64_t addr, bool want, uint64_t
 	if (!want) return *(glb_chunk_p)safe;
 	if (addr + 16u <= limit) return *(glb_chunk_p)addr;
 	uint32_t d[4] = {0u, 0u, 0u, 0u};
+	typedef const unsigned char __attribute__((address_space(1))) *glb_u8p;
 	for (uint32_t k = 0; k < 15u && addr + k < limit; k++)
-		d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(addr)[k] << ((k & 3u) * 8u);
+		d[k >> 2] |= (uint32_t)((glb_u8p)addr)[k] << ((k & 3u) * 8u);
 	return u32x4{d[0], d[1], d[2], d[3]};
 }
 
@@ -1936,14 +1955,15 @@ template <> struct lines_prefetch<LdsSelfPol> { static constexpr bool value = fa
 template <> struct lines_prefetch<SparsePol> { static constexpr bool value = false; };
 template <> struct lines_prefetch<TinyPol<uint64_t>> { static constexpr bool value = false; };   /* sixteen 64-bit columns a chunk */
 
-/* The record walk (SparsePol) stays on walk_generic: one build of walk_lines32<SparsePol> lost the state of a lane between an
- * input's first and second chunk in ~45 % of its launches (8+ wavefronts per workgroup; inputs whose match straddles byte 16),
- * the builds before and after it -- same walk source, a different order of the loads around it -- in none of 300
- * (profiles/r08i_*).  Its per-byte loop mixes flat loads that land in LDS or in memory with global loads under complementary
- * exec masks; which instruction order trips, and whether it is the compiler's wait-count merge or the hardware, was not
- * found.  Automata of that layout are served by walk_lazy_lines (walk_lazy.h) on these fronts anyway. */
+/* Which policies this kernel takes: all of them.  Round 5 kept the record walk (SparsePol) on walk_generic: one build of
+ * walk_lines32<SparsePol> lost the state of a lane between an input's first and second chunk in ~45 % of its launches (8+
+ * wavefronts per workgroup; inputs whose match straddles byte 16), the builds before and after it -- same walk source, a
+ * different order of the loads around it -- in none of 300 (profiles/r08i_*).  Its per-byte loop mixed FLAT loads that land in
+ * LDS or in memory (a record fetched through a generic pointer) with global loads under complementary exec masks.  Round 6
+ * rewrote every such fetch with explicit address spaces (SparsePol::next_t: no FLAT instruction is left in any walk kernel) and
+ * runs the harness that showed the loss as a test (tests/test_gpu_round6.py: 1 200 launches of this instantiation by workgroup
+ * size); see DESIGN.md section 4 for what is and is not known about the cause. */
 template <class Pol> struct lines32_ok { static constexpr bool value = true; };
-template <> struct lines32_ok<SparsePol> { static constexpr bool value = false; };
 
 /* the kernel around it: a packed front (FR_OFF64 / FR_OFF32 / FR_LENS), plain outputs, a batch below 4 GiB and 2^29 inputs --
  * the host front knows that, a device front launches this kernel AND walk_generic and offsets_pick says which one runs */
@@ -2311,7 +2331,7 @@ walk_ragged(const WalkArgs a)
 						uint32_t d[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
 						for (uint32_t k = 0; k < 15; k++)
-							if (k < ntail) d[k >> 2] |= (uint32_t)reinterpret_cast<const unsigned char *>(np0)[k] << ((k & 3u) * 8u);
+							if (k < ntail) d[k >> 2] |= (uint32_t)((const unsigned char __attribute__((address_space(1))) *)np0)[k] << ((k & 3u) * 8u);
 						const u32x4 dv = {d[0], d[1], d[2], d[3]};
 						*reinterpret_cast<u32x4 *>(rd + (rot & 7u) * 16u) = dv;
 						direct = true;

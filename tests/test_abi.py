@@ -99,3 +99,43 @@ def test_on_disk_description_roundtrip(built, tmp_path):
         with pytest.raises(OSError) as ei:
             FlatDfa.read_c(q)
         assert ei.value.errno == _errno.EINVAL
+
+
+def test_no_flat_instruction_in_any_walk_kernel(built):
+    """Every load of the walk kernels names its address space: LDS (ds_read) or device memory (global_load / buffer_load).  A
+    FLAT load whose lanes split between LDS and memory completes over two paths and two wait counters; the two intermittent
+    wrong-answer builds in this project's history were kernels with such loads inside lane-divergent loops
+    (profiles/r08i_*).  Round 6 removed them all; this keeps it so.  (The input generators are not the
+    product: gen_affix_kernel reads its by-value argument arrays with flat loads.)"""
+    import re
+    import subprocess
+    import tempfile
+    import libfsm_amd
+    so = os.path.join(os.path.dirname(libfsm_amd.__file__), "libfsm_hip.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("no ROCm LLVM tools here")
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fat])
+        data = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        offs = [m.start() for m in re.finditer(re.escape(magic), data)] + [len(data)]
+        assert len(offs) > 4
+        bad, nkernels = {}, 0
+        for k in range(len(offs) - 1):
+            b, e = os.path.join(td, f"b{k}.bundle"), os.path.join(td, f"b{k}.elf")
+            open(b, "wb").write(data[offs[k]:offs[k + 1]])
+            subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + b,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + e])
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", e], capture_output=True, text=True).stdout
+            cur = None
+            for line in dis.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1)
+                    nkernels += "walk_" in cur
+                elif cur and "walk_" in cur and re.search(r"\bflat_(load|store|atomic)", line):
+                    bad[cur] = bad.get(cur, 0) + 1
+        assert nkernels > 150, nkernels
+        assert not bad, {k[:80]: v for k, v in list(bad.items())[:6]}
