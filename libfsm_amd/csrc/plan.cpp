@@ -969,13 +969,24 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	 * children of a trie node (consecutive ids: stride 1) and ANY record with two exceptions -- the usual shape of a deep
 	 * literal-set node whose failure state is itself beyond the LDS set: one child of its own, one inherited --; base =
 	 * sentinel where the targets are no such progression (a hit then takes the exact path) */
-	auto make_deep = [&](uint32_t s, uint32_t e, uint64_t &bits, uint32_t &fm1, uint32_t &stride) {
+	/* ... and where they are not (round 6): CLONES.  44 816 of the 982 000 deep states of the 1e5-literal automaton have three
+	 * exceptions that are no progression -- their own child and two inherited ones -- and a hit on such a record used to be a
+	 * sentinel: the whole chunk re-walked the exact way, the wavefront waiting.  A word planted in a line passes ~9 deep states
+	 * and met one in a third of the cases: 8-64 byte lines of which every 8th ends in a literal ran at 260 GB/s where lines
+	 * without one ran at 410.  Such a state now gets k fresh consecutive ids behind the last real state, one per exception in
+	 * class order -- clone j stands for the state its j-th exception leads to: same own record, same carried record (the
+	 * carried record of a state entered from (state, class) does not depend on the target's id), cloneof[] maps it back
+	 * wherever an id leaves the fast path (results, the exact re-walk) -- and its record is the progression {bits, first clone
+	 * - 1, 1}.  `clonable`: every target lies beyond the LDS set, at most 8 of them. */
+	const uint32_t CLONE_MAX = 8;
+	auto make_deep = [&](uint32_t s, uint32_t e, uint64_t &bits, uint32_t &fm1, uint32_t &stride, bool *clonable = nullptr) {
 		stride = 0;
+		if (clonable) *clonable = false;
 		if (e == Z) { bits = ~(uint64_t)0; fm1 = SENT; return; }
 		bits = 0;
 		uint32_t t0 = 0, k = 0;
 		int64_t d = 1;
-		bool ok = true;
+		bool ok = true, deep = true;
 		const uint32_t *rs = row(s);
 		for (uint32_t b = 0; b < nbits; b++) {
 			const uint32_t f = evalF(e, b);
@@ -986,11 +997,12 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 			if (k == 0) t0 = t;
 			else if (k == 1) d = (int64_t)t - (int64_t)t0;
 			if ((int64_t)t != (int64_t)t0 + (int64_t)k * d || t < H) ok = false;    /* (a target inside the LDS set would have to carry itself) */
+			if (t < H || t >= N) deep = false;
 			k++;
 		}
 		if (d == 0 || d >= (1 << 22) || d <= -(1 << 22)) ok = false;
 		if (k == 0) { fm1 = 0; return; }
-		if (!ok) { fm1 = SENT; return; }
+		if (!ok) { fm1 = SENT; if (clonable) *clonable = deep && k <= CLONE_MAX; return; }
 		stride = (uint32_t)(int32_t)d;
 		fm1 = t0 - stride;
 	};
@@ -1012,7 +1024,8 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 			const uint32_t es = s < H ? s : car[s];
 			uint64_t sb = 0;
 			uint32_t sfm1 = 0, sstr = 0;
-			if (s >= H) make_deep(s, es, sb, sfm1, sstr);
+			bool sclon = false;
+			if (s >= H) make_deep(s, es, sb, sfm1, sstr, &sclon);
 			const uint32_t *rs = row(s);
 			for (uint32_t c = 0; c < C; c++) {
 				const uint32_t m = rs[c], b = bit_of[c];
@@ -1028,7 +1041,7 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 					const bool own = s >= H && ((sb >> b) & 1u);
 					if (!(f & SENT)) {
 						cr = f >= H ? cfbF(es, b) : f;
-						exact = own && sfm1 == SENT;
+						exact = own && sfm1 == SENT && !sclon;      /* (a clonable record's hit enters a clone of m straight-line: m must carry cr) */
 					}
 				}
 				if (exact) {
@@ -1057,8 +1070,22 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	const uint32_t sh_off = 0, filt_off = 1024u, rec_off = filt_off + fwords * 4u, lds_bytes = rec_off + (H + 1u) * 16u;
 	const uint32_t lds_w = lds_bytes / 4u, grec_w = (16u + lds_w + 3u) & ~3u;
 	std::vector<uint32_t> &img = p.lazy_img;
-	const size_t car_w = (size_t)grec_w + (size_t)S1 * 4u;
-	img.assign(car_w + S1, 0);
+	/* the clones: decided now (the carried records are final), numbered from S1 up */
+	std::vector<uint32_t> cloneof;                 /* clone S1 + j stands for state cloneof[j] */
+	std::vector<uint32_t> clone_first(S1, 0);      /* a cloned state's first clone */
+	for (uint32_t s2 = H; s2 < N; s2++) {
+		uint64_t bits;
+		uint32_t fm1, stride;
+		bool clon = false;
+		make_deep(s2, car[s2] == NONE ? Z : car[s2], bits, fm1, stride, &clon);
+		if (!clon || (uint64_t)S1 + cloneof.size() + CLONE_MAX >= (1u << 24)) continue;
+		clone_first[s2] = S1 + (uint32_t)cloneof.size();
+		for (uint32_t b = 0; b < nbits; b++)
+			if ((bits >> b) & 1u) cloneof.push_back(row(s2)[cls_of_bit[b]]);
+	}
+	const uint32_t NCL = (uint32_t)cloneof.size();
+	const size_t car_w = (size_t)grec_w + ((size_t)S1 + NCL) * 4u;
+	img.assign(car_w + S1 + NCL, 0);
 	uint32_t *L = &img[16];
 	for (uint32_t n = 0; n < H; n++) {
 		uint32_t *r = L + rec_off / 4u + n * 4u;
@@ -1077,11 +1104,17 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 		uint64_t bits;
 		uint32_t fm1, stride;
 		make_deep(s, car[s] == NONE ? Z : car[s], bits, fm1, stride);
+		if (clone_first[s] != 0) { fm1 = clone_first[s] - 1u; stride = 1u; }     /* the k-th exception leads to its k-th clone */
 		uint32_t *r = &img[grec_w + (size_t)s * 4u];
 		r[0] = (uint32_t)bits; r[1] = (uint32_t)(bits >> 32); r[2] = fm1; r[3] = stride;
 		img[car_w + s] = car[s] == NONE ? Z : car[s];   /* what the state carries: read by the kernel after an exact step into it */
 		if (car[s] == Z) nzstates++;
 		else if (fm1 == SENT) nsent++;
+	}
+	/* a clone's own record is the record of the state it stands for (written above: clones of clones' targets included) */
+	for (uint32_t j = 0; j < NCL; j++) {
+		memcpy(&img[grec_w + ((size_t)S1 + j) * 4u], &img[grec_w + (size_t)cloneof[j] * 4u], 16);
+		img[car_w + S1 + j] = cloneof[j];
 	}
 	/* the filter: the exceptions of the states [H, F), as many states as keep it under ~0.22 keys per bit */
 	uint64_t nkeys = 0;
@@ -1111,7 +1144,7 @@ static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const
 	img[9] = nzstates;
 	img[10] = nsent;
 	img[11] = abs_reach ? 1u : 0u;
-	img[12] = nbits;
+	img[12] = NCL;                         /* clones: own records S1 .. S1 + NCL - 1, cloneof[] right behind car[] */
 	img[13] = S1;
 	img[14] = (uint32_t)(car_w * 4u);
 	{

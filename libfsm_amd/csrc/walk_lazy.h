@@ -63,8 +63,36 @@ __device__ __forceinline__ uint32_t sparse_next_global(const uint32_t *img, uint
 
 struct LazyCtx {
 	uint32_t H, F, fmask, recbase, abs_min;
-	__amdgpu_buffer_rsrc_t own;     /* the own records, 16 bytes per state: out-of-range offsets read zeros */
+	uint32_t S1, nabs;              /* real states (ids from S1 up are CLONES: plan.cpp build_lazy); absorbing ones = [abs_min, abs_min + nabs) */
+	const uint32_t *cloneof;        /* clone S1 + j stands for state cloneof[j] */
+	__amdgpu_buffer_rsrc_t own;     /* the own records, 16 bytes per state and clone: out-of-range offsets read zeros */
 };
+
+/* the state an id stands for: itself, or -- a clone, an id the fast path alone knows -- the one it copies.  Wherever an id
+ * leaves the fast path: results, the exact re-walk. */
+__device__ __forceinline__ uint32_t lazy_unclone(const LazyCtx &cx, uint32_t id)
+{
+	if (id >= cx.S1) id = ((const uint32_t __attribute__((address_space(1))) *)(uintptr_t)cx.cloneof)[id - cx.S1];
+	return id;
+}
+
+/* the header words every lazy kernel needs (wave-uniform, and known to be: read through the scalar unit's eyes) */
+__device__ __forceinline__ void lazy_ctx_init(LazyCtx &cx, const uint32_t *lz, const WalkArgs &a)
+{
+	cx.H = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[1]);
+	cx.F = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[2]);
+	cx.fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[3] - 1u) << 2));
+	cx.recbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[4]);
+	cx.abs_min = a.abs_min;
+	cx.S1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[13]);
+	cx.nabs = cx.S1 - (a.abs_min < cx.S1 ? a.abs_min : cx.S1);
+	cx.cloneof = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(lz) + lz[14]) + lz[13];   /* right behind car[S1] */
+	/* a buffer resource in VGPRs costs a waterfall loop per load: make every word of it a scalar */
+	const uint64_t ob = reinterpret_cast<uint64_t>(lz) + lz[7];
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32));
+	const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[13] + lz[12]) * 16u));
+	cx.own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)nrec, 0x00020000);
+}
 
 typedef const u32x4 __attribute__((address_space(3))) *lazy_rec_p;
 typedef const uint32_t __attribute__((address_space(3))) *lazy_u32_p;
@@ -144,7 +172,7 @@ __device__ __forceinline__ void lazy_step(const LazyCtx &cx, LazyState &s, uint3
 	nA = (uint32_t)(__mul24((int)nA, (int)g.w) + (int)g.z);
 	uint32_t m = hA ? nA : ev;
 	if (ABS || TAIL) {
-		const bool ab = (ABS && s.id >= cx.abs_min) | (TAIL && !live);
+		const bool ab = (ABS && (s.id - cx.abs_min) < cx.nabs) | (TAIL && !live);      /* (clone ids lie beyond the absorbing range) */
 		m = ab ? s.id : m;
 		rep = ab ? s.E : rep;
 	}
@@ -176,7 +204,7 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 		lazy_step<ABS>(cx, c, sh, b);
 		if ((int32_t)(b | sh) < 0) {
 			/* the exact step; what a state beyond the LDS set carries comes from plan.cpp's car[] */
-			c.id = sparse_next_global(simg, id, byte, cx.abs_min);
+			c.id = sparse_next_global(simg, lazy_unclone(cx, id), byte, cx.abs_min);
 			c.E = c.id < cx.H ? c.id : car[c.id];
 		}
 		id = c.id;
@@ -196,12 +224,7 @@ walk_lazy(const WalkArgs a)
 	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
 	const uint32_t *car = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(lz) + lz[14]);   /* what a state beyond the LDS set carries */
 	LazyCtx cx;
-	/* wave-uniform, and known to be: the header words are read through the scalar unit's eyes */
-	cx.H = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[1]);
-	cx.F = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[2]);
-	cx.fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[3] - 1u) << 2));
-	cx.recbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[4]);
-	cx.abs_min = a.abs_min;
+	lazy_ctx_init(cx, lz, a);
 	{
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(lz + 16);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
@@ -210,13 +233,6 @@ walk_lazy(const WalkArgs a)
 	}
 	/* LDS addresses are formed from table-relative offsets: the dynamic segment must start at LDS address 0 */
 	if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
-	{
-		/* a buffer resource in VGPRs costs a waterfall loop per load: make every word of it a scalar */
-		const uint64_t ob = reinterpret_cast<uint64_t>(lz) + lz[7];
-		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32));
-		const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lz[13] * 16u));
-		cx.own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)nrec, 0x00020000);
-	}
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
@@ -285,12 +301,12 @@ walk_lazy(const WalkArgs a)
 			if (ABS && (a.early & 1u)) {
 				bool done = true;
 #pragma unroll
-				for (int r = 0; r < ROWS; r++) done = done && st[r].id >= a.abs_min;
+				for (int r = 0; r < ROWS; r++) done = done && (st[r].id - cx.abs_min) < cx.nabs;
 				if (__all(done)) break;
 			}
 		}
 #pragma unroll
-		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + (uint32_t)r, i[r], i[r] < a.n, st[r].id);
+		for (int r = 0; r < ROWS; r++) write_result(a, tile * ROWS + (uint32_t)r, i[r], i[r] < a.n, lazy_unclone(cx, st[r].id));
 	}
 }
 
@@ -343,11 +359,7 @@ walk_lazy_lines(const WalkArgs a)
 	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
 	const uint32_t *car = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(lz) + lz[14]);
 	LazyCtx cx;
-	cx.H = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[1]);
-	cx.F = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[2]);
-	cx.fmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lz[3] - 1u) << 2));
-	cx.recbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lz[4]);
-	cx.abs_min = a.abs_min;
+	lazy_ctx_init(cx, lz, a);
 	{
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(lz + 16);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
@@ -355,12 +367,6 @@ walk_lazy_lines(const WalkArgs a)
 		for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) dst[i] = src[i];
 	}
 	if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds != 0u) __builtin_trap();
-	{
-		const uint64_t ob = reinterpret_cast<uint64_t>(lz) + lz[7];
-		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32));
-		const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lz[13] * 16u));
-		cx.own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)nrec, 0x00020000);
-	}
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63u;
@@ -410,7 +416,7 @@ walk_lazy_lines(const WalkArgs a)
 				s.id = cid;
 			}
 		}
-		if (have) write_result_lane(a, fli, s.id);
+		if (have) write_result_lane(a, fli, lazy_unclone(cx, s.id));
 	};
 	/* the lanes with p set queue their tails (cnt in 1..15 bytes at cur); the queue is walked first when they do not fit */
 	auto push = [&](bool p, uint32_t li, uint32_t id, uint32_t E, uint64_t cur, uint32_t cnt) {
@@ -450,13 +456,13 @@ walk_lazy_lines(const WalkArgs a)
 				if (__any(fin)) {
 					/* a piece of an input of 4 GiB and more has ended where the input has not (u64 offsets and fixed strides can say so;
 					 * lengths and u32 offsets cannot): it goes on with what is really left */
-					if (fin && rem[r] == 0u && (f_off || (!f_off32 && !f_lens && a.len == nullptr)) && !(ABS && (a.early & 1u) && st[r].id >= a.abs_min)) {
+					if (fin && rem[r] == 0u && (f_off || (!f_off32 && !f_lens && a.len == nullptr)) && !(ABS && (a.early & 1u) && (st[r].id - cx.abs_min) < cx.nabs)) {
 						const uint64_t endb = f_off ? a.off[(uint64_t)li[r] + 1u] : ((uint64_t)li[r] + 1u) * a.stride;
 						const uint64_t left = base + endb - cur[r];
 						rem[r] = left > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)left;
 						fin = rem[r] < 16u;
 					}
-					if (fin && rem[r] == 0u) write_result_lane(a, li[r], st[r].id);
+					if (fin && rem[r] == 0u) write_result_lane(a, li[r], lazy_unclone(cx, st[r].id));
 					push(fin && rem[r] != 0u, li[r], st[r].id, st[r].E, cur[r], rem[r]);
 					act[r] = act[r] && !fin;
 					rem[r] = fin ? 0u : rem[r];
@@ -591,7 +597,7 @@ walk_lazy_lines(const WalkArgs a)
 			cur[r] += adv;
 			rem[r] -= adv;
 			/* an absorbing state ends the input early (fsm_exec stops pulling bytes at a missing edge, exec.c:133-138) */
-			if (ABS && (a.early & 1u) && act[r] && st[r].id >= a.abs_min) rem[r] = 0u;
+			if (ABS && (a.early & 1u) && act[r] && (st[r].id - cx.abs_min) < cx.nabs) rem[r] = 0u;
 		}
 	}
 	while (qcount != 0u) flush();

@@ -448,9 +448,16 @@ def lazy_decode(p):
     sh = L[:256]
     filt = L[filt_off // 4: filt_off // 4 + fwords]
     rec = L[rec_off // 4:].reshape(H + 1, 4)
-    own = img[grec_off // 4: grec_off // 4 + 4 * p.S1].reshape(p.S1, 4)
+    ncl = int(img[12])                                   # clones: ids S1 .. S1 + ncl - 1 (round 6), own records behind the states', cloneof[] behind car[]
+    own = img[grec_off // 4: grec_off // 4 + 4 * (p.S1 + ncl)].reshape(p.S1 + ncl, 4)
     car = img[int(img[14]) // 4: int(img[14]) // 4 + p.S1]
-    return dict(H=H, F=F, fwords=fwords, sh=sh, filt=filt, rec=rec, own=own, car=car, abs_reach=int(img[11]), nkeys=int(img[8]), nz=int(img[9]), nsent=int(img[10]))
+    cloneof = img[int(img[14]) // 4 + p.S1: int(img[14]) // 4 + p.S1 + ncl]
+    assert int(img[14]) // 4 == grec_off // 4 + 4 * (p.S1 + ncl)
+    for j in range(ncl):                                 # a clone stands for a real, non-absorbing state beyond the LDS set and has its record
+        t = int(cloneof[j])
+        assert H <= t < p.abs_min and np.array_equal(own[p.S1 + j], own[t]), (j, t)
+    return dict(H=H, F=F, fwords=fwords, sh=sh, filt=filt, rec=rec, own=own, car=car, abs_reach=int(img[11]), nkeys=int(img[8]), nz=int(img[9]), nsent=int(img[10]),
+                S1=p.S1, ncl=ncl, cloneof=cloneof)
 
 
 def lazy_probe(b0, b1, fm1, sh):
@@ -478,7 +485,7 @@ def lazy_step(z, abs_min, sid, E, sh, use_abs):
         if hA:
             stride = int(g[3]) - (1 << 32) if int(g[3]) & SENT else int(g[3])
             m = (int(g[2]) + pc * stride) & 0xFFFFFFFF
-    if use_abs and sid >= abs_min:
+    if use_abs and abs_min <= sid < z["S1"]:             # (clone ids lie beyond the absorbing range: the kernel's range test)
         m, rep = sid, E
     return m, rep, bool((m | rep | sh) & SENT)
 
@@ -497,23 +504,26 @@ def check_lazy(p, want, max_pairs=None):
     seen = {(p.start, p.start)}
     todo = [(p.start, p.start)]
     nfast = nsent = nsent_bit = 0
+    real = lambda x: int(z["cloneof"][x - p.S1]) if x >= p.S1 else x     # the state an id stands for (walk_lazy.h lazy_unclone)
     while todo:
         s, E = todo.pop()
-        if s >= N:
+        if real(s) >= N:
             continue
         for by in range(256):
             sh = int(z["sh"][by])
             m, rep, sent = lazy_step(z, N, s, E, sh, use_abs)
-            t = int(want[s][by])
+            t = int(want[real(s)][by])
             if sent:
                 nsent += 1
                 nsent_bit += not (sh & SENT)
                 m, rep = t, (t if t < H else int(z["car"][t]))            # the exact path; a state beyond the LDS set is handed what it carries
             else:
                 nfast += 1
-                assert m == t, (s, E, by, m, t)
+                assert m < p.S1 + z["ncl"] and real(m) == t, (s, E, by, m, t)
                 assert rep <= H
-            if m >= N:
+                if m >= p.S1:                                # a clone is entered with what the state it stands for carries (or that state carries
+                    assert rep == int(z["car"][t]) or int(z["car"][t]) == H, (s, by, m, rep)   # nothing -- Z: its record excepts everything)
+            if real(m) >= N:
                 assert use_abs, "an absorbing state is reachable: the kernel variant that tests for it must be the one launched"
                 continue
             if m < H:
