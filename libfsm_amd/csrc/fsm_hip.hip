@@ -98,6 +98,7 @@ struct fsm_hip_dfa {
 	int knob_seg = 0;            /* 0 auto (128) */
 	int knob_prefetch = -1;      /* -1 auto (on) */
 	int knob_nt = -1;            /* -1 auto */
+	int knob_rows = 0;           /* the lazy walk's inputs per lane; 0 auto */
 	int knob_waves = 0;          /* 0 auto */
 	int knob_blocks_per_cu = 0;  /* 0 auto */
 	int knob_early = -1;         /* -1: from flags */
@@ -646,7 +647,10 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		c.mode = IN_LAZY;
 		c.nt = d->knob_nt > 0;      /* nontemporal input loads: A/B knob (FSM_HIP_KNOB_NT) */
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
-		c.nb = 4;
+		/* inputs per lane x chunks in flight: 3 x 4 (kern_glob.hip: 1 036 GB/s on the 1e5-literal automaton; 2 x 4: 1 000, 3 x 2: 970,
+		 * 4 x 2: 758 -- profiles/r09j_*); FSM_HIP_KNOB_ROWS / _NB pick the others (A/B) */
+		c.lazy_rows = d->knob_rows == 2 || d->knob_rows == 4 ? d->knob_rows : 3;
+		c.nb = c.lazy_rows == 4 || (c.lazy_rows == 3 && d->knob_nb == 2) ? 2 : 4;
 		c.waves = 16;
 		c.lds = d->plan.lazy_lds_bytes;
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
@@ -657,9 +661,12 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		 * are not a multiple of 64, unaligned rows, resumed walks -- one input per lane slot with lane refill (walk_lazy_lines) */
 		c.mode = IN_LAZY_LINES;
 		c.lazy_abs = d->plan.lazy_img[11] != 0 || resumed;   /* a resumed input may start in DEAD */
-		/* whole chunks per slot and turn: 4, or 2 where the inputs are short (launch_walk decides -- on the device where the host
-		 * cannot know: 8-64 byte lines 410 against 364 GB/s, 0-1024 bytes 533 against 557; FSM_HIP_KNOB_NB forces one) */
-		c.nb = d->knob_nb == 2 ? 2 : 4;
+		/* THREE slots per lane, two whole chunks per slot and turn: on every line mix but 8-16 bytes faster than two slots with two
+		 * or four chunks (0-1024 bytes 607 against 557 GB/s, 8-64 bytes 427 / 395, all 64 bytes 863 / 732, all 1 KiB 773 / 739:
+		 * profiles/r09k_*) -- which that round's first half chose between by the mean length, on the device where the host could
+		 * not know it.  FSM_HIP_KNOB_ROWS = 2 brings the two-slot forms back (FSM_HIP_KNOB_NB = 2 / 4 chunks: A/B). */
+		c.lazy_rows = d->knob_rows == 2 ? 2 : 3;
+		c.nb = c.lazy_rows == 3 || d->knob_nb == 2 ? 2 : 4;
 		c.waves = 16;
 		/* the table + the wavefronts' queues: all the LDS there is (plan.cpp leaves at least FSMHIP_LAZY_QBYTES: 112 entries per
 		 * wavefront; the kernel uses up to 128) */
@@ -869,12 +876,7 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 			} else (void)hipGetLastError();
 		} else (void)hipGetLastError();
 	}
-	/* the lazy walk on variable-length inputs: two forms, 2 or 4 whole chunks a turn; the hand-over is at a mean of 56 bytes */
-	const uint32_t lazy_mean = 56u;
-	const bool lazy_lines = c.mode == IN_LAZY_LINES && varlen && d->knob_nb <= 0;
-	const bool lazy_pick = lazy_lines && known_bytes == 0 && !hint.short_mean;
-	const bool lazy_short = lazy_lines && !lazy_pick && (known_bytes != 0 ? known_bytes / a.n < lazy_mean : hint.short_mean);
-	const bool pick = pick_len || fits32 < 0 || lazy_pick;
+	const bool pick = pick_len || fits32 < 0;
 
 	fsm_hip_dfa *md = const_cast<fsm_hip_dfa *>(d);
 	DfaLock lk(md->mu);   /* the timing events, the flag ring and the tile-base block are per dfa */
@@ -892,11 +894,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		a.pick_flag = md->d_pick + (md->pick_next++ % PICK_FLAGS);
 		a.skip_flag = a.pick_flag;
 		/* bit 0: walk_ragged is a candidate (else every batch counts as short); bit 1: so is walk_lines32 */
-		if (lazy_pick)   /* PICK_GENERIC = the short form, PICK_RAGGED = the long one */
-			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, lazy_mean, lazy_mean, 1u | 4u);
-		else
-			hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)pick_mean_of(d, false), (uint32_t)pick_mean_of(d, true),
-			                   (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u) | (fits32 != 1 && !skip_generic ? 4u : 0u));
+		hipLaunchKernelGGL(offsets_pick, dim3(1), dim3(256), 0, s, a, (uint32_t)pick_mean_of(d, false), (uint32_t)pick_mean_of(d, true),
+		                   (pick_len ? 1u : 0u) | (fits32 != 0 ? 2u : 0u) | (fits32 != 1 && !skip_generic ? 4u : 0u));
 		e = hipGetLastError();
 	}
 	/* the per-lane kernels (short inputs): walk_generic unless the batch is known to fit 32 bits, walk_lines32 unless known not to */
@@ -934,24 +933,12 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 		}
 		debug_stage(s, "walk (per-lane)");
 	}
-	if (e == hipSuccess && lazy_pick) {
-		/* the short form beside the long one (below); offsets_pick lets one of them run */
-		LaunchCfg c2 = c;
-		c2.nb = 2;
-		WalkArgs a2 = a;
-		a2.run_when = PICK_GENERIC;
-		c2.kfn = nullptr;
-		e = launch_layout(d, eager, c2, a2, dim3((unsigned)nblocks), dim3((unsigned)c2.waves * 64u), s);
-		if (e == hipSuccess) md->last_kernel_pick[PICK_GENERIC] = kernel_name(c2.kfn, s);
-	}
 	if (e == hipSuccess && c.mode != IN_GENERIC) {
-		LaunchCfg cl = c;
-		if (lazy_short) cl.nb = 2;
 		a.run_when = PICK_RAGGED;
-		cl.kfn = nullptr;
-		e = launch_layout(d, eager, cl, a, dim3((unsigned)nblocks), dim3((unsigned)cl.waves * 64u), s);
+		c.kfn = nullptr;
+		e = launch_layout(d, eager, c, a, dim3((unsigned)nblocks), dim3((unsigned)c.waves * 64u), s);
 		if (e == hipSuccess) {
-			md->last_kernel = kernel_name(cl.kfn, s);
+			md->last_kernel = kernel_name(c.kfn, s);
 			md->last_kernel_pick[PICK_RAGGED] = md->last_kernel;
 		}
 		debug_stage(s, "walk");
@@ -1450,7 +1437,7 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 	switch (knob) {
 	case FSM_HIP_KNOB_INPUT_MODE: d->knob_input_mode = value; break;
 	case FSM_HIP_KNOB_NB: d->knob_nb = value; break;
-	case FSM_HIP_KNOB_ROWS: break;   /* retired: two inputs per lane never helped the table walks (profiles/r01_sweep2*); the lazy walk always has two */
+	case FSM_HIP_KNOB_ROWS: d->knob_rows = value; break;   /* the lazy walk's inputs per lane (2 / 3 / 4: A/B); the table walks have one */
 	case FSM_HIP_KNOB_LAZY_DYN: d->knob_lazy_dyn = value != 0; break;
 	case FSM_HIP_KNOB_LAZY_LINES: d->knob_lazy_lines = value != 0; break;
 	case FSM_HIP_KNOB_MASK: break;   /* retired: exec-masking absorbing lanes cost more than it saved */

@@ -10,12 +10,21 @@ hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a
 		/* fixed-stride rows, plain walk, an automaton with a lazy form: states beyond the LDS set are entered without their record */
 		/* (three inputs per lane with two chunks in flight, and two with two, measured no faster than <2, 4>:
 		 * profiles/r06b_c5_lazy_variants_1e7.txt) */
-		walk_fn k = c.nt ? (c.lazy_abs ? walk_lazy<true, 2, 4, true> : walk_lazy<false, 2, 4, true>) : (c.lazy_abs ? walk_lazy<true, 2, 4> : walk_lazy<false, 2, 4>);
+		/* THREE inputs per lane, four chunks each in flight (round 6: 1 036 GB/s on the 1e5-literal automaton where round 5's two
+		 * inputs gave 888).  What made room for the third: no record sends a hit the exact way any more (plan.cpp's clones), and
+		 * the byte -> shift lookups are taken eight at a time with their OR at once (walk_lazy.h) -- 128 registers, no scratch.
+		 * FSM_HIP_KNOB_ROWS / _NB pick the other shapes (A/B: profiles/r09j_*). */
+		walk_fn k = c.lazy_abs ? walk_lazy<true, 3, 4> : walk_lazy<false, 3, 4>;
+		if (c.lazy_rows == 2) k = c.nt ? (c.lazy_abs ? walk_lazy<true, 2, 4, true> : walk_lazy<false, 2, 4, true>) : (c.lazy_abs ? walk_lazy<true, 2, 4> : walk_lazy<false, 2, 4>);
+		else if (c.lazy_rows == 3 && c.nb == 2) k = c.lazy_abs ? walk_lazy<true, 3, 2> : walk_lazy<false, 3, 2>;
+		else if (c.lazy_rows == 4) k = c.lazy_abs ? walk_lazy<true, 4, 2> : walk_lazy<false, 4, 2>;
 		return launch_fn(k, c, a, grid, block, s);
 	}
 	if (pol == POL_SPARSE && eager == 0 && c.mode == IN_LAZY_LINES) {
 		/* the same walk on inputs of any length / metadata form, and resumed walks: one input per lane slot, lane refill */
-		walk_fn k = c.nb == 2 ? (c.lazy_abs ? walk_lazy_lines<true, 2, 2> : walk_lazy_lines<false, 2, 2>) : (c.lazy_abs ? walk_lazy_lines<true, 2, 4> : walk_lazy_lines<false, 2, 4>);
+		/* three slots per lane, two whole chunks per slot and turn (fsm_hip.hip pick_cfg has the numbers); two slots by knob (A/B) */
+		walk_fn k = c.lazy_abs ? walk_lazy_lines<true, 3, 2> : walk_lazy_lines<false, 3, 2>;
+		if (c.lazy_rows == 2) k = c.nb == 2 ? (c.lazy_abs ? walk_lazy_lines<true, 2, 2> : walk_lazy_lines<false, 2, 2>) : (c.lazy_abs ? walk_lazy_lines<true, 2, 4> : walk_lazy_lines<false, 2, 4>);
 		return launch_fn(k, c, a, grid, block, s);
 	}
 	if (pol == POL_SPARSE && eager == 0 && c.sparse_fast && c.mode == IN_DIRECT) {

@@ -22,6 +22,7 @@ struct LaunchCfg {
 	int nt;              /* LDS-DMA, 128-byte segments: nontemporal loads */
 	int sparse_fast;     /* sparse layout, per-lane loads, plain walk: the entry-as-state policy (SparseFastPol) */
 	int lazy_abs;        /* IN_LAZY: an absorbing state is reachable (the kernel variant that tests for one) */
+	int lazy_rows;       /* IN_LAZY: inputs per lane (3, or 2 / 4 by FSM_HIP_KNOB_ROWS: A/B) */
 	int lines32;         /* IN_GENERIC, plain walk of a packed batch below 4 GiB / 2^29 inputs: the 32-bit kernel (walk_lines32) */
 	uint32_t lds;        /* dynamic LDS bytes per workgroup */
 	int probe;           /* 1: do not launch, only say (kfn) which kernel it would be (fsm_hip.hip sizes a workgroup by the kernel's registers) */

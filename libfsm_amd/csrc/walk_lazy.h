@@ -265,25 +265,34 @@ walk_lazy(const WalkArgs a)
 				for (int r = 0; r < ROWS; r++) cur[j][r] = NT ? __builtin_nontemporal_load(&q[r][g * NB + j]) : q[r][g * NB + j];
 #pragma unroll
 			for (int j = 0; j < NB; j++) {
-				uint32_t sh[ROWS][16];
-#pragma unroll
-				for (int r = 0; r < ROWS; r++)
-#pragma unroll
-					for (int k = 0; k < 16; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], k) * 4u);
 				uint32_t sid[ROWS], sE[ROWS], bacc[ROWS];
-				/* a byte whose class owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too */
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) {
 					sid[r] = st[r].id;
 					sE[r] = st[r].E;
 					bacc[r] = 0u;
-#pragma unroll
-					for (int k = 0; k < 16; k++) bacc[r] |= sh[r][k];
 				}
+				/* the byte -> shift lookups eight bytes at a time, their OR into the sentinel word taken at once (a byte whose class
+				 * owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too).  Left to itself the compiler
+				 * ORs the sixteen shifts in at the block's END and keeps them alive for it: the registers of a third input per lane. */
 #pragma unroll
-				for (int k = 0; k < 16; k++)
+				for (int h = 0; h < 2; h++) {
+					uint32_t sh[ROWS][8];
 #pragma unroll
-					for (int r = 0; r < ROWS; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
+					for (int r = 0; r < ROWS; r++)
+#pragma unroll
+						for (int k = 0; k < 8; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], 8 * h + k) * 4u);
+#pragma unroll
+					for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+						for (int k = 0; k < 8; k++) bacc[r] |= sh[r][k];
+						__asm__ volatile("" : "+v"(bacc[r]));
+					}
+#pragma unroll
+					for (int k = 0; k < 8; k++)
+#pragma unroll
+						for (int r = 0; r < ROWS; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
+				}
 				uint32_t ball = 0;
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) ball |= bacc[r];
@@ -339,7 +348,8 @@ walk_lazy(const WalkArgs a)
  * order, so any load in flight delays the first gather wait behind it (a chunk asked for per step instead of NB per turn
  * measured 12 % slower on 1 KiB lines).
  * Measured, 4 GB of lines on the 1e5-literal automaton (tests/tools/c5_lines_probe.py; round 5's kernel: 523 / 243 GB/s on the
- * first two): 0-1024 bytes 559, 8-64 bytes 363; all 1024 bytes 754, all 64 bytes 770 (the fixed-stride kernel: 900).
+ * first two): two slots per lane, four chunks a turn: 0-1024 bytes 559, 8-64 bytes 363 (410 at two chunks a turn); all 1024 bytes
+ * 754, all 64 bytes 770.  THREE slots, two chunks a turn (shipped; 32 bytes of scratch outside the step block): 607 / 427 / 773 / 863.
  * Built and dropped: a slot changing inputs in MID-turn (its next input chosen at the turn's head, the old input's queue entry
  * pre-written and the state ORed in at the step its whole chunks end): no idle slots, but the bookkeeping costs more than
  * they did -- 565 / 308 on the same two mixes, 618 on 64-byte lines.
@@ -353,7 +363,6 @@ template <bool ABS, int ROWS, int NB>
 __global__ void __launch_bounds__(1024)
 walk_lazy_lines(const WalkArgs a)
 {
-	if (a.skip_flag != nullptr && *a.skip_flag != a.run_when) return;   /* the other form of this kernel took the batch (fsm_hip.hip launch_walk) */
 	extern __shared__ __align__(16) unsigned char lds[];
 	const uint32_t *lz = static_cast<const uint32_t *>(a.lazy);
 	const uint32_t *simg = static_cast<const uint32_t *>(a.tab);
