@@ -23,7 +23,7 @@ enum {
 	                                  * correct, slower than walk_generic everywhere, removed in round 4; the record is
 	                                  * profiles/r03s_packed_* and tools/packed_model.py) */
 	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
-	FSM_HIP_KNOB_ROWS          = 3,  /* the lazy walk (walk_lazy.h): inputs per lane -- 0 auto (3), 2, 3, 4 (A/B aid; ignored elsewhere) */
+	FSM_HIP_KNOB_ROWS          = 3,  /* the lazy walk (walk_lazy.h): inputs / slots per lane -- 0 auto (3), 2 = round 5's shape (A/B aid; ignored elsewhere) */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
 	FSM_HIP_KNOB_EARLY_RETIRE  = 6,  /* -1: from the dfa's flags; else a bit set -- 1: retire a wavefront whose lanes are all absorbing

@@ -643,14 +643,14 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 	c.lazy_abs = 0;
 	if (mode == IN_DIRECT && layout == FSM_HIP_LAYOUT_SPARSE && !eager && !resumed && d->d_lazy != nullptr && d->knob_sparse_fast == 3 &&
 	    (stride / 16u) % 4u == 0) {
-		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, two inputs per lane (walk_lazy.h) */
+		/* the lazy walk: one 16-wave workgroup per CU beside its 131 KiB of tables, three inputs per lane (walk_lazy.h) */
 		c.mode = IN_LAZY;
 		c.nt = d->knob_nt > 0;      /* nontemporal input loads: A/B knob (FSM_HIP_KNOB_NT) */
 		c.lazy_abs = d->plan.lazy_img[11] != 0;
 		/* inputs per lane x chunks in flight: 3 x 4 (kern_glob.hip: 1 036 GB/s on the 1e5-literal automaton; 2 x 4: 1 000, 3 x 2: 970,
-		 * 4 x 2: 758 -- profiles/r09j_*); FSM_HIP_KNOB_ROWS / _NB pick the others (A/B) */
-		c.lazy_rows = d->knob_rows == 2 || d->knob_rows == 4 ? d->knob_rows : 3;
-		c.nb = c.lazy_rows == 4 || (c.lazy_rows == 3 && d->knob_nb == 2) ? 2 : 4;
+		 * 4 x 2: 758 -- profiles/r09j_*); FSM_HIP_KNOB_ROWS = 2: round 5's shape (A/B) */
+		c.lazy_rows = d->knob_rows == 2 ? 2 : 3;
+		c.nb = 4;
 		c.waves = 16;
 		c.lds = d->plan.lazy_lds_bytes;
 		c.blocks_per_cu = d->knob_blocks_per_cu > 0 ? d->knob_blocks_per_cu : 1;
@@ -840,7 +840,8 @@ static int launch_walk(const fsm_hip_dfa *d, WalkArgs a, bool fast_ok, hipStream
 	const uint64_t known_bytes = hint.bytes != 0 ? hint.bytes : !varlen ? (uint64_t)a.n * a.stride : 0;
 	const LaunchCfg c = pick_cfg(d, fast_ok, a.stride, eager, hint.short_mean, known_bytes >= ((uint64_t)1 << 36), a.state_io != nullptr, a.n >= ((uint64_t)1 << 32));
 	const uint64_t ntiles = (a.n + 63u) / 64u;
-	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + 127u) / 128u + c.waves - 1) / c.waves
+	const uint64_t lazy_tile = 64u * (uint64_t)(c.lazy_rows > 0 ? c.lazy_rows : 2);      /* inputs per wavefront of the fixed-stride lazy walk */
+	uint64_t nblocks = c.mode == IN_LAZY ? ((a.n + lazy_tile - 1u) / lazy_tile + c.waves - 1) / c.waves
 		: c.mode == IN_LAZY_LINES ? ((a.n + FSMHIP_LAZY_PIECE - 1u) / FSMHIP_LAZY_PIECE + c.waves - 1) / c.waves : (ntiles + c.waves - 1) / c.waves;
 	const uint64_t cap = (uint64_t)d->ncu * c.blocks_per_cu;
 	if (nblocks > cap) nblocks = cap;

@@ -13,11 +13,9 @@ hipError_t launch_glob(int pol, int eager, const LaunchCfg &c, const WalkArgs &a
 		/* THREE inputs per lane, four chunks each in flight (round 6: 1 036 GB/s on the 1e5-literal automaton where round 5's two
 		 * inputs gave 888).  What made room for the third: no record sends a hit the exact way any more (plan.cpp's clones), and
 		 * the byte -> shift lookups are taken eight at a time with their OR at once (walk_lazy.h) -- 128 registers, no scratch.
-		 * FSM_HIP_KNOB_ROWS / _NB pick the other shapes (A/B: profiles/r09j_*). */
+		 * FSM_HIP_KNOB_ROWS = 2: round 5's shape (A/B; the 3 x 2 and 4 x 2 shapes of profiles/r09j_* were measured and are not built). */
 		walk_fn k = c.lazy_abs ? walk_lazy<true, 3, 4> : walk_lazy<false, 3, 4>;
 		if (c.lazy_rows == 2) k = c.nt ? (c.lazy_abs ? walk_lazy<true, 2, 4, true> : walk_lazy<false, 2, 4, true>) : (c.lazy_abs ? walk_lazy<true, 2, 4> : walk_lazy<false, 2, 4>);
-		else if (c.lazy_rows == 3 && c.nb == 2) k = c.lazy_abs ? walk_lazy<true, 3, 2> : walk_lazy<false, 3, 2>;
-		else if (c.lazy_rows == 4) k = c.lazy_abs ? walk_lazy<true, 4, 2> : walk_lazy<false, 4, 2>;
 		return launch_fn(k, c, a, grid, block, s);
 	}
 	if (pol == POL_SPARSE && eager == 0 && c.mode == IN_LAZY_LINES) {

@@ -870,7 +870,7 @@ static int build_sparse(Plan &p, uint32_t lds_limit)
  *
  * Image (u32 words): hdr[16] | LDS part: sh[256] at LDS address 0 (byte -> 63 - bit, or 0x80000000 for bytes whose
  * class owns no bit), filter[fwords], records[H + 1] (the last one all-sentinel: Z)
- * | own records, 16 bytes per state {bits, base, stride} | car[S1].
+ * | own records, 16 bytes per state {bits, base, stride}, then one per CLONE (round 6: img[12] of them, ids S1 ..) | car[S1] | cloneof[].
  */
 static void build_lazy(Plan &p, uint32_t lds_limit, const uint8_t *bit_of, const std::vector<uint32_t> &base)
 {

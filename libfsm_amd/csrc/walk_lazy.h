@@ -19,9 +19,18 @@
  *   - any answer with bit 31 set is a SENTINEL (non-consecutive targets, a class without a bit, a state reached in
  *     two ways...): the 16-byte chunk is then re-walked for those lanes with the exact records of build_sparse in
  *     device memory.  The planner proves the rest (plan.cpp, tests/test_plan.py).
- * One workgroup of 16 waves per CU next to a 131 KiB table (64 KiB filter + 4 162 records + the byte map), TWO inputs
- * per lane for the instruction-level parallelism the second workgroup used to give; per-lane 16-byte input loads,
- * four chunks per row in flight (as walk_direct_np).  Fixed-stride rows, plain (non-eager, non-resumed) walks.
+ * One workgroup of 16 waves per CU next to a 131 KiB table (64 KiB filter + 4 162 records + the byte map), several inputs
+ * per lane for the instruction-level parallelism the second workgroup used to give (two in rounds 4-5, THREE since round
+ * 6); per-lane 16-byte input loads, four chunks per row in flight (as walk_direct_np).  Fixed-stride rows, plain
+ * (non-eager, non-resumed) walks.
+ * Round 6: 888 -> 1 036 GB/s on the 1e5-literal automaton (1e7 x 1 KiB rows), in three steps that needed one another:
+ *   - plan.cpp's CLONES: no own record sends a hit the exact way any more (44 816 of them did: a literal planted in a row's
+ *     tail re-walked its chunk with the wavefront waiting) -- 934;
+ *   - the byte -> shift lookups eight bytes at a time, their OR into the sentinel word taken at once: the compiler kept all
+ *     sixteen shifts of every input alive to the block's end for that OR -- 1 000 with two inputs, and registers for
+ *   - a third input per lane (128 registers, no scratch) -- 1 036.  (Four: 758.  profiles/r09i_*, r09j_*.)
+ * What bounds it there: 25.2 vector instructions per byte-step at 4 cycles each = 1.54 TB/s at full VALU issue; the walk
+ * reaches two thirds of that with 16 wavefronts per CU, the most a 131 KiB table leaves room for.
  */
 #ifndef FSM_HIP_WALK_LAZY_H
 #define FSM_HIP_WALK_LAZY_H
