@@ -32,6 +32,7 @@ import sys
 import time
 
 import numpy as np
+_T0 = time.time()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -591,6 +592,13 @@ def compact_line(res, detail_path=DETAIL_FILE, limit=LINE_LIMIT):
         out["sub_results"] = [_pick(s_, ("workload", "value", "frac", "parity")) for s_ in out["sub_results"]]
         line = json.dumps(out, separators=(",", ":"))
     return line
+
+
+def progress(msg):
+    """one line on stderr per leg (rank 0): a run that dies says where (stdout stays the one JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.1f s] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
 
 
 def emit(res):
@@ -1211,7 +1219,7 @@ def main():
         text = buf_all.view(-1)[: K * nl * ll]
         hip.gen_inputs_device(text.data_ptr(), K * nl, ll, 0, SEED ^ 0x77, bytes(range(32, 127)))
         off = (torch.arange(nl + 1, device="cuda", dtype=torch.int64) * ll)       # every job: 100 000 lines of 64 bytes, its own slice of the text
-        ends = end_all[: K * nl]
+        ends = torch.empty(K * nl, dtype=torch.int32, device="cuda")      # (its own block: the main workload's end states are 1e8, these 1.024e8)
         ds = [hip.HipDfa(gs[q % len(gs)].flat, hip.DEFER_UPLOAD) for q in range(K)]
         jobs = [(text.data_ptr() + q * nl * ll, off.data_ptr(), nl, ends.data_ptr() + q * nl * 4, 0) for q in range(K)]
         torch.cuda.synchronize()
@@ -1263,6 +1271,7 @@ def main():
         r["config"]["input_len"] = r["config"]["mean_len"]
         emit(r)
         return
+    progress("main workload %s" % a.workload)
     main_res = run(a.workload)
     subs = []
     if world == 1 and a.subs == "auto" and a.n == 0 and not shrunk:
@@ -1278,6 +1287,7 @@ def main():
             plan.append((wl, "short", None))
             plan.append((wl, "ragged", None))
         for wl, variant, n_wl in plan:
+            progress("sub-result %s%s" % (wl, "_" + variant if variant else ""))
             if variant in ("short", "ragged"):
                 subs.append(run_lines(wl, variant))
                 continue
@@ -1293,15 +1303,18 @@ def main():
             if r["config"].get("table_layout") in ("comb256", "lds", "lds2", "comb"):
                 lds_chain_ceiling(r)        # the lookup layouts' own denominator beside the HBM one
             subs.append(r)
+        progress("sub-result c3_eager40")
         try:
             subs.append(run_eager40())
             lds_chain_ceiling(subs[-1]) if subs[-1]["config"].get("table_layout") in ("comb256", "lds", "lds2", "comb") else None
         except Exception as e:  # noqa: BLE001
             subs.append({"workload": "c3_eager40", "value": None, "error": repr(e)[:300]})
+        progress("sub-result multi_dfa")
         try:
             main_res["multi_dfa"] = run_multi_dfa()
         except Exception as e:  # noqa: BLE001
             main_res["multi_dfa"] = {"error": repr(e)[:300]}
+        progress("sub-result multi_dfa_bulk")
         try:
             main_res["multi_dfa_bulk"] = run_multi_dfa_bulk()
         except Exception as e:  # noqa: BLE001

@@ -484,7 +484,8 @@ struct fsm_hip_multi_batch {
 };
 int fsm_hip_exec_multi(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k);
 /* the same with DEVICE pointers inside b[] (the array itself is host memory); enqueued on hip_stream, not waited for.
- * Not capturable into a HIP graph (the descriptors ride in a staging block that the next call reuses). */
+ * Not capturable into a HIP graph (the descriptors ride in a staging block that the next call reuses): fsm_hip_multi_prepare
+ * + fsm_hip_multi_launch below are. */
 int fsm_hip_exec_multi_device(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch *b, size_t k, void *hip_stream);
 /* ... with end-ids delivered by the device, per job (what the reference's multi-pattern consumers want beside accept / reject:
  * re(1) -z src/re/main.c:1152-1166, the generated matchers' `unsigned *id` src/libfsm/print/c.c:569-619): id_out (n entries,
@@ -506,8 +507,21 @@ int fsm_hip_exec_multi_ids_device(const struct fsm_hip_dfa *const *dfa, const st
 /* The device-pointer forms fuse every job whose plain next-state table fits the kernel's LDS copy (16 384 entries), whatever
  * its line count: workgroups of four wavefronts map to (dfa, 256 consecutive lines) and share one copy of that dfa's table --
  * 1 024 small automata x 1e5 lines each are ONE launch (round 5 sent every job above 65 536 lines through its dfa's own walk,
- * one launch each). */
-/* kernels the last fsm_hip_exec_multi* call of this process launched (1 when every job was small), and how many jobs rode
+ * one launch each).  A job of few but very long lines is fused too (correct, one lane per line): hand such a job to its dfa's
+ * own fronts.  Every dfa of a device-pointer submission is launched on the one hip_stream: they must live on that stream's
+ * device (fsm_hip_node_exec_multi shards a submission by DFA over several). */
+/* The PREPARED form of a device-pointer submission: descriptors, tile map and the automata's tables go to the device ONCE
+ * (fsm_hip_multi_prepare: allocates, copies, waits); fsm_hip_multi_launch is then one kernel launch on hip_stream (plus one
+ * per job whose table is too big to fuse) -- no copy, no allocation, no wait, so it can be captured into a HIP graph and
+ * replayed on whatever the jobs' buffers hold by then (reperf runs the same matcher over and over, src/retest/reperf.c:772-784;
+ * this is that loop for K matchers at once).  All dfas on one device (EINVAL otherwise); they and the buffers named in b[]
+ * must outlive the handle; b[] itself is copied.  ids_mode as fsm_hip_exec_multi_ids (ignored when no job has id_out). */
+struct fsm_hip_multi_prepared;
+int fsm_hip_multi_prepare(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode,
+	struct fsm_hip_multi_prepared **out);
+int fsm_hip_multi_launch(const struct fsm_hip_multi_prepared *p, void *hip_stream);
+void fsm_hip_multi_prepared_free(struct fsm_hip_multi_prepared *p);
+/* kernels the last fsm_hip_exec_multi* / fsm_hip_multi_launch call of this process launched (1 when every job was small), and how many jobs rode
  * in the fused one */
 unsigned fsm_hip_multi_last_launches(void);
 unsigned fsm_hip_multi_last_fused_jobs(void);

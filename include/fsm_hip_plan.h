@@ -31,7 +31,7 @@ enum {
 	                                  * absorbing-lane masking, 16: walk_generic always asks for four chunks; measurement / test aids
 	                                  * of the lines kernels: 32: never walk_lines32 (walk_generic's own body, what batches of 4 GiB
 	                                  * and more run), 64: walk_lines32 keeps the first chunk's skip tests, 128: round 4's resource
-	                                  * bound (total - 8: loses bytes; for the test that pins the range rule) */
+	                                  * bound (total - 8: loses bytes; for the test that pins the range rule: EINVAL unless FSM_HIP_TEST_KNOBS is set in the environment) */
 	FSM_HIP_KNOB_MASK          = 7,  /* retired (accepted, ignored)                                   */
 	FSM_HIP_KNOB_HOT_BYTES     = 8,  /* global layout: bytes of the table head mirrored in LDS        */
 	FSM_HIP_KNOB_SEG           = 9,  /* LDS-DMA mode: bytes of each row per tile, 64 or 128 (0 auto)  */

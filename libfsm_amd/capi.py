@@ -1016,6 +1016,36 @@ def exec_multi_ids_device(dfas: Sequence["HipDfa"], jobs: Sequence[tuple], ids_m
         raise _oserr("fsm_hip_exec_multi_ids_device")
 
 
+class MultiPrepared:
+    """fsm_hip_multi_prepare / _launch / _prepared_free: a device-pointer submission put on the device once; launch() is
+    one kernel launch on the stream (capturable into a HIP graph).  jobs[q] = (d_base, d_off, n, d_end, d_bitmap, d_ids)."""
+
+    def __init__(self, dfas: Sequence["HipDfa"], jobs: Sequence[tuple], ids_mode: int = 0):
+        lib = load_library()
+        k = len(jobs)
+        arr = (MultiBatchIds * max(k, 1))()
+        for q, (b, o, n, e, m, i) in enumerate(jobs):
+            arr[q].base, arr[q].off, arr[q].n, arr[q].end_out, arr[q].accept_bitmap, arr[q].id_out = b or None, o or None, n, e or None, m or None, i or None
+        hs = (C.c_void_p * max(k, 1))(*[d._h for d in dfas])
+        self._keep = list(dfas)
+        self._p = C.c_void_p()
+        C.set_errno(0)
+        if lib.fsm_hip_multi_prepare(hs, arr, C.c_size_t(k), C.c_int(ids_mode), C.byref(self._p)) != 0:
+            raise _oserr("fsm_hip_multi_prepare")
+
+    def launch(self, stream: int = 0) -> None:
+        C.set_errno(0)
+        if load_library().fsm_hip_multi_launch(self._p, C.c_void_p(stream or None)) != 0:
+            raise _oserr("fsm_hip_multi_launch")
+
+    def close(self) -> None:
+        if self._p:
+            lib = load_library()
+            lib.fsm_hip_multi_prepared_free.restype = None
+            lib.fsm_hip_multi_prepared_free(self._p)
+            self._p = C.c_void_p()
+
+
 def multi_last_launches() -> int:
     lib = load_library()
     lib.fsm_hip_multi_last_launches.restype = C.c_uint

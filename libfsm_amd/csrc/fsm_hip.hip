@@ -1451,7 +1451,11 @@ extern "C" int fsm_hip_dfa_tune(struct fsm_hip_dfa *d, int knob, int value)
 		break;
 	case FSM_HIP_KNOB_WAVES: d->knob_waves = value; break;
 	case FSM_HIP_KNOB_BLOCKS_PER_CU: d->knob_blocks_per_cu = value; break;
-	case FSM_HIP_KNOB_EARLY_RETIRE: d->knob_early = value; break;
+	case FSM_HIP_KNOB_EARLY_RETIRE:
+		/* bit 128 is round 4's resource bound, kept for the test that pins the range rule: it LOSES bytes.  Not for a stray value */
+		if (value >= 0 && (value & 128) && getenv("FSM_HIP_TEST_KNOBS") == nullptr) { errno = EINVAL; return -1; }
+		d->knob_early = value;
+		break;
 	case FSM_HIP_KNOB_NOSKIP: d->knob_noskip = value; break;
 	case FSM_HIP_KNOB_RAGGED_ALIGN: break;   /* retired: segments start at the input's own first byte now */
 	case FSM_HIP_KNOB_PK_RMIN:

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <numeric>
 #include <vector>
 
@@ -199,6 +200,25 @@ bool fusable(const Plan *p, size_t n, uint64_t bytes, bool host)
 	return p->dense.size() <= MULTI_LDS_ENTRIES && n < ((size_t)1 << 31);
 }
 
+/* the automaton's side of fused job f: its plain table, byte classes, end states and (asked for) ids into the host block `pin`
+ * at the layout's offsets, the descriptor pointing at the same offsets of the device block `dev` */
+void fill_tables(unsigned char *pin, unsigned char *dev, const Lay &L, size_t f, const Plan *p, const std::vector<uint32_t> &fid, MultiJob &j)
+{
+	memcpy(pin + L.dense[f], p->dense.data(), p->dense.size() * 4u);
+	uint32_t *c4 = reinterpret_cast<uint32_t *>(pin + L.cls[f]);
+	for (unsigned w = 0; w < 64; w++)
+		c4[w] = (uint32_t)p->cls[4 * w] | ((uint32_t)p->cls[4 * w + 1] << 8) | ((uint32_t)p->cls[4 * w + 2] << 16) | ((uint32_t)p->cls[4 * w + 3] << 24);
+	memcpy(pin + L.fin[f], p->fin.data(), (size_t)p->S1 * 4u);
+	if (L.fid[f] != (size_t)-1) memcpy(pin + L.fid[f], fid.data(), (size_t)p->S1 * 4u);
+	memset(&j, 0, sizeof j);
+	j.fid = L.fid[f] != (size_t)-1 ? reinterpret_cast<const uint32_t *>(dev + L.fid[f]) : nullptr;
+	j.dense = reinterpret_cast<const uint32_t *>(dev + L.dense[f]);
+	j.cls4 = reinterpret_cast<const uint32_t *>(dev + L.cls[f]);
+	j.fin = reinterpret_cast<const uint32_t *>(dev + L.fin[f]);
+	j.C = p->C; j.S1 = p->S1; j.start = p->start; j.abs_min = p->abs_min;
+	j.lds_table = p->dense.size() <= MULTI_LDS_ENTRIES ? 1u : 0u;
+}
+
 /* one job as the entry points hand it over (ids: optional) */
 struct JobView {
 	const unsigned char *base;
@@ -284,18 +304,8 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const Job
 			const size_t q = fj[f];
 			const Plan *p = dfa_plan(dfa[q]);
 			const size_t n = b[q].n;
-			memcpy(cx.pin + L.dense[f], p->dense.data(), p->dense.size() * 4u);
-			uint32_t *c4 = reinterpret_cast<uint32_t *>(cx.pin + L.cls[f]);
-			for (unsigned w = 0; w < 64; w++)
-				c4[w] = (uint32_t)p->cls[4 * w] | ((uint32_t)p->cls[4 * w + 1] << 8) | ((uint32_t)p->cls[4 * w + 2] << 16) | ((uint32_t)p->cls[4 * w + 3] << 24);
-			memcpy(cx.pin + L.fin[f], p->fin.data(), (size_t)p->S1 * 4u);
-			if (L.fid[f] != (size_t)-1) memcpy(cx.pin + L.fid[f], fids[f].data(), (size_t)p->S1 * 4u);
 			MultiJob &j = jobs[f];
-			memset(&j, 0, sizeof j);
-			j.fid = L.fid[f] != (size_t)-1 ? reinterpret_cast<const uint32_t *>(cx.dev + L.fid[f]) : nullptr;
-			j.dense = reinterpret_cast<const uint32_t *>(cx.dev + L.dense[f]);
-			j.cls4 = reinterpret_cast<const uint32_t *>(cx.dev + L.cls[f]);
-			j.fin = reinterpret_cast<const uint32_t *>(cx.dev + L.fin[f]);
+			fill_tables(cx.pin, cx.dev, L, f, p, fids[f], j);
 			if (host) {
 				const size_t bytes = (size_t)b[q].off[n];
 				memcpy(cx.pin + L.off[f], b[q].off, (n + 1) * 8u);
@@ -316,9 +326,7 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const Job
 				j.limit = 0;              /* the kernel reads off[n] */
 			}
 			j.n = n;
-			j.C = p->C; j.S1 = p->S1; j.start = p->start; j.abs_min = p->abs_min;
 			j.tile0 = t0;
-			j.lds_table = p->dense.size() <= MULTI_LDS_ENTRIES ? 1u : 0u;
 			const uint32_t nt = (uint32_t)((n + MULTI_WAVES * 64u - 1u) / (MULTI_WAVES * 64u));
 			for (uint32_t t = 0; t < nt; t++) tile_job[t0 + t] = (uint32_t)f;
 			t0 += nt;
@@ -361,9 +369,10 @@ int run_device_group(int device, const struct fsm_hip_dfa *const *dfa, const Job
 	return 0;
 }
 
-int exec_multi(const struct fsm_hip_dfa *const *dfa, const JobView *b, int ids_mode, size_t k, bool host, hipStream_t stream)
+/* what every form of a submission checks before anything is launched; *ids_mode: ERROR -> EARLIEST once no job is ambiguous */
+int check_jobs(const struct fsm_hip_dfa *const *dfa, const JobView *b, int *ids_mode_io, size_t k, bool host)
 {
-	if (k == 0) { g_last_launches = 0; g_last_fused_jobs = 0; return 0; }
+	int ids_mode = *ids_mode_io;
 	if (dfa == nullptr || b == nullptr) { errno = EINVAL; return -1; }
 	bool want_ids = false;
 	for (size_t q = 0; q < k; q++) want_ids = want_ids || b[q].id_out != nullptr;
@@ -388,6 +397,14 @@ int exec_multi(const struct fsm_hip_dfa *const *dfa, const JobView *b, int ids_m
 			if (b[q].off[b[q].n] != 0 && b[q].base == nullptr) { errno = EINVAL; return -1; }
 		}
 	}
+	*ids_mode_io = ids_mode;
+	return 0;
+}
+
+int exec_multi(const struct fsm_hip_dfa *const *dfa, const JobView *b, int ids_mode, size_t k, bool host, hipStream_t stream)
+{
+	if (k == 0) { g_last_launches = 0; g_last_fused_jobs = 0; return 0; }
+	if (check_jobs(dfa, b, &ids_mode, k, host) != 0) return -1;
 	/* jobs by device (a submission usually has one) */
 	std::vector<int> devs;
 	for (size_t q = 0; q < k; q++) {
@@ -442,6 +459,133 @@ extern "C" int fsm_hip_exec_multi_ids_device(const struct fsm_hip_dfa *const *df
 {
 	const std::vector<JobView> v = views(b, k);
 	return exec_multi(dfa, k && b ? v.data() : nullptr, ids_mode, k, false, static_cast<hipStream_t>(hip_stream));
+}
+
+/*
+ * The PREPARED form: a submission of device-resident jobs whose descriptors, tile map and tables are put on the device ONCE.
+ * fsm_hip_multi_launch is then one kernel launch (plus one per job whose table is too big to fuse: its dfa's own device front)
+ * on the caller's stream -- no copy, no allocation, no wait: it can be captured into a HIP graph and replayed on whatever the
+ * jobs' buffers hold by then (reperf's loop over the same matcher, src/retest/reperf.c:772-784, for K matchers at once).
+ */
+struct fsm_hip_multi_prepared {
+	int device = 0, ids_mode = FSM_HIP_IDS_EARLIEST;
+	unsigned char *dev = nullptr;
+	size_t jobs_off = 0, tiles_off = 0;
+	uint32_t ntiles = 0;
+	unsigned fused = 0;
+	struct Single { const struct fsm_hip_dfa *dfa; JobView v; };
+	std::vector<Single> singles;
+};
+
+extern "C" int fsm_hip_multi_prepare(const struct fsm_hip_dfa *const *dfa, const struct fsm_hip_multi_batch_ids *b, size_t k, int ids_mode,
+	struct fsm_hip_multi_prepared **out)
+{
+	if (out == nullptr) { errno = EINVAL; return -1; }
+	*out = nullptr;
+	std::vector<JobView> v = views(b, k);
+	if (k != 0 && check_jobs(dfa, v.data(), &ids_mode, k, false) != 0) return -1;
+	for (size_t q = 1; q < k; q++)
+		if (dfa_device(dfa[q]) != dfa_device(dfa[0])) { errno = EINVAL; return -1; }      /* one stream, one device (fsm_hip_node_exec_multi shards) */
+	fsm_hip_multi_prepared *pp = new (std::nothrow) fsm_hip_multi_prepared;
+	if (pp == nullptr) { errno = ENOMEM; return -1; }
+	pp->ids_mode = ids_mode;
+	pp->device = k != 0 ? dfa_device(dfa[0]) : 0;
+	std::vector<size_t> fj;
+	for (size_t q = 0; q < k; q++) {
+		if (v[q].n == 0) continue;
+		if (fusable(dfa_plan(dfa[q]), v[q].n, 0, false)) fj.push_back(q);
+		else pp->singles.push_back({dfa[q], v[q]});
+	}
+	if (!fj.empty()) {
+		const size_t kf = fj.size();
+		uint64_t tiles = 0;
+		for (size_t q : fj) tiles += (v[q].n + MULTI_WAVES * 64u - 1u) / (MULTI_WAVES * 64u);
+		if (tiles > 0x7FFFFFFFu) { delete pp; errno = EINVAL; return -1; }
+		std::vector<std::vector<uint32_t>> fids(kf);
+		for (size_t f = 0; f < kf; f++)
+			if (v[fj[f]].id_out != nullptr && dfa_ids_by_state(dfa[fj[f]], ids_mode, fids[f], nullptr) != 0) { delete pp; return -1; }
+		Lay L;
+		size_t o = 0;
+		L.jobs = o; o += up16(kf * sizeof(MultiJob));
+		L.tiles = o; o += up16((size_t)tiles * 4u);
+		L.dense.resize(kf); L.cls.resize(kf); L.fin.resize(kf); L.fid.assign(kf, (size_t)-1);
+		for (size_t f = 0; f < kf; f++) {
+			const Plan *p = dfa_plan(dfa[fj[f]]);
+			L.dense[f] = o; o += up16(p->dense.size() * 4u);
+			L.cls[f] = o; o += 256u;
+			L.fin[f] = o; o += up16((size_t)p->S1 * 4u);
+			if (!fids[f].empty()) { L.fid[f] = o; o += up16((size_t)p->S1 * 4u); }
+		}
+		int prev = -1;
+		(void)hipGetDevice(&prev);
+		struct Restore { int prev, dev; ~Restore() { if (prev >= 0 && prev != dev) { int e = errno; (void)hipSetDevice(prev); errno = e; } } } restore{prev, pp->device};
+		hipError_t e = prev != pp->device ? hipSetDevice(pp->device) : hipSuccess;
+		std::vector<unsigned char> host(o);
+		if (e == hipSuccess) e = hipMalloc((void **)&pp->dev, o);
+		if (e != hipSuccess) { delete pp; errno = hip_errno_(e); return -1; }
+		MultiJob *jobs = reinterpret_cast<MultiJob *>(host.data() + L.jobs);
+		uint32_t *tile_job = reinterpret_cast<uint32_t *>(host.data() + L.tiles);
+		uint32_t t0 = 0;
+		for (size_t f = 0; f < kf; f++) {
+			const size_t q = fj[f];
+			MultiJob &j = jobs[f];
+			fill_tables(host.data(), pp->dev, L, f, dfa_plan(dfa[q]), fids[f], j);
+			j.base = v[q].base; j.off = v[q].off;
+			j.end_out = v[q].end_out; j.id_out = v[q].id_out; j.bitmap = v[q].accept_bitmap;
+			j.limit = 0;
+			j.n = v[q].n;
+			j.tile0 = t0;
+			const uint32_t nt = (uint32_t)((v[q].n + MULTI_WAVES * 64u - 1u) / (MULTI_WAVES * 64u));
+			for (uint32_t t = 0; t < nt; t++) tile_job[t0 + t] = (uint32_t)f;
+			t0 += nt;
+		}
+		e = hipMemcpy(pp->dev, host.data(), o, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { (void)hipFree(pp->dev); delete pp; errno = hip_errno_(e); return -1; }
+		pp->jobs_off = L.jobs; pp->tiles_off = L.tiles; pp->ntiles = (uint32_t)tiles; pp->fused = (unsigned)kf;
+	}
+	*out = pp;
+	return 0;
+}
+
+extern "C" int fsm_hip_multi_launch(const struct fsm_hip_multi_prepared *pp, void *hip_stream)
+{
+	if (pp == nullptr) { errno = EINVAL; return -1; }
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	if (prev != pp->device) MTRY(hipSetDevice(pp->device));
+	struct Restore { int prev, dev; ~Restore() { if (prev >= 0 && prev != dev) { int e = errno; (void)hipSetDevice(prev); errno = e; } } } restore{prev, pp->device};
+	unsigned launches = 0;
+	if (pp->ntiles != 0) {
+		hipLaunchKernelGGL(walk_multi, dim3(pp->ntiles), dim3(MULTI_WAVES * 64u), 0, s, reinterpret_cast<const MultiJob *>(pp->dev + pp->jobs_off),
+		                   reinterpret_cast<const uint32_t *>(pp->dev + pp->tiles_off));
+		MTRY(hipGetLastError());
+		launches++;
+	}
+	for (const auto &sg : pp->singles) {
+		const JobView &j = sg.v;
+		const int r = j.id_out == nullptr
+			? fsm_hip_exec_batch_offsets_device(sg.dfa, j.base, j.off, j.n, j.end_out, j.accept_bitmap, s)
+			: fsm_hip_exec_batch_packed_all_device(sg.dfa, j.base, FSM_HIP_META_OFF64, j.off, j.n, j.end_out, j.accept_bitmap, pp->ids_mode, j.id_out, nullptr, s);
+		if (r != 0) return -1;
+		launches++;
+	}
+	g_last_launches = launches;
+	g_last_fused_jobs = pp->fused;
+	return 0;
+}
+
+extern "C" void fsm_hip_multi_prepared_free(struct fsm_hip_multi_prepared *pp)
+{
+	if (pp == nullptr) return;
+	if (pp->dev != nullptr) {
+		int prev = -1;
+		(void)hipGetDevice(&prev);
+		if (prev != pp->device) (void)hipSetDevice(pp->device);
+		(void)hipFree(pp->dev);           /* (waits for the device: a launch still reading the block ends first) */
+		if (prev >= 0 && prev != pp->device) (void)hipSetDevice(prev);
+	}
+	delete pp;
 }
 
 extern "C" unsigned fsm_hip_multi_last_launches(void) { return g_last_launches.load(); }

@@ -722,6 +722,11 @@ def test_inputs_ending_just_below_the_resource_bound(hip, layout):
                     tl = torch.from_numpy(np.diff(off).astype(np.int32)).cuda()
                     end = torch.full((n,), 7, dtype=torch.int32, device="cuda")
                     for early in (-1, 33, 1 | 128, 33 | 128):
+                        if early >= 128:     # the byte-losing bound is a test aid: refused without the environment's say-so
+                            os.environ.pop("FSM_HIP_TEST_KNOBS", None)
+                            with pytest.raises(OSError):
+                                dfa.tune(hip.KNOB_EARLY_RETIRE, early)
+                            os.environ["FSM_HIP_TEST_KNOBS"] = "1"
                         dfa.tune(hip.KNOB_EARLY_RETIRE, early)
                         for form in ("off64", "off32", "len"):
                             end.fill_(7)

@@ -168,3 +168,66 @@ def test_many_dfa_device_front_fuses_big_jobs_of_small_automata(hip):
         assert np.array_equal(bits, want[q] != NO), q
     for d in dfas:
         d.close()
+
+
+@pytest.mark.gpu
+def test_prepared_many_dfa_submission_replays_from_a_hip_graph(hip):
+    """fsm_hip_multi_prepare puts descriptors, tile map and tables on the device once; fsm_hip_multi_launch is one kernel launch
+    with no copy, allocation or wait -- captured into a HIP graph and replayed on three different sets of lines in the same
+    buffers; end states, bitmap and ids against each dfa's own walk (reperf's repeat loop, src/retest/reperf.c:772-784, for
+    all the retest goldens' automata at once)."""
+    import torch
+    gs = [Golden(p) for p in _golden_paths("retest")]
+    K, n, L = len(gs), 700, 24
+    rng = np.random.RandomState(12)
+    dfas, jobs, keep = [], [], []
+    off = (np.arange(n + 1) * L).astype(np.int64)
+    for g in gs:
+        d = hip.HipDfa(g.flat, hip.DEFER_UPLOAD)
+        tb = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+        to = torch.from_numpy(off).cuda()
+        te = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        ti = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        tm = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        keep.append((tb, to, te, ti, tm))
+        dfas.append(d)
+        jobs.append((tb.data_ptr(), to.data_ptr(), n, te.data_ptr(), tm.data_ptr(), ti.data_ptr()))
+    pr = hip.MultiPrepared(dfas, jobs, 1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        pr.launch(st.cuda_stream)        # warm (nothing to warm: the launch is the kernel alone), then captured
+        st.synchronize()
+        assert hip.multi_last_launches() == 1 and hip.multi_last_fused_jobs() == K
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            pr.launch(st.cuda_stream)
+    for rep in range(3):
+        want, wid = [], []
+        for q, g in enumerate(gs):
+            seeds = g.strings() or [b"a"]
+            rows = rng.randint(97, 123, (n, L)).astype(np.uint8)
+            for i in range(0, n, 2):        # every other line starts with one of the record's own test strings
+                sd = seeds[rng.randint(len(seeds))][:L]
+                rows[i, :len(sd)] = np.frombuffer(sd, np.uint8)
+            one = hip.HipDfa(g.flat)
+            e, _ = one.exec_batch(rows)
+            ids = one.exec_batch_ids(rows, 1)
+            one.close()
+            want.append(e)
+            wid.append(ids)
+            keep[q][0][:n * L].copy_(torch.from_numpy(rows.reshape(-1)))
+            keep[q][2].fill_(7)
+            keep[q][3].fill_(7)
+            keep[q][4].fill_(-1)
+        torch.cuda.synchronize()
+        gr.replay()
+        torch.cuda.synchronize()
+        for q in range(K):
+            tb, to, te, ti, tm = keep[q]
+            assert np.array_equal(te.cpu().numpy().view(np.uint32), want[q]), (rep, q)
+            bits = np.unpackbits(tm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+            assert np.array_equal(bits, want[q] != NO), (rep, q)
+            assert np.array_equal(ti.cpu().numpy().view(np.uint32), wid[q]), (rep, q)
+    pr.close()
+    for d in dfas:
+        d.close()
