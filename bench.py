@@ -663,6 +663,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FSM_BENCH_FORCE_DIST=1: a ONE-rank run goes the N > 1 way all the same (RCCL communicator, the bitmap all-gather overlapped with
+    # the next walk, the reductions, 1.25e8 inputs): the multi-GPU path on the real stack wherever only one GPU is at hand
+    dist_on = world > 1 or bool(os.environ.get("FSM_BENCH_FORCE_DIST"))
     if world != a.gpus:   # the launcher's word wins; the line reports what ran
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} ranks", file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
@@ -671,8 +674,11 @@ def main():
     backend = os.environ.get("FSM_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:     # forced: no launcher set the rendezvous up
+            for k_, v_ in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k_, v_)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -681,7 +687,7 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     import libfsm_amd as hip
     hip.load_library()
@@ -694,11 +700,11 @@ def main():
     def default_n(wl):
         if wl == "c5":
             return 10_000_000
-        return 125_000_000 if world > 1 else 100_000_000   # N > 1: configs[3] = 1e9 inputs over 8 GPUs
+        return 125_000_000 if dist_on else 100_000_000   # N > 1: configs[3] = 1e9 inputs over 8 GPUs
 
     requested = a.n if a.n > 0 else default_n(a.workload)
     n_total = requested if a.scaling == "strong" else requested * world
-    n_total = n_total // (64 * world) * (64 * world) if world > 1 else n_total   # equal shards of whole bitmap words
+    n_total = n_total // (64 * world) * (64 * world) if dist_on else n_total   # equal shards of whole bitmap words
     first, n = shard_range(n_total, rank, world)
     free, _total = torch.cuda.mem_get_info()
     need = n * (L + 4) + n // 8 + (1 << 30)
@@ -706,7 +712,7 @@ def main():
     if need > free * 0.92:  # shrink rather than risk an OOM strike; reported in config
         n = int((free * 0.92 - (1 << 30)) // (L + 5)) // 64 * 64
         shrunk = True
-        assert world == 1, "the shard does not fit this GPU"
+        assert not dist_on, "the shard does not fit this GPU"
     buf_all = torch.empty((n, L), dtype=torch.uint8, device="cuda")
     end_all = torch.empty(n, dtype=torch.int32, device="cuda")
 
@@ -743,8 +749,8 @@ def main():
 
         # N > 1: the all-gather of step k's bitmap runs on RCCL's stream while step k+1's walk kernel runs
         # (two bitmap / gather buffers); every gather is waited for before the timed region ends.
-        bms = [bm, torch.zeros_like(bm)] if world > 1 else [bm]
-        gats = [torch.empty(nwords * world, dtype=torch.int64, device="cuda") for _ in range(2)] if world > 1 else [None]
+        bms = [bm, torch.zeros_like(bm)] if dist_on else [bm]
+        gats = [torch.empty(nwords * world, dtype=torch.int64, device="cuda") for _ in range(2)] if dist_on else [None]
         pending = [None, None]
         tick = [0]
         kernel_ms = []
@@ -752,13 +758,13 @@ def main():
         def step(record):
             k = tick[0] % len(bms)
             tick[0] += 1
-            if world > 1 and pending[k] is not None:
+            if dist_on and pending[k] is not None:
                 pending[k].wait()      # stream-level: the gather that last read this bitmap buffer is done
                 pending[k] = None
             dfa.exec_batch_device(buf.data_ptr(), L, n_, end.data_ptr(), bms[k].data_ptr(), stream=stream)
             if record:
                 kernel_ms.append(dfa.last_kernel_ms())  # HIP events on the launch stream, around the walk kernel only
-            if world > 1:
+            if dist_on:
                 # the match bitmap over RCCL/xGMI (libfsm_amd/shard.py)
                 pending[k] = dist.all_gather_into_tensor(gats[k], bms[k], async_op=True)
 
@@ -775,7 +781,7 @@ def main():
             step(False)
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -783,17 +789,17 @@ def main():
             step(True)
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
         acc_t = (end != -1).sum().to(torch.int64).reshape(1)
         rank_kms = None
-        if world > 1:
+        if dist_on:
             dist.all_reduce(acc_t)
             mine = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
             allk = [torch.zeros_like(mine) for _ in range(world)]
@@ -840,7 +846,7 @@ def main():
                 "table_layout": info["layout_name"], "table_bytes": info["table_bytes"], "lds_bytes_per_block": info["lds_bytes"],
                 "waves_per_block": info["waves_per_block"],
                 "sharding": (f"{world} contiguous index ranges ({a.scaling} scaling); RCCL all-gather of each step's accept bitmap, overlapped with the next step's walk"
-                             if world > 1 else "single GPU"),
+                             if dist_on else "single GPU"),
                 "accepted_inputs": int(acc_t.item()),
             },
             **({"multi_gpu": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), **rccl_identity(torch), "walk_kernel_ms_per_rank": rank_kms,
@@ -870,7 +876,7 @@ def main():
                                        "input byte where the record-as-state walk made 0.33 -- and is bound by instruction issue now, not by gathers and not by HBM "
                                        "(profiles/r06b_c5_lazy_pmc_rows2.txt; DESIGN.md section 3): the fraction of HBM peak is reported for uniformity, "
                                        "roofline.gather_ceiling gives the memory-side denominator")
-        if world == 1 and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
+        if not dist_on and with_cpu and not a.no_cpu_baseline and a.cpu_sample != 0:
             sample = a.cpu_sample if a.cpu_sample > 0 else (400_000 if wl == "c2" else 100_000)
             idx = sample_indices(n_, sample)
             tidx = torch.from_numpy(idx).cuda()
@@ -888,10 +894,10 @@ def main():
         # the full-N compare, for the main workload of a default run -- and for c5 wherever it runs (round 4: its
         # table is 1 GB as the oracle keeps it and the cpu_baseline leg has built it already; 1e7 rows take the walker's threads
         # about a minute)
-        if world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5") \
+        if not dist_on and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5") \
                 and wl != a.workload and over_budget():
             res["full_parity_skipped"] = "time budget (FSM_BENCH_TIME_BUDGET) reached: sample parity only"
-        elif world == 1 and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5"):
+        elif not dist_on and variant is None and not a.no_full_parity and with_cpu and not a.no_cpu_baseline and (a.full_parity or wl == a.workload or wl == "c5"):
             res["full_parity"] = full_parity(torch, flat, buf, end, n_, L)
             if res["full_parity"]["mismatches"]:
                 res["value"] = None
@@ -915,7 +921,7 @@ def main():
         res["_buf"] = (buf, bm)
         # a digest of all n end states: a variant run over the same inputs (noskip, loadskip) must reproduce the main run's
         res["_digest"] = (int(end.to(torch.int64).sum().item()), int((end.to(torch.int64) * (torch.arange(n_, device="cuda", dtype=torch.int64) % 1000003 + 1)).sum().item()),
-                          int(acc_t.item())) if world == 1 else None
+                          int(acc_t.item())) if not dist_on else None
         dfa.close()
         return res
 
@@ -1274,7 +1280,7 @@ def main():
     progress("main workload %s" % a.workload)
     main_res = run(a.workload)
     subs = []
-    if world == 1 and a.subs == "auto" and a.n == 0 and not shrunk:
+    if not dist_on and a.subs == "auto" and a.n == 0 and not shrunk:
         plan = []
         if a.workload == "c3":
             plan.append(("c3", "noskip", None))
@@ -1321,7 +1327,7 @@ def main():
             main_res["multi_dfa_bulk"] = {"error": repr(e)[:300]}
         # leave the main workload's inputs in the buffer for the stream probe below
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.barrier()   # leave together with rank 0, which still probes the stream rate and prints
             dist.destroy_process_group()
         return
@@ -1347,7 +1353,7 @@ def main():
             res[k] = main_res[k]
     # N = 1 on a box that shows several GPUs: the C multi-device front on all of them, in a subprocess of its own
     # (its failure must not cost the line above); FSM_BENCH_NODE_FRONT=1 forces it on a one-GPU box
-    if world == 1 and a.subs == "auto" and a.n == 0 and (torch.cuda.device_count() > 1 or os.environ.get("FSM_BENCH_NODE_FRONT")):
+    if not dist_on and a.subs == "auto" and a.n == 0 and (torch.cuda.device_count() > 1 or os.environ.get("FSM_BENCH_NODE_FRONT")):
         import subprocess
         del buf, bm
         buf_all = end_all = None
@@ -1367,7 +1373,7 @@ def main():
         if any(s.get("parity_vs_cpu_sample") == "MISMATCH" for s in subs):
             res["value"] = None
     emit(res)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

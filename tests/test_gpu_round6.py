@@ -231,3 +231,27 @@ def test_prepared_many_dfa_submission_replays_from_a_hip_graph(hip):
     pr.close()
     for d in dfas:
         d.close()
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_goes_the_multi_gpu_way_over_rccl():
+    """FSM_BENCH_FORCE_DIST=1: bench.py's N > 1 path -- an RCCL communicator, the accept bitmap's all-gather overlapped with the next
+    walk, the reductions, the multi_gpu record -- with ONE rank on this box's GPU: the real collective library under the real call
+    pattern (two ranks over gloo: tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu; RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--workload", "c2", "--inputs", "1048576"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 4 and r["value"] > 0
+    assert r["multi_gpu"]["backend"] == "nccl" and r["multi_gpu"]["world_size"] == 1 and r["multi_gpu"].get("rccl_version")
+    assert abs(r["config"]["accepted_inputs"] - 1048576 // 8) < 64
+    assert "RCCL all-gather" in r["config"]["sharding"]
