@@ -78,7 +78,8 @@ walk_multi(const MultiJob *jobs, const uint32_t *tile_job)
 	typedef u32x4m __attribute__((aligned(1))) u32x4_any;
 	typedef const u32x4_any __attribute__((address_space(1))) *g_chunkp;
 	__shared__ uint32_t cls4[64];
-	__shared__ uint16_t tab[MULTI_LDS_ENTRIES];
+	__shared__ uint16_t cls2[256];                  /* LDS tables: 2 * class of a byte -- the byte offset of its column in a row of u16 */
+	__shared__ uint16_t tab[MULTI_LDS_ENTRIES];     /* ... and per (state, class) the BYTE offset of the next state's row */
 	const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_job[blockIdx.x]);
 	const MultiJob &j = jobs[ji];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -86,9 +87,14 @@ walk_multi(const MultiJob *jobs, const uint32_t *tile_job)
 	const bool in_lds = j.lds_table != 0u;
 	const g_u32p dense = (g_u32p)(uintptr_t)j.dense, fin = (g_u32p)(uintptr_t)j.fin, fid = (g_u32p)(uintptr_t)j.fid;
 	const g_u64p off = (g_u64p)(uintptr_t)j.off;
-	if (tid < 64u) cls4[tid] = ((g_u32p)(uintptr_t)j.cls4)[tid];
+	if (tid < 64u) {
+		const uint32_t w4 = ((g_u32p)(uintptr_t)j.cls4)[tid];
+		cls4[tid] = w4;
+#pragma unroll
+		for (int q = 0; q < 4; q++) cls2[tid * 4u + (uint32_t)q] = (uint16_t)(((w4 >> (8 * q)) & 0xffu) * 2u);
+	}
 	if (in_lds)
-		for (uint32_t e = tid; e < S1 * C; e += MULTI_WAVES * 64u) tab[e] = (uint16_t)(dense[e] * C);   /* row offset of the next state */
+		for (uint32_t e = tid; e < S1 * C; e += MULTI_WAVES * 64u) tab[e] = (uint16_t)(dense[e] * C * 2u);   /* (S1 * C <= 16 384 entries: < 2^16 bytes) */
 	__syncthreads();
 
 	const uint64_t tile = blockIdx.x - j.tile0, i = tile * (MULTI_WAVES * 64u) + tid;
@@ -96,33 +102,57 @@ walk_multi(const MultiJob *jobs, const uint32_t *tile_job)
 	uint64_t beg = 0, len = 0;
 	if (valid) { beg = off[i]; len = off[i + 1] - beg; }
 	const uint64_t limit = j.limit != 0u ? j.limit : off[j.n];
-	const uint32_t unit = in_lds ? C : 1u;            /* the walk's state: row offset (LDS) or state index (global table) */
+	const uint32_t unit = in_lds ? C * 2u : 1u;       /* the walk's state: byte offset of its row (LDS) or state index (global table) */
 	const uint32_t absorbing = j.abs_min * unit;
 	uint32_t s = j.start * unit;
 	const uint64_t p = reinterpret_cast<uint64_t>(j.base) + beg;
+	typedef const uint16_t __attribute__((address_space(3))) *l_u16p;
+	const uint32_t cls2_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)cls2;
+	const uint32_t tab_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)tab;
 
-	for (uint64_t t = 0; __any(t < len && s < absorbing); t += 16u) {
-		if (!(t < len && s < absorbing)) continue;
-		const uint32_t cnt = len - t < 16u ? (uint32_t)(len - t) : 16u;
+	for (uint64_t t = 0;; t += 16u) {
+		const bool live = t < len && s < absorbing;
+		if (!__any(live)) break;
+		const uint32_t cnt = !live ? 0u : len - t < 16u ? (uint32_t)(len - t) : 16u;
 		u32x4m w = {0u, 0u, 0u, 0u};
-		if (beg + t + 16u <= limit) {
-			w = *(g_chunkp)(p + t);
-		} else {
-			uint32_t d[4] = {0u, 0u, 0u, 0u};
-			for (uint32_t k = 0; k < cnt; k++) d[k >> 2] |= (uint32_t)((g_u8p)(p + t))[k] << ((k & 3u) * 8u);
-			w = u32x4m{d[0], d[1], d[2], d[3]};
+		if (live) {
+			if (beg + t + 16u <= limit) {
+				w = *(g_chunkp)(p + t);
+			} else {
+				uint32_t d[4] = {0u, 0u, 0u, 0u};
+				for (uint32_t k = 0; k < cnt; k++) d[k >> 2] |= (uint32_t)((g_u8p)(p + t))[k] << ((k & 3u) * 8u);
+				w = u32x4m{d[0], d[1], d[2], d[3]};
+			}
 		}
+		if (in_lds) {
+			/* two LDS reads per byte: the byte's column offset (state-independent: all sixteen asked for at once), then the row */
+			uint32_t c2[16];
 #pragma unroll
-		for (int k = 0; k < 16; k++) {
-			if ((uint32_t)k < cnt) {
-				const uint32_t b = byte_at(w, k);
-				const uint32_t c = (cls4[b >> 2] >> ((b & 3u) * 8u)) & 0xffu;
-				if (in_lds) s = (uint32_t)tab[s + c];
-				else s = dense[(uint64_t)s * C + c];
+			for (int k = 0; k < 16; k++) c2[k] = *(l_u16p)(uintptr_t)(cls2_at + byte_at(w, k) * 2u);
+			if (__all(cnt == 16u || cnt == 0u)) {          /* whole chunks everywhere (lines of one length, the middle of long ones) */
+				uint32_t sn = s;
+#pragma unroll
+				for (int k = 0; k < 16; k++) sn = *(l_u16p)(uintptr_t)(tab_at + sn + c2[k]);
+				s = cnt != 0u ? sn : s;
+			} else {
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					const uint32_t sn = *(l_u16p)(uintptr_t)(tab_at + s + c2[k]);
+					s = (uint32_t)k < cnt ? sn : s;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				if ((uint32_t)k < cnt) {
+					const uint32_t b = byte_at(w, k);
+					const uint32_t c = (cls4[b >> 2] >> ((b & 3u) * 8u)) & 0xffu;
+					s = dense[(uint64_t)s * C + c];
+				}
 			}
 		}
 	}
-	const uint32_t fs = in_lds ? s / C : s;
+	const uint32_t fs = in_lds ? s / (C * 2u) : s;
 	uint32_t end = FSM_HIP_NO_MATCH;
 	if (valid) end = fin[fs];
 	typedef uint32_t __attribute__((address_space(1))) *g_u32w;
