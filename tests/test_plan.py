@@ -541,8 +541,8 @@ def test_lazy_form_of_literal_sets(built):
     """The lazy walk's image for literal sets of several shapes: full depth-1 / depth-2 levels (the shape of configs[4]),
     sparse ones, anchored and unanchored: exact on every reachable (state, carried, byte)."""
     rng = np.random.RandomState(23)
-    shapes = [(b"abcd", 400, 3, 9, 2), (b"abcdefgh", 3000, 4, 10, 2), (b"abcdefghijklmnop", 4000, 5, 9, 0),
-              (b"abcdefghijklmnopqrstuvwxyz0123456789", 3000, 6, 12, 2), (b"ab", 60, 2, 8, 2)]
+    shapes = [(b"abcd", 400, 3, 9, 2), (b"abcdefgh", 1500, 4, 10, 2), (b"abcdefghijklmnop", 2000, 5, 9, 0),
+              (b"abcdefghijklmnopqrstuvwxyz0123456789", 1500, 6, 12, 2), (b"ab", 60, 2, 8, 2)]
     seen_lazy = 0
     for alpha_b, nw, lo, hi, flags in shapes:
         alpha = np.frombuffer(alpha_b, np.uint8)

@@ -15,7 +15,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "libfsm_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-UNITS = ["kern_tiny", "kern_lds", "kern_comb", "kern_glob", "kern_glob16"]
+UNITS = ["kern_tiny", "kern_lds", "kern_comb", "kern_glob", "kern_glob16", "multi"]
 # --strict also holds the kernels the bench lines run to a bound on SGPR spills (scalar registers parked in vector lanes: an
 # instruction each way, and in the short-lines kernels they sat inside the per-tile path -- 23-37 of them in round 4)
 HOT_SSPILL = [("walk_lines32<", 8), ("walk_ldsdma<CombSelfPol, 128, 2, 768>", 0), ("walk_ldsdma<Tiny5Pol, 128, 2, 1024>", 0),
