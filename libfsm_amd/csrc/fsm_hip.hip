@@ -661,12 +661,10 @@ static LaunchCfg pick_cfg(const fsm_hip_dfa *d, bool fast_ok, uint64_t stride, i
 		 * are not a multiple of 64, unaligned rows, resumed walks -- one input per lane slot with lane refill (walk_lazy_lines) */
 		c.mode = IN_LAZY_LINES;
 		c.lazy_abs = d->plan.lazy_img[11] != 0 || resumed;   /* a resumed input may start in DEAD */
-		/* THREE slots per lane, two whole chunks per slot and turn: on every line mix but 8-16 bytes faster than two slots with two
-		 * or four chunks (0-1024 bytes 607 against 557 GB/s, 8-64 bytes 427 / 395, all 64 bytes 863 / 732, all 1 KiB 773 / 739:
-		 * profiles/r09k_*) -- which that round's first half chose between by the mean length, on the device where the host could
-		 * not know it.  FSM_HIP_KNOB_ROWS = 2 brings the two-slot forms back (FSM_HIP_KNOB_NB = 2 / 4 chunks: A/B). */
+		/* THREE slots per lane, three whole chunks per slot and turn (kern_glob.hip has the numbers).  FSM_HIP_KNOB_ROWS = 2 brings the
+		 * two-slot forms back (FSM_HIP_KNOB_NB = 2 / 4 chunks), FSM_HIP_KNOB_NB = 2 / 4 at three slots the two- and four-chunk turns: A/B */
 		c.lazy_rows = d->knob_rows == 2 ? 2 : 3;
-		c.nb = c.lazy_rows == 3 || d->knob_nb == 2 ? 2 : 4;
+		c.nb = c.lazy_rows == 3 ? (d->knob_nb == 2 || d->knob_nb == 4 ? d->knob_nb : 3) : d->knob_nb == 2 ? 2 : 4;
 		c.waves = 16;
 		/* the table + the wavefronts' queues: all the LDS there is (plan.cpp leaves at least FSMHIP_LAZY_QBYTES: 112 entries per
 		 * wavefront; the kernel uses up to 128) */

@@ -224,7 +224,7 @@ __device__ __forceinline__ void lazy_careful(const LazyCtx &cx, const uint32_t *
 /* ROWS inputs per lane (independent chains: the instruction-level parallelism a second workgroup per CU would give),
  * NB 16-byte chunks per row in flight.  a.tile_ctr != NULL: the wavefronts claim their tiles of 64 * ROWS inputs from that
  * counter (zeroed on the launch stream) instead of striding: the tail of the persistent grid balances to one tile. */
-template <bool ABS, int ROWS, int NB, bool NT = false>
+template <bool ABS, int ROWS, int NB, bool NT = false, int SHQ = 8>
 __global__ void __launch_bounds__(1024)
 walk_lazy(const WalkArgs a)
 {
@@ -285,20 +285,20 @@ walk_lazy(const WalkArgs a)
 				 * owns no bit has bit 31 set in its sh entry: the chunk then goes the exact way too).  Left to itself the compiler
 				 * ORs the sixteen shifts in at the block's END and keeps them alive for it: the registers of a third input per lane. */
 #pragma unroll
-				for (int h = 0; h < 2; h++) {
-					uint32_t sh[ROWS][8];
+				for (int h = 0; h < 16 / SHQ; h++) {
+					uint32_t sh[ROWS][SHQ];
 #pragma unroll
 					for (int r = 0; r < ROWS; r++)
 #pragma unroll
-						for (int k = 0; k < 8; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], 8 * h + k) * 4u);
+						for (int k = 0; k < SHQ; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(cur[j][r], SHQ * h + k) * 4u);
 #pragma unroll
 					for (int r = 0; r < ROWS; r++) {
 #pragma unroll
-						for (int k = 0; k < 8; k++) bacc[r] |= sh[r][k];
+						for (int k = 0; k < SHQ; k++) bacc[r] |= sh[r][k];
 						__asm__ volatile("" : "+v"(bacc[r]));
 					}
 #pragma unroll
-					for (int k = 0; k < 8; k++)
+					for (int k = 0; k < SHQ; k++)
 #pragma unroll
 						for (int r = 0; r < ROWS; r++) lazy_step<ABS>(cx, st[r], sh[r][k], bacc[r]);
 				}
@@ -358,7 +358,10 @@ walk_lazy(const WalkArgs a)
  * measured 12 % slower on 1 KiB lines).
  * Measured, 4 GB of lines on the 1e5-literal automaton (tests/tools/c5_lines_probe.py; round 5's kernel: 523 / 243 GB/s on the
  * first two): two slots per lane, four chunks a turn: 0-1024 bytes 559, 8-64 bytes 363 (410 at two chunks a turn); all 1024 bytes
- * 754, all 64 bytes 770.  THREE slots, two chunks a turn (shipped; 32 bytes of scratch outside the step block): 607 / 427 / 773 / 863.
+ * 754, all 64 bytes 770.  THREE slots, two chunks a turn (32 bytes of scratch outside the step block): 607 / 427 / 773 / 863.
+ * SHQ = the byte -> shift lookups taken at once per slot (8: the fixed-stride kernel's; it keeps 8 x ROWS registers busy).  Two at
+ * a time gives 24 registers back, a THIRD chunk per turn fits without scratch, and a turn's head and chunk wait are paid per 48
+ * bytes of an input: 664 / 486 / 843 / 955 (shipped: <ABS, 3, 3, 2>; profiles/r09u_*).
  * Built and dropped: a slot changing inputs in MID-turn (its next input chosen at the turn's head, the old input's queue entry
  * pre-written and the state ORed in at the step its whole chunks end): no idle slots, but the bookkeeping costs more than
  * they did -- 565 / 308 on the same two mixes, 618 on 64-byte lines.
@@ -368,7 +371,7 @@ walk_lazy(const WalkArgs a)
 #define FSMHIP_LAZY_QMIN 112u                                          /* queue entries per wavefront that plan.cpp guarantees */
 #define FSMHIP_LAZY_QBYTES (16u * FSMHIP_LAZY_QMIN * 16u)              /* 16 wavefronts x 112 entries x 16 bytes = 28 KiB of LDS behind the table */
 
-template <bool ABS, int ROWS, int NB>
+template <bool ABS, int ROWS, int NB, int SHQ = 8>
 __global__ void __launch_bounds__(1024)
 walk_lazy_lines(const WalkArgs a)
 {
@@ -566,20 +569,20 @@ walk_lazy_lines(const WalkArgs a)
 #pragma unroll
 			for (int r = 0; r < ROWS; r++) bacc[r] = 0u;
 #pragma unroll
-			for (int h = 0; h < 2; h++) {
-				uint32_t sh[ROWS][8];
+			for (int h = 0; h < 16 / SHQ; h++) {
+				uint32_t sh[ROWS][SHQ];
 #pragma unroll
 				for (int r = 0; r < ROWS; r++)
 #pragma unroll
-					for (int k = 0; k < 8; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(w[0][r], 8 * h + k) * 4u);
+					for (int k = 0; k < SHQ; k++) sh[r][k] = *(lazy_u32_p)(uintptr_t)(byte_of(w[0][r], SHQ * h + k) * 4u);
 #pragma unroll
 				for (int r = 0; r < ROWS; r++) {
 #pragma unroll
-					for (int k = 0; k < 8; k++) bacc[r] |= sh[r][k];
+					for (int k = 0; k < SHQ; k++) bacc[r] |= sh[r][k];
 					__asm__ volatile("" : "+v"(bacc[r]));
 				}
 #pragma unroll
-				for (int k = 0; k < 8; k++)
+				for (int k = 0; k < SHQ; k++)
 #pragma unroll
 					for (int r = 0; r < ROWS; r++) lazy_step<ABS, false>(cx, st[r], sh[r][k], bacc[r]);
 			}

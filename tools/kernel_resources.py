@@ -21,9 +21,9 @@ UNITS = ["kern_tiny", "kern_lds", "kern_comb", "kern_glob", "kern_glob16", "mult
 HOT_SSPILL = [("walk_lines32<", 8), ("walk_ldsdma<CombSelfPol, 128, 2, 768>", 0), ("walk_ldsdma<Tiny5Pol, 128, 2, 1024>", 0),
               ("walk_direct<Comb256Pol, 8, 1>", 0), ("walk_lazy<", 8), ("walk_ragged<Tiny5Pol, 768, 0>", 24), ("walk_ragged<CombSelfPol, 768, 0>", 48),
               ("walk_direct<Glob16Pol, 4, 2>", 0)]
-# the one kernel that is allowed scratch: three slots per lane with 32 bytes of it (outside the step block) measured faster than two slots
-# without on every line mix but 8-16 bytes (profiles/r09k_*)
-SCRATCH_OK = [("walk_lazy_lines<false, 3, 2>", 64), ("walk_lazy_lines<true, 3, 2>", 64)]
+# the one kernel that is allowed scratch: the A/B form of the lines kernel with the lookups eight at a time (32 bytes outside the step
+# block; the shipped <., 3, 3, 2> has none)
+SCRATCH_OK = [("walk_lazy_lines<false, 3, 2, 8>", 64), ("walk_lazy_lines<true, 3, 2, 8>", 64)]
 
 
 def demangle(names):
