@@ -22,7 +22,8 @@ enum {
 	                                  * -1 auto.  (4 was walk_packed -- a lane owning a byte range across input boundaries:
 	                                  * correct, slower than walk_generic everywhere, removed in round 4; the record is
 	                                  * profiles/r03s_packed_* and tools/packed_model.py) */
-	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8)       */
+	FSM_HIP_KNOB_NB            = 2,  /* direct mode: 16-byte chunks in flight per lane (4 or 8); the lazy lines kernel (walk_lazy.h): whole chunks per
+	                                  * slot and turn, 2 or 4 instead of the default 3 (A/B aid) */
 	FSM_HIP_KNOB_ROWS          = 3,  /* the lazy walk (walk_lazy.h): inputs / slots per lane -- 0 auto (3), 2 = round 5's shape (A/B aid; ignored elsewhere) */
 	FSM_HIP_KNOB_WAVES         = 4,  /* wavefronts per workgroup (1..16)                              */
 	FSM_HIP_KNOB_BLOCKS_PER_CU = 5,  /* persistent grid = CUs * this                                  */
